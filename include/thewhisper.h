@@ -1,0 +1,165 @@
+/*
+ * thewhisper.h - C ABI of libthewhisper_gfx950.so, the MI355X (gfx950 / CDNA4) Whisper hot path.
+ *
+ * The reference (TheStageAI/TheWhisper) has NO C ABI / FFI for this path: its NVIDIA backend hands
+ * the whole computation to a Python model object (Hugging Face `WhisperForConditionalGeneration`, or
+ * the closed TensorRT wheel) under `ASRPipeline` (R:thestage_speechkit/nvidia/asr_pipeline.py:47-60),
+ * and its Apple backend swaps encoder/decoder modules under the same object
+ * (R:thestage_speechkit/apple/model.py:601-614).  Each entry point below therefore cites the
+ * Python-level interface it replaces (R: = /root/reference, HF: = transformers 5.15.0).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no C++/torch types.  Every function returns 0 on success
+ *    and a negative TW_E* code on failure; tw_last_error() returns a human-readable message.
+ *  - "dev" pointers are HIP device pointers owned by the caller (torch); the library never frees
+ *    them and never retains them after the call returns, except nothing: weights are COPIED
+ *    (converted / repacked) into the context at tw_load_weight time.
+ *  - "host" pointers are ordinary host memory.  Calls that return host data synchronise the
+ *    stream; all other calls only enqueue work on `stream` (a hipStream_t passed as void*; pass
+ *    torch's current stream so ordering with torch ops is automatic; NULL = default stream).
+ *  - A context is bound to one device, owns its workspace / KV arenas (allocated in tw_create, freed
+ *    in tw_destroy) and is NOT thread-safe: one context per (GPU, worker thread).
+ *  - Batch entries ("streams") of one call occupy slots 0..B-1 of the context, B <= max_batch.
+ */
+#ifndef THEWHISPER_H
+#define THEWHISPER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TW_VERSION_STRING "thewhisper-gfx950 0.1.0"
+
+/* element types of caller buffers and of the context's compute mode */
+enum { TW_F32 = 0, TW_BF16 = 1, TW_F16 = 2 };
+
+/* error codes */
+enum {
+  TW_OK = 0,
+  TW_EINVAL = -1,   /* bad argument / unsupported configuration */
+  TW_EHIP = -2,     /* HIP runtime error (message has the hipError string) */
+  TW_ESTATE = -3,   /* call order violated (e.g. decode before encode / weights not finalized) */
+  TW_ENOMEM = -4,
+  TW_ENAME = -5     /* unknown weight name or shape mismatch */
+};
+
+#define TW_MAX_ALIGN_HEADS 32
+
+typedef struct tw_ctx tw_ctx;
+
+/* Model + capacity description.  Mirrors the fields of HF `WhisperConfig` that the hot path uses
+ * (HF:models/whisper/configuration_whisper.py) plus the per-context capacities. */
+typedef struct tw_config {
+  int32_t d_model;
+  int32_t enc_layers;
+  int32_t dec_layers;
+  int32_t heads;                 /* head_dim = d_model / heads must be 64 */
+  int32_t ffn;
+  int32_t vocab;
+  int32_t n_mels;
+  int32_t source_positions;      /* T: encoder frames per chunk = 50 * chunk_seconds (<= 1500).  When
+                                    < 1500 the 1500-row positional table is linearly interpolated at
+                                    load time exactly like patch_hf_model
+                                    (R:thestage_speechkit/nvidia/asr_pipeline.py:15-27). */
+  int32_t target_positions;      /* decoder positions, 448 */
+  int32_t max_batch;             /* concurrent streams per call */
+  int32_t dtype;                 /* TW_BF16 (production) or TW_F32 (strict-parity mode) */
+  int32_t n_align_heads;         /* alignment heads for word timestamps (generation_config.alignment_heads) */
+  int32_t align_heads[2 * TW_MAX_ALIGN_HEADS]; /* (layer, head) pairs */
+  int32_t device;                /* HIP device ordinal */
+  int32_t use_graph;             /* 1: replay the decode step from a captured hipGraph */
+} tw_config;
+
+/* Options of one greedy decode (A9/A10).  Mirrors what HF's generate derives from
+ * generation_config + the three Whisper logits processors
+ * (HF:models/whisper/generation_whisper.py:1774-1812, HF:generation/logits_process.py:1816-2047). */
+typedef struct tw_greedy_opts {
+  int32_t eos_id;
+  int32_t pad_id;
+  int32_t max_new_tokens;
+  int32_t min_new_tokens;        /* MinNewTokensLength: eos masked until this many new tokens */
+  int32_t max_length;            /* prompt + new tokens cap (generation_config.max_length) */
+  int32_t timestamps;            /* 1: apply WhisperTimeStampLogitsProcessor */
+  int32_t no_timestamps_id;      /* timestamp_begin = no_timestamps_id + 1 */
+  int32_t max_initial_timestamp_index; /* < 0: unset */
+  int32_t n_begin_suppress;
+  const int32_t* begin_suppress; /* host */
+  int32_t n_suppress;
+  const int32_t* suppress;       /* host */
+  int32_t want_alignment;        /* 1: record alignment-head cross-attention rows for tw_token_timestamps */
+} tw_greedy_opts;
+
+const char* tw_version(void);
+/* ctx may be NULL: returns the message of the last failed tw_create on this thread. */
+const char* tw_last_error(const tw_ctx* ctx);
+
+/* Replaces: model construction under ASRPipeline.__init__
+ * (R:thestage_speechkit/nvidia/asr_pipeline.py:47-60). */
+int tw_create(const tw_config* cfg, tw_ctx** out);
+int tw_destroy(tw_ctx* ctx);
+
+/* Replaces: `from_pretrained` weight materialisation (R:thestage_speechkit/nvidia/asr_pipeline.py:58-60).
+ * `name` is the HF state_dict key (layout table in SURVEY.md section 8b), `dev_ptr` a contiguous device tensor
+ * of element type `dtype` (TW_F32/TW_BF16/TW_F16) and shape `shape[ndim]`.  The tensor is converted to
+ * the context dtype and copied/repacked; the caller may free it afterwards. */
+int tw_load_weight(tw_ctx* ctx, const char* name, const void* dev_ptr, int32_t dtype, int32_t ndim,
+                   const int64_t* shape, void* stream);
+/* Checks that every tensor arrived, interpolates the encoder positions (A0), folds the 1/8
+ * query scale into q_proj, builds fused QKV blocks. */
+int tw_finalize_weights(tw_ctx* ctx, void* stream);
+
+/* A1.  Replaces: WhisperFeatureExtractor._torch_extract_fbank_features
+ * (HF:models/whisper/feature_extraction_whisper.py:135-168) as called from the ASR pipeline
+ * (HF:pipelines/automatic_speech_recognition.py:67-72).
+ * pcm_dev: float32 [B, pcm_stride] mono 16 kHz; n_valid_host[b] (may be NULL = n_samples) samples
+ * are real, the rest up to n_samples is treated as zero padding; out_dev: [B, n_mels, n_samples/160]
+ * of element type out_dtype (TW_F32 or the context dtype). */
+int tw_logmel(tw_ctx* ctx, const float* pcm_dev, int64_t pcm_stride, const int32_t* n_valid_host, int32_t B,
+              int32_t n_samples, void* out_dev, int32_t out_dtype, void* stream);
+
+/* A2-A4.  Replaces: WhisperEncoder.forward (HF:models/whisper/modeling_whisper.py:540-646).
+ * mel_dev: [B, n_mels, 2T] of mel_dtype.  The encoder output is kept inside the context (slots
+ * 0..B-1); if out_hidden_dev != NULL it is also written there as [B, T, d_model] in out_dtype. */
+int tw_encode(tw_ctx* ctx, const void* mel_dev, int32_t mel_dtype, int32_t B, void* out_hidden_dev,
+              int32_t out_dtype, void* stream);
+
+/* A5.  Replaces: the lazy cross-attention K/V projection + EncoderDecoderCache.is_updated
+ * (HF:models/whisper/modeling_whisper.py:312-335).  Projects the context's encoder output of slots
+ * 0..B-1 into the per-layer cross K/V arenas, once per chunk. */
+int tw_cross_kv(tw_ctx* ctx, int32_t B, void* stream);
+
+/* A6-A8.  Replaces: WhisperDecoder.forward + proj_out for ONE new token per stream
+ * (HF:models/whisper/modeling_whisper.py:649-795, :1080).  tw_decoder_reset rewinds the self-attention
+ * cache to position 0.  ids_host: int32 [B].  logits_dev: float32 [B, vocab] or NULL. */
+int tw_decoder_reset(tw_ctx* ctx, int32_t B, void* stream);
+int tw_decode_step(tw_ctx* ctx, int32_t B, const int32_t* ids_host, float* logits_dev, void* stream);
+
+/* A9+A10.  Replaces: GenerationMixin._sample (HF:generation/utils.py:2783-2946) for num_beams=1,
+ * do_sample=False with Whisper's logits processors, as invoked by
+ * WhisperGenerationMixin.generate_with_fallback (HF:models/whisper/generation_whisper.py:1027).
+ * prompt_host: int32 [B, n_prompt]; out_ids_host: int32 [B, max_length] receives prompt + generated
+ * tokens padded with pad_id; out_len_host[0] = common sequence length (HF pads finished rows).
+ * Requires tw_encode + tw_cross_kv for the same B. */
+int tw_generate_greedy(tw_ctx* ctx, int32_t B, const int32_t* prompt_host, int32_t n_prompt,
+                       const tw_greedy_opts* opts, int32_t* out_ids_host, int32_t* out_len_host, void* stream);
+
+/* A11.  Replaces: _extract_token_timestamps + _median_filter + _dynamic_time_warping
+ * (HF:models/whisper/generation_whisper.py:241-381, :43-61, :64-115) on the alignment rows recorded by the
+ * last tw_generate_greedy(want_alignment=1).  num_frames_host[b] = valid mel frames (crop to //2);
+ * out_ts_host: float32 [B, seq_len] seconds (seq_len = out_len of the greedy call). */
+int tw_token_timestamps(tw_ctx* ctx, int32_t B, int32_t n_prompt, int32_t seq_len, const int32_t* num_frames_host,
+                        double time_precision, float* out_ts_host, void* stream);
+/* Debug/parity access: copy the recorded alignment rows [B, n_align_heads, n_rows, T] (float32) to host. */
+int tw_get_alignment(tw_ctx* ctx, int32_t B, int32_t n_rows, float* out_host, void* stream);
+
+/* Per-stage device timings (milliseconds, HIP events on the call's stream) of the most recent call
+ * of each kind: [0]=logmel [1]=encode [2]=cross_kv [3]=greedy loop [4]=token_timestamps; also the
+ * number of decode steps of the last greedy call in steps_out.  Used by bench.py for the roofline. */
+int tw_last_timings(tw_ctx* ctx, float* ms_out5, int32_t* steps_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* THEWHISPER_H */

@@ -1,0 +1,848 @@
+// C ABI (include/thewhisper.h) + context + kernel orchestration for the MI355X Whisper hot path.
+// Host-side control only: every FLOP/byte of the path runs in the gfx950 kernels of k_*.hip.
+#include "../../include/thewhisper.h"
+#include "tw_common.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <set>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct LayerW {
+  void *ln1_g = nullptr, *ln1_b = nullptr;  // self_attn_layer_norm
+  void *wqkv = nullptr, *bqkv = nullptr;    // [3d, d], [3d] (q rows pre-scaled by 1/8, k bias = 0)
+  void *wo = nullptr, *bo = nullptr;
+  void *lnx_g = nullptr, *lnx_b = nullptr;  // encoder_attn_layer_norm (decoder)
+  void *wq_c = nullptr, *bq_c = nullptr;    // cross q (pre-scaled)
+  void *wkv_c = nullptr, *bkv_c = nullptr;  // [2d, d] cross k|v
+  void *wo_c = nullptr, *bo_c = nullptr;
+  void *ln2_g = nullptr, *ln2_b = nullptr;  // final_layer_norm
+  void *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
+};
+
+}  // namespace
+
+struct tw_ctx {
+  tw_config cfg{};
+  int dtype = 1;
+  size_t esz = 2;
+  int d = 0, H = 0, ffn = 0, V = 0, T = 0, Tp = 0, P = 0, C = 0, Bmax = 0, Le = 0, Ld = 0, n_mels = 0, Ha = 0;
+  std::string err;
+  std::vector<void*> allocs;
+  hipStream_t own_stream = nullptr;
+
+  // weights
+  void *conv1_w = nullptr, *conv1_b = nullptr, *conv2_w = nullptr, *conv2_b = nullptr;
+  void *enc_pos_raw = nullptr, *enc_pos = nullptr, *enc_ln_g = nullptr, *enc_ln_b = nullptr;
+  void *tok_emb = nullptr, *dec_pos = nullptr, *dec_ln_g = nullptr, *dec_ln_b = nullptr;
+  std::vector<LayerW> enc, dec;
+  std::set<std::string> loaded;
+  bool finalized = false;
+
+  // log-mel
+  LogmelTables lm{};
+  float* logspec_ws = nullptr; size_t logspec_cap = 0;
+  unsigned* lm_max = nullptr;
+  int* n_valid_dev = nullptr;
+
+  // encoder workspace
+  void *melT = nullptr, *h1 = nullptr, *xa = nullptr, *xb = nullptr, *lnbuf = nullptr, *qbuf = nullptr, *kbuf = nullptr,
+       *vtbuf = nullptr, *attn = nullptr, *ffnh = nullptr, *enc_out = nullptr;
+  int encoded_B = 0, cross_B = 0;
+
+  // decoder state
+  void *self_k = nullptr, *self_v = nullptr, *cross_k = nullptr, *cross_v = nullptr;
+  void *dx0 = nullptr, *dx1 = nullptr, *dq = nullptr, *datt = nullptr, *dh = nullptr;
+  float* logits = nullptr;
+  float* align = nullptr;
+  int* align_slot = nullptr;  // [Ld][H]
+  int *seq = nullptr, *cur_ids = nullptr, *finished = nullptr, *last_ts = nullptr;
+  DecState* stt = nullptr;
+  int* begin_suppress_dev = nullptr; int* suppress_dev = nullptr;
+  int* h_pinned = nullptr;  // pinned host scratch: finished ring [8][Bmax] + misc
+  hipEvent_t ring_ev[8]{};
+  int last_seq_len = 0, last_n_prompt = 0;
+  int enc_pos_rows = 0;  // rows of the encoder positional table as loaded (1500 upstream)
+
+  // dtw workspace
+  float *zbuf = nullptr, *mat = nullptr, *out_ts = nullptr;
+  signed char* trace = nullptr;
+  int* n_cols = nullptr;
+
+  // graph replay of one decode step
+  hipGraphExec_t step_graph = nullptr;
+  std::string step_graph_key;
+
+  // timing
+  hipEvent_t ev0[5]{}, ev1[5]{};
+  bool ev_valid[5]{};
+  int last_steps = 0;
+};
+
+namespace {
+
+int fail(tw_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf; else g_create_error = buf;
+  return code;
+}
+
+#define HIPCHK(c, expr)                                                                       \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      return fail((c), TW_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+template <typename P>
+int dalloc(tw_ctx* c, P** p, size_t bytes, bool zero) {
+  void* q = nullptr;
+  if (bytes == 0) bytes = 16;
+  hipError_t e = hipMalloc(&q, bytes);
+  if (e != hipSuccess) return fail(c, TW_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  c->allocs.push_back(q);
+  if (zero) {
+    e = hipMemset(q, 0, bytes);
+    if (e != hipSuccess) return fail(c, TW_EHIP, "hipMemset failed: %s", hipGetErrorString(e));
+  }
+  *p = reinterpret_cast<P*>(q);
+  return TW_OK;
+}
+#define ALLOC(c, ptr, bytes, zero)                   \
+  do {                                               \
+    int _r = dalloc((c), &(ptr), (bytes), (zero));   \
+    if (_r != TW_OK) return _r;                      \
+  } while (0)
+
+inline hipStream_t pick_stream(tw_ctx* c, void* s) { return s ? reinterpret_cast<hipStream_t>(s) : c->own_stream; }
+
+char* at(void* base, size_t elems, size_t esz) { return reinterpret_cast<char*>(base) + elems * esz; }
+
+// slaney mel bank, float64 (HF:audio_utils.py:638-729), then cast to float32 as the reference does
+void build_mel_bank(int n_mels, std::vector<float>& bank, std::vector<int>& lo, std::vector<int>& hi) {
+  const int nb = 201;
+  auto hz2mel = [](double f) { return f >= 1000.0 ? 15.0 + std::log(f / 1000.0) * (27.0 / std::log(6.4)) : 3.0 * f / 200.0; };
+  auto mel2hz = [](double m) { return m >= 15.0 ? 1000.0 * std::exp((std::log(6.4) / 27.0) * (m - 15.0)) : 200.0 * m / 3.0; };
+  const double mmin = hz2mel(0.0), mmax = hz2mel(8000.0);
+  std::vector<double> ff(n_mels + 2);
+  for (int i = 0; i < n_mels + 2; ++i) ff[i] = mel2hz(mmin + (mmax - mmin) * (double)i / (double)(n_mels + 1));
+  bank.assign((size_t)nb * n_mels, 0.f);
+  lo.assign(n_mels, nb);
+  hi.assign(n_mels, 0);
+  for (int k = 0; k < nb; ++k) {
+    const double fk = 8000.0 * (double)k / (double)(nb - 1);
+    for (int m = 0; m < n_mels; ++m) {
+      const double down = -(ff[m] - fk) / (ff[m + 1] - ff[m]);
+      const double up = (ff[m + 2] - fk) / (ff[m + 2] - ff[m + 1]);
+      double v = std::fmax(0.0, std::fmin(down, up));
+      v *= 2.0 / (ff[m + 2] - ff[m]);
+      const float vf = (float)v;
+      bank[(size_t)k * n_mels + m] = vf;
+      if (vf != 0.f) {
+        if (k < lo[m]) lo[m] = k;
+        if (k + 1 > hi[m]) hi[m] = k + 1;
+      }
+    }
+  }
+  for (int m = 0; m < n_mels; ++m)
+    if (hi[m] == 0) lo[m] = 0;
+}
+
+int upload(tw_ctx* c, void* dst, const void* src, size_t bytes) {
+  HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return TW_OK;
+}
+
+void tic(tw_ctx* c, int i, hipStream_t st) { (void)hipEventRecord(c->ev0[i], st); }
+void toc(tw_ctx* c, int i, hipStream_t st) { (void)hipEventRecord(c->ev1[i], st); c->ev_valid[i] = true; }
+
+}  // namespace
+
+extern "C" {
+
+const char* tw_version(void) { return TW_VERSION_STRING; }
+
+const char* tw_last_error(const tw_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int tw_destroy(tw_ctx* c) {
+  if (!c) return TW_OK;
+  (void)hipDeviceSynchronize();
+  if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
+  for (void* p : c->allocs) (void)hipFree(p);
+  if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  for (int i = 0; i < 5; ++i) {
+    if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
+    if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
+  }
+  for (int i = 0; i < 8; ++i)
+    if (c->ring_ev[i]) (void)hipEventDestroy(c->ring_ev[i]);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+  return TW_OK;
+}
+
+int tw_create(const tw_config* cfg, tw_ctx** out) {
+  if (!cfg || !out) return fail(nullptr, TW_EINVAL, "tw_create: null argument");
+  *out = nullptr;
+  if (cfg->heads <= 0 || cfg->d_model != cfg->heads * 64)
+    return fail(nullptr, TW_EINVAL, "head_dim must be 64 (d_model=%d heads=%d)", cfg->d_model, cfg->heads);
+  if (cfg->dtype != TW_BF16 && cfg->dtype != TW_F32) return fail(nullptr, TW_EINVAL, "dtype must be TW_BF16 or TW_F32");
+  if (cfg->d_model % 64 || cfg->ffn % 64 || cfg->d_model > 1280)
+    return fail(nullptr, TW_EINVAL, "d_model/ffn must be multiples of 64 and d_model <= 1280");
+  if (cfg->max_batch < 1 || cfg->max_batch > 16) return fail(nullptr, TW_EINVAL, "max_batch must be in [1,16]");
+  if (cfg->source_positions < 8 || cfg->source_positions > 1500 || cfg->target_positions < 8 || cfg->target_positions > 511)
+    return fail(nullptr, TW_EINVAL, "source_positions must be in [8,1500], target_positions in [8,511]");
+  if (cfg->n_align_heads < 0 || cfg->n_align_heads > TW_MAX_ALIGN_HEADS) return fail(nullptr, TW_EINVAL, "bad n_align_heads");
+  if (cfg->n_mels < 1 || cfg->n_mels > 256) return fail(nullptr, TW_EINVAL, "bad n_mels");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, TW_EHIP, "no HIP device available (the MI355X path has no CPU fallback)");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, TW_EINVAL, "device %d out of range", cfg->device);
+  if (hipSetDevice(cfg->device) != hipSuccess) return fail(nullptr, TW_EHIP, "hipSetDevice failed");
+
+  tw_ctx* c = new tw_ctx();
+  c->cfg = *cfg;
+  c->dtype = cfg->dtype;
+  c->esz = cfg->dtype == TW_BF16 ? 2 : 4;
+  c->d = cfg->d_model; c->H = cfg->heads; c->ffn = cfg->ffn; c->V = cfg->vocab;
+  c->T = cfg->source_positions; c->Tp = (c->T + 63) / 64 * 64; c->P = cfg->target_positions;
+  c->n_mels = cfg->n_mels; c->C = (cfg->n_mels + 63) / 64 * 64;
+  c->Bmax = cfg->max_batch; c->Le = cfg->enc_layers; c->Ld = cfg->dec_layers; c->Ha = cfg->n_align_heads;
+  auto bail = [&](int r) { g_create_error = c->err; tw_destroy(c); return r; };
+#define CALLOC(ptr, bytes, zero) do { int _r = dalloc(c, &(ptr), (bytes), (zero)); if (_r != TW_OK) return bail(_r); } while (0)
+#define CHIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { fail(c, TW_EHIP, "%s: %s", #expr, hipGetErrorString(_e)); return bail(TW_EHIP); } } while (0)
+  CHIP(init_decode_kernels());
+  CHIP(hipStreamCreate(&c->own_stream));
+  for (int i = 0; i < 5; ++i) { CHIP(hipEventCreate(&c->ev0[i])); CHIP(hipEventCreate(&c->ev1[i])); }
+  for (int i = 0; i < 8; ++i) CHIP(hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming));
+  CHIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), sizeof(int) * (8 * 16 + 64), hipHostMallocDefault));
+
+  const size_t e = c->esz;
+  const size_t d = c->d, H = c->H, F = c->ffn, V = c->V, T = c->T, Tp = c->Tp, P = c->P, C = c->C, B = c->Bmax;
+  // ---- weights ----
+  CALLOC(c->conv1_w, d * 3 * C * e, true);
+  CALLOC(c->conv1_b, d * e, true);
+  CALLOC(c->conv2_w, d * 3 * d * e, true);
+  CALLOC(c->conv2_b, d * e, true);
+  CALLOC(c->enc_pos_raw, (size_t)1500 * d * 4, true);
+  CALLOC(c->enc_pos, T * d * e, true);
+  CALLOC(c->enc_ln_g, d * e, true);
+  CALLOC(c->enc_ln_b, d * e, true);
+  CALLOC(c->tok_emb, V * d * e, true);
+  CALLOC(c->dec_pos, P * d * e, true);
+  CALLOC(c->dec_ln_g, d * e, true);
+  CALLOC(c->dec_ln_b, d * e, true);
+  c->enc.resize(c->Le);
+  c->dec.resize(c->Ld);
+  auto alloc_layer = [&](LayerW& L, bool decoder) -> int {
+    int r;
+#define LA(ptr, n) if ((r = dalloc(c, &(ptr), (n) * e, true)) != TW_OK) return r
+    LA(L.ln1_g, d); LA(L.ln1_b, d); LA(L.wqkv, 3 * d * d); LA(L.bqkv, 3 * d); LA(L.wo, d * d); LA(L.bo, d);
+    LA(L.ln2_g, d); LA(L.ln2_b, d); LA(L.w1, F * d); LA(L.b1, F); LA(L.w2, d * F); LA(L.b2, d);
+    if (decoder) {
+      LA(L.lnx_g, d); LA(L.lnx_b, d); LA(L.wq_c, d * d); LA(L.bq_c, d); LA(L.wkv_c, 2 * d * d); LA(L.bkv_c, 2 * d);
+      LA(L.wo_c, d * d); LA(L.bo_c, d);
+    }
+#undef LA
+    return TW_OK;
+  };
+  for (auto& L : c->enc) { int r = alloc_layer(L, false); if (r != TW_OK) return bail(r); }
+  for (auto& L : c->dec) { int r = alloc_layer(L, true); if (r != TW_OK) return bail(r); }
+
+  // ---- log-mel tables ----
+  {
+    std::vector<double> tw(400), win(400);
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int j = 0; j < 400; ++j) { tw[j] = std::cos(two_pi * j / 400.0); win[j] = 0.5 - 0.5 * std::cos(two_pi * j / 400.0); }
+    std::vector<float> bank; std::vector<int> lo, hi;
+    build_mel_bank(c->n_mels, bank, lo, hi);
+    double *dtw_ = nullptr, *dwin = nullptr; float* dbank = nullptr; int *dlo = nullptr, *dhi = nullptr;
+    CALLOC(dtw_, 400 * 8, false); CALLOC(dwin, 400 * 8, false); CALLOC(dbank, bank.size() * 4, false);
+    CALLOC(dlo, lo.size() * 4, false); CALLOC(dhi, hi.size() * 4, false);
+    CHIP(hipMemcpy(dtw_, tw.data(), 400 * 8, hipMemcpyHostToDevice));
+    CHIP(hipMemcpy(dwin, win.data(), 400 * 8, hipMemcpyHostToDevice));
+    CHIP(hipMemcpy(dbank, bank.data(), bank.size() * 4, hipMemcpyHostToDevice));
+    CHIP(hipMemcpy(dlo, lo.data(), lo.size() * 4, hipMemcpyHostToDevice));
+    CHIP(hipMemcpy(dhi, hi.data(), hi.size() * 4, hipMemcpyHostToDevice));
+    c->lm = LogmelTables{dtw_, dwin, dbank, dlo, dhi};
+    c->logspec_cap = B * (size_t)c->n_mels * (2 * T);
+    CALLOC(c->logspec_ws, c->logspec_cap * 4, false);
+    CALLOC(c->lm_max, B * 4, true);
+    CALLOC(c->n_valid_dev, B * 4, true);
+  }
+  // ---- encoder workspace ----
+  CALLOC(c->melT, B * (2 * T + 2) * C * e, true);
+  CALLOC(c->h1, B * (2 * T + 2) * d * e, true);   // pad rows 0 and 2T+1 of every clip stay zero
+  CALLOC(c->xa, B * T * d * e, false);
+  CALLOC(c->xb, B * T * d * e, false);
+  CALLOC(c->lnbuf, B * T * d * e, false);
+  CALLOC(c->qbuf, B * T * d * e, false);
+  CALLOC(c->kbuf, B * T * d * e, false);
+  CALLOC(c->vtbuf, B * H * 64 * Tp * e, true);      // key padding [T, Tp) stays zero
+  CALLOC(c->attn, B * T * d * e, false);
+  CALLOC(c->ffnh, B * T * F * e, false);
+  CALLOC(c->enc_out, B * T * d * e, false);
+  // ---- decoder state ----
+  const size_t Ld = c->Ld;
+  CALLOC(c->self_k, Ld * B * P * d * e, true);
+  CALLOC(c->self_v, Ld * B * P * d * e, true);
+  CALLOC(c->cross_k, Ld * B * T * d * e, false);
+  CALLOC(c->cross_v, Ld * B * T * d * e, false);
+  CALLOC(c->dx0, B * d * e, true); CALLOC(c->dx1, B * d * e, true); CALLOC(c->dq, B * d * e, true);
+  CALLOC(c->datt, B * d * e, true); CALLOC(c->dh, B * F * e, true);
+  CALLOC(c->logits, B * V * 4, true);
+  const size_t Ha = c->Ha > 0 ? c->Ha : 1;
+  CALLOC(c->align, B * Ha * P * T * 4, true);
+  CALLOC(c->align_slot, Ld * H * 4, false);
+  {
+    std::vector<int> slots(Ld * H, -1);
+    for (int j = 0; j < c->Ha; ++j) {
+      const int l = cfg->align_heads[2 * j], h = cfg->align_heads[2 * j + 1];
+      if (l < 0 || l >= (int)Ld || h < 0 || h >= (int)H) { fail(c, TW_EINVAL, "alignment head (%d,%d) out of range", l, h); return bail(TW_EINVAL); }
+      slots[(size_t)l * H + h] = j;
+    }
+    CHIP(hipMemcpy(c->align_slot, slots.data(), slots.size() * 4, hipMemcpyHostToDevice));
+  }
+  CALLOC(c->seq, B * P * 4, true); CALLOC(c->cur_ids, B * 4, true); CALLOC(c->finished, B * 4, true);
+  CALLOC(c->last_ts, B * 4, true); CALLOC(c->stt, sizeof(DecState), true);
+  CALLOC(c->begin_suppress_dev, 64 * 4, true); CALLOC(c->suppress_dev, 1024 * 4, true);
+  // ---- dtw workspace ----
+  CALLOC(c->zbuf, B * Ha * P * T * 4, false);
+  CALLOC(c->mat, B * P * T * 4, false);
+  CALLOC(c->trace, B * (P + 1) * (T + 1), false);
+  CALLOC(c->out_ts, B * (P + 1) * 4, false);
+  CALLOC(c->n_cols, B * 4, true);
+#undef CALLOC
+#undef CHIP
+  *out = c;
+  return TW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weights
+// ---------------------------------------------------------------------------------------------
+int tw_load_weight(tw_ctx* c, const char* name_c, const void* src, int32_t sdt, int32_t ndim, const int64_t* shape,
+                   void* stream) {
+  if (!c || !name_c || !src || !shape) return fail(c, TW_EINVAL, "tw_load_weight: null argument");
+  if (sdt != TW_F32 && sdt != TW_BF16 && sdt != TW_F16) return fail(c, TW_EINVAL, "unsupported source dtype %d", sdt);
+  hipStream_t st = pick_stream(c, stream);
+  const std::string name(name_c);
+  const int d = c->d, F = c->ffn;
+  long long numel = 1;
+  for (int i = 0; i < ndim; ++i) numel *= shape[i];
+  auto want = [&](std::initializer_list<long long> s) -> bool {
+    if ((int)s.size() != ndim) return false;
+    int i = 0;
+    for (long long v : s) if (shape[i++] != v) return false;
+    return true;
+  };
+  auto conv = [&](void* dst, float scale) -> int {
+    HIPCHK(c, launch_convert(c->dtype, sdt, src, dst, numel, scale, st));
+    c->loaded.insert(name);
+    return TW_OK;
+  };
+  auto bad_shape = [&]() { return fail(c, TW_ENAME, "shape mismatch for %s", name_c); };
+
+  if (name == "proj_out.weight") return TW_OK;  // tied to embed_tokens (HF:models/whisper/modeling_whisper.py:965)
+  if (name == "model.encoder.conv1.weight") {
+    if (!want({d, c->n_mels, 3})) return bad_shape();
+    HIPCHK(c, launch_conv_weight_reorder(c->dtype, sdt, src, c->conv1_w, d, c->n_mels, c->C, st));
+    c->loaded.insert(name);
+    return TW_OK;
+  }
+  if (name == "model.encoder.conv2.weight") {
+    if (!want({d, d, 3})) return bad_shape();
+    HIPCHK(c, launch_conv_weight_reorder(c->dtype, sdt, src, c->conv2_w, d, d, d, st));
+    c->loaded.insert(name);
+    return TW_OK;
+  }
+  if (name == "model.encoder.conv1.bias") return want({d}) ? conv(c->conv1_b, 1.f) : bad_shape();
+  if (name == "model.encoder.conv2.bias") return want({d}) ? conv(c->conv2_b, 1.f) : bad_shape();
+  if (name == "model.encoder.embed_positions.weight") {
+    if (ndim != 2 || shape[1] != d || shape[0] > 1500) return bad_shape();
+    HIPCHK(c, launch_convert(TW_F32, sdt, src, c->enc_pos_raw, numel, 1.f, st));
+    c->loaded.insert(name);
+    c->enc_pos_rows = (int)shape[0];
+    return TW_OK;
+  }
+  if (name == "model.encoder.layer_norm.weight") return want({d}) ? conv(c->enc_ln_g, 1.f) : bad_shape();
+  if (name == "model.encoder.layer_norm.bias") return want({d}) ? conv(c->enc_ln_b, 1.f) : bad_shape();
+  if (name == "model.decoder.embed_tokens.weight") return want({c->V, d}) ? conv(c->tok_emb, 1.f) : bad_shape();
+  if (name == "model.decoder.embed_positions.weight") {
+    if (ndim != 2 || shape[1] != d || shape[0] < c->P) return bad_shape();
+    numel = (long long)c->P * d;
+    return conv(c->dec_pos, 1.f);
+  }
+  if (name == "model.decoder.layer_norm.weight") return want({d}) ? conv(c->dec_ln_g, 1.f) : bad_shape();
+  if (name == "model.decoder.layer_norm.bias") return want({d}) ? conv(c->dec_ln_b, 1.f) : bad_shape();
+
+  // per-layer tensors: model.{encoder|decoder}.layers.{i}.<rest>
+  bool is_dec = false;
+  size_t pos = std::string::npos;
+  const std::string pe = "model.encoder.layers.", pd = "model.decoder.layers.";
+  if (name.compare(0, pe.size(), pe) == 0) pos = pe.size();
+  else if (name.compare(0, pd.size(), pd) == 0) { pos = pd.size(); is_dec = true; }
+  if (pos == std::string::npos) return fail(c, TW_ENAME, "unknown weight name %s", name_c);
+  const size_t dot = name.find('.', pos);
+  if (dot == std::string::npos) return fail(c, TW_ENAME, "unknown weight name %s", name_c);
+  const int li = std::atoi(name.substr(pos, dot - pos).c_str());
+  const std::string rest = name.substr(dot + 1);
+  std::vector<LayerW>& Ls = is_dec ? c->dec : c->enc;
+  if (li < 0 || li >= (int)Ls.size()) return fail(c, TW_ENAME, "layer index out of range in %s", name_c);
+  LayerW& L = Ls[li];
+  const size_t e = c->esz;
+  const float qs = 0.125f;  // head_dim^-0.5 for head_dim 64, exact in bf16: folded into q_proj (HF scales q before QK^T, :309)
+  const bool isw = want({d, d}), isb = want({d});
+  if (rest == "self_attn_layer_norm.weight") return isb ? conv(L.ln1_g, 1.f) : bad_shape();
+  if (rest == "self_attn_layer_norm.bias") return isb ? conv(L.ln1_b, 1.f) : bad_shape();
+  if (rest == "final_layer_norm.weight") return isb ? conv(L.ln2_g, 1.f) : bad_shape();
+  if (rest == "final_layer_norm.bias") return isb ? conv(L.ln2_b, 1.f) : bad_shape();
+  if (rest == "self_attn.q_proj.weight") return isw ? conv(L.wqkv, qs) : bad_shape();
+  if (rest == "self_attn.q_proj.bias") return isb ? conv(L.bqkv, qs) : bad_shape();
+  if (rest == "self_attn.k_proj.weight") return isw ? conv(at(L.wqkv, (size_t)d * d, e), 1.f) : bad_shape();
+  if (rest == "self_attn.v_proj.weight") return isw ? conv(at(L.wqkv, (size_t)2 * d * d, e), 1.f) : bad_shape();
+  if (rest == "self_attn.v_proj.bias") return isb ? conv(at(L.bqkv, (size_t)2 * d, e), 1.f) : bad_shape();
+  if (rest == "self_attn.out_proj.weight") return isw ? conv(L.wo, 1.f) : bad_shape();
+  if (rest == "self_attn.out_proj.bias") return isb ? conv(L.bo, 1.f) : bad_shape();
+  if (rest == "fc1.weight") return want({F, d}) ? conv(L.w1, 1.f) : bad_shape();
+  if (rest == "fc1.bias") return want({F}) ? conv(L.b1, 1.f) : bad_shape();
+  if (rest == "fc2.weight") return want({d, F}) ? conv(L.w2, 1.f) : bad_shape();
+  if (rest == "fc2.bias") return isb ? conv(L.b2, 1.f) : bad_shape();
+  if (is_dec) {
+    if (rest == "encoder_attn_layer_norm.weight") return isb ? conv(L.lnx_g, 1.f) : bad_shape();
+    if (rest == "encoder_attn_layer_norm.bias") return isb ? conv(L.lnx_b, 1.f) : bad_shape();
+    if (rest == "encoder_attn.q_proj.weight") return isw ? conv(L.wq_c, qs) : bad_shape();
+    if (rest == "encoder_attn.q_proj.bias") return isb ? conv(L.bq_c, qs) : bad_shape();
+    if (rest == "encoder_attn.k_proj.weight") return isw ? conv(L.wkv_c, 1.f) : bad_shape();
+    if (rest == "encoder_attn.v_proj.weight") return isw ? conv(at(L.wkv_c, (size_t)d * d, e), 1.f) : bad_shape();
+    if (rest == "encoder_attn.v_proj.bias") return isb ? conv(at(L.bkv_c, (size_t)d, e), 1.f) : bad_shape();
+    if (rest == "encoder_attn.out_proj.weight") return isw ? conv(L.wo_c, 1.f) : bad_shape();
+    if (rest == "encoder_attn.out_proj.bias") return isb ? conv(L.bo_c, 1.f) : bad_shape();
+  }
+  return fail(c, TW_ENAME, "unknown weight name %s", name_c);
+}
+
+int tw_finalize_weights(tw_ctx* c, void* stream) {
+  if (!c) return TW_EINVAL;
+  hipStream_t st = pick_stream(c, stream);
+  const size_t expect = 4 + 1 + 2 + (size_t)c->Le * 15 + 2 + 2 + (size_t)c->Ld * 24;
+  if (c->loaded.size() != expect) {
+    return fail(c, TW_ESTATE, "tw_finalize_weights: %zu of %zu tensors loaded", c->loaded.size(), expect);
+  }
+  const int n_old = c->enc_pos_rows;  // rows of the positional table as loaded
+  if (c->T > n_old) return fail(c, TW_EINVAL, "source_positions %d exceeds the positional table (%d rows)", c->T, n_old);
+  // A0: patch_hf_model (R:thestage_speechkit/nvidia/asr_pipeline.py:15-27)
+  HIPCHK(c, launch_interp_positions(c->dtype, TW_F32, c->enc_pos_raw, c->enc_pos, n_old, c->T, c->d, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  c->finalized = true;
+  return TW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// A1 log-mel
+// ---------------------------------------------------------------------------------------------
+int tw_logmel(tw_ctx* c, const float* pcm, int64_t pcm_stride, const int32_t* n_valid_host, int32_t B, int32_t n_samples,
+              void* out, int32_t out_dtype, void* stream) {
+  if (!c || !pcm || !out) return fail(c, TW_EINVAL, "tw_logmel: null argument");
+  if (B < 1 || B > c->Bmax) return fail(c, TW_EINVAL, "tw_logmel: B=%d outside [1,%d]", B, c->Bmax);
+  if (n_samples < 400 || n_samples % 160 != 0) return fail(c, TW_EINVAL, "n_samples must be a multiple of 160 and >= 400");
+  if ((size_t)B * c->n_mels * (n_samples / 160) > c->logspec_cap)
+    return fail(c, TW_EINVAL, "tw_logmel: n_samples=%d exceeds the context capacity (%d frames)", n_samples, 2 * c->T);
+  if (out_dtype != TW_F32 && out_dtype != c->dtype) return fail(c, TW_EINVAL, "out_dtype must be TW_F32 or the context dtype");
+  hipStream_t st = pick_stream(c, stream);
+  const int* nv = nullptr;
+  if (n_valid_host) {
+    memcpy(c->h_pinned + 128, n_valid_host, sizeof(int) * B);
+    HIPCHK(c, hipMemcpyAsync(c->n_valid_dev, c->h_pinned + 128, sizeof(int) * B, hipMemcpyHostToDevice, st));
+    nv = c->n_valid_dev;
+  }
+  tic(c, 0, st);
+  HIPCHK(c, launch_logmel(pcm, pcm_stride, nv, B, n_samples, c->n_mels, c->lm, c->logspec_ws, c->lm_max, out, out_dtype, st));
+  toc(c, 0, st);
+  if (n_valid_host) HIPCHK(c, hipStreamSynchronize(st));  // pinned staging buffer is reused
+  return TW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// A2-A4 encoder
+// ---------------------------------------------------------------------------------------------
+int tw_encode(tw_ctx* c, const void* mel, int32_t mel_dtype, int32_t B, void* out_hidden, int32_t out_dtype, void* stream) {
+  if (!c || !mel) return fail(c, TW_EINVAL, "tw_encode: null argument");
+  if (!c->finalized) return fail(c, TW_ESTATE, "tw_encode before tw_finalize_weights");
+  if (B < 1 || B > c->Bmax) return fail(c, TW_EINVAL, "tw_encode: B=%d outside [1,%d]", B, c->Bmax);
+  hipStream_t st = pick_stream(c, stream);
+  const int d = c->d, T = c->T, C = c->C, H = c->H, F = c->ffn, dt = c->dtype;
+  const size_t e = c->esz;
+  tic(c, 1, st);
+  HIPCHK(c, launch_mel_transpose(dt, mel_dtype, mel, c->melT, B, c->n_mels, 2 * T, C, st));
+  {  // conv1 (k3,p1) + GELU as a GEMM over overlapping 3-row windows of the padded token-major mel
+    GemmEpilogue ep{};
+    ep.bias = c->conv1_b; ep.gelu = 1; ep.mode = EPI_ROWMAJOR;
+    ep.c_map = RowMap{2 * T, (long long)(2 * T + 2) * d, d};
+    ep.out = at(c->h1, d, e);
+    HIPCHK(c, launch_gemm(dt, c->melT, RowMap{2 * T, (long long)(2 * T + 2) * C, C}, c->conv1_w, B * 2 * T, d, 3 * C, ep, st));
+  }
+  {  // conv2 (k3,s2,p1) + GELU + positions: windows of 3 rows at stride 2 rows
+    GemmEpilogue ep{};
+    ep.bias = c->conv2_b; ep.gelu = 1; ep.mode = EPI_ROWMAJOR;
+    ep.res = c->enc_pos; ep.res_map = plain_rows(d); ep.res_mod = T;
+    ep.c_map = plain_rows(d);
+    ep.out = c->xa;
+    HIPCHK(c, launch_gemm(dt, c->h1, RowMap{T, (long long)(2 * T + 2) * d, 2LL * d}, c->conv2_w, B * T, d, 3 * d, ep, st));
+  }
+  const int M = B * T;
+  for (int l = 0; l < c->Le; ++l) {
+    const LayerW& L = c->enc[l];
+    HIPCHK(c, launch_layernorm(dt, c->xa, L.ln1_g, L.ln1_b, c->lnbuf, M, d, st));
+    {
+      GemmEpilogue ep{};
+      ep.bias = L.bqkv; ep.mode = EPI_QKV_ENC; ep.T = T; ep.Tp = c->Tp; ep.H = H;
+      ep.out = c->qbuf; ep.out2 = c->kbuf; ep.out3 = c->vtbuf;
+      HIPCHK(c, launch_gemm(dt, c->lnbuf, plain_rows(d), L.wqkv, M, 3 * d, d, ep, st));
+    }
+    HIPCHK(c, launch_enc_attention(dt, c->qbuf, c->kbuf, c->vtbuf, c->attn, B, H, T, c->Tp, st));
+    {
+      GemmEpilogue ep{};
+      ep.bias = L.bo; ep.mode = EPI_ROWMAJOR; ep.res = c->xa; ep.res_map = plain_rows(d); ep.c_map = plain_rows(d);
+      ep.out = c->xb;
+      HIPCHK(c, launch_gemm(dt, c->attn, plain_rows(d), L.wo, M, d, d, ep, st));
+    }
+    HIPCHK(c, launch_layernorm(dt, c->xb, L.ln2_g, L.ln2_b, c->lnbuf, M, d, st));
+    {
+      GemmEpilogue ep{};
+      ep.bias = L.b1; ep.gelu = 1; ep.mode = EPI_ROWMAJOR; ep.c_map = plain_rows(F); ep.out = c->ffnh;
+      HIPCHK(c, launch_gemm(dt, c->lnbuf, plain_rows(d), L.w1, M, F, d, ep, st));
+    }
+    {
+      GemmEpilogue ep{};
+      ep.bias = L.b2; ep.mode = EPI_ROWMAJOR; ep.res = c->xb; ep.res_map = plain_rows(d); ep.c_map = plain_rows(d);
+      ep.out = c->xa;
+      HIPCHK(c, launch_gemm(dt, c->ffnh, plain_rows(F), L.w2, M, d, F, ep, st));
+    }
+  }
+  HIPCHK(c, launch_layernorm(dt, c->xa, c->enc_ln_g, c->enc_ln_b, c->enc_out, M, d, st));
+  toc(c, 1, st);
+  if (out_hidden) HIPCHK(c, launch_convert(out_dtype, dt, c->enc_out, out_hidden, (long long)M * d, 1.f, st));
+  c->encoded_B = B;
+  c->cross_B = 0;
+  return TW_OK;
+}
+
+int tw_cross_kv(tw_ctx* c, int32_t B, void* stream) {
+  if (!c) return TW_EINVAL;
+  if (B < 1 || B > c->encoded_B) return fail(c, TW_ESTATE, "tw_cross_kv: B=%d but %d clips encoded", B, c->encoded_B);
+  hipStream_t st = pick_stream(c, stream);
+  const int d = c->d, T = c->T;
+  const size_t per_layer = (size_t)c->Bmax * T * d;
+  tic(c, 2, st);
+  for (int l = 0; l < c->Ld; ++l) {
+    const LayerW& L = c->dec[l];
+    GemmEpilogue ep{};
+    ep.bias = L.bkv_c; ep.mode = EPI_KV_CROSS; ep.T = T; ep.Tp = c->Tp; ep.H = c->H;
+    ep.out = at(c->cross_k, per_layer * l, c->esz);
+    ep.out2 = at(c->cross_v, per_layer * l, c->esz);
+    HIPCHK(c, launch_gemm(c->dtype, c->enc_out, plain_rows(d), L.wkv_c, B * T, 2 * d, d, ep, st));
+  }
+  toc(c, 2, st);
+  c->cross_B = B;
+  return TW_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// decoder
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// one token for every stream: embed -> Ld layers -> final LN + tied logits (fp32)
+int decode_core(tw_ctx* c, int B, hipStream_t st) {
+  const int d = c->d, H = c->H, F = c->ffn, T = c->T, P = c->P, dt = c->dtype;
+  const size_t e = c->esz;
+  HIPCHK(c, launch_embed(dt, c->cur_ids, c->stt, c->tok_emb, c->dec_pos, c->dx0, B, d, st));
+  void* xin = c->dx0;
+  void* xmid = c->dx1;
+  const size_t self_layer = (size_t)c->Bmax * P * d;
+  const size_t cross_layer = (size_t)c->Bmax * T * d;
+  for (int l = 0; l < c->Ld; ++l) {
+    const LayerW& L = c->dec[l];
+    void* sk = at(c->self_k, self_layer * l, e);
+    void* sv = at(c->self_v, self_layer * l, e);
+    {  // LN + fused QKV; k,v rows go straight into the cache at position pos
+      GemvArgs a{};
+      a.x = xin; a.ldx = d; a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.W = L.wqkv; a.bias = L.bqkv; a.N = 3 * d; a.K = d; a.B = B;
+      a.y = c->dq; a.ldy = d; a.kcache = sk; a.vcache = sv; a.cache_bstride = (long long)P * d; a.d_model = d; a.stt = c->stt;
+      HIPCHK(c, launch_gemv(dt, a, st));
+    }
+    HIPCHK(c, launch_dec_self_attn(dt, c->dq, sk, sv, (long long)P * d, c->datt, B, H, c->stt, st));
+    {
+      GemvArgs a{};
+      a.x = c->datt; a.ldx = d; a.W = L.wo; a.bias = L.bo; a.N = d; a.K = d; a.B = B; a.res = xin; a.ldres = d;
+      a.y = xmid; a.ldy = d;
+      HIPCHK(c, launch_gemv(dt, a, st));
+    }
+    {
+      GemvArgs a{};
+      a.x = xmid; a.ldx = d; a.ln_g = L.lnx_g; a.ln_b = L.lnx_b; a.W = L.wq_c; a.bias = L.bq_c; a.N = d; a.K = d; a.B = B;
+      a.y = c->dq; a.ldy = d;
+      HIPCHK(c, launch_gemv(dt, a, st));
+    }
+    HIPCHK(c, launch_dec_cross_attn(dt, c->dq, at(c->cross_k, cross_layer * l, e), at(c->cross_v, cross_layer * l, e),
+                                    c->datt, B, H, T, c->Ha > 0 ? c->align_slot + (size_t)l * H : nullptr, c->align, c->Ha,
+                                    P, c->stt, st));
+    {
+      GemvArgs a{};
+      a.x = c->datt; a.ldx = d; a.W = L.wo_c; a.bias = L.bo_c; a.N = d; a.K = d; a.B = B; a.res = xmid; a.ldres = d;
+      a.y = xin; a.ldy = d;
+      HIPCHK(c, launch_gemv(dt, a, st));
+    }
+    {
+      GemvArgs a{};
+      a.x = xin; a.ldx = d; a.ln_g = L.ln2_g; a.ln_b = L.ln2_b; a.W = L.w1; a.bias = L.b1; a.N = F; a.K = d; a.B = B;
+      a.gelu = 1; a.y = c->dh; a.ldy = F;
+      HIPCHK(c, launch_gemv(dt, a, st));
+    }
+    {
+      GemvArgs a{};
+      a.x = c->dh; a.ldx = F; a.W = L.w2; a.bias = L.b2; a.N = d; a.K = F; a.B = B; a.res = xin; a.ldres = d;
+      a.y = xmid; a.ldy = d;
+      HIPCHK(c, launch_gemv(dt, a, st));
+    }
+    void* t = xin; xin = xmid; xmid = t;
+  }
+  {
+    GemvArgs a{};
+    a.x = xin; a.ldx = d; a.ln_g = c->dec_ln_g; a.ln_b = c->dec_ln_b; a.W = c->tok_emb; a.N = c->V; a.K = d; a.B = B;
+    a.y_f32 = c->logits;
+    HIPCHK(c, launch_gemv(dt, a, st));
+  }
+  return TW_OK;
+}
+
+int reset_state(tw_ctx* c, int n_prompt, hipStream_t st) {
+  DecState s{0, n_prompt, 0, 0};
+  memcpy(c->h_pinned + 192 - 8, &s, sizeof s);
+  HIPCHK(c, hipMemcpyAsync(c->stt, c->h_pinned + 192 - 8, sizeof s, hipMemcpyHostToDevice, st));
+  return TW_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tw_decoder_reset(tw_ctx* c, int32_t B, void* stream) {
+  if (!c) return TW_EINVAL;
+  if (B < 1 || B > c->cross_B) return fail(c, TW_ESTATE, "tw_decoder_reset: B=%d but cross K/V holds %d clips", B, c->cross_B);
+  hipStream_t st = pick_stream(c, stream);
+  int r = reset_state(c, 0, st);
+  if (r != TW_OK) return r;
+  HIPCHK(c, hipStreamSynchronize(st));
+  return TW_OK;
+}
+
+int tw_decode_step(tw_ctx* c, int32_t B, const int32_t* ids_host, float* logits_dev, void* stream) {
+  if (!c || !ids_host) return fail(c, TW_EINVAL, "tw_decode_step: null argument");
+  if (B < 1 || B > c->cross_B) return fail(c, TW_ESTATE, "tw_decode_step: B=%d but cross K/V holds %d clips", B, c->cross_B);
+  hipStream_t st = pick_stream(c, stream);
+  HIPCHK(c, hipMemcpyAsync(c->cur_ids, ids_host, sizeof(int) * B, hipMemcpyHostToDevice, st));
+  int r = decode_core(c, B, st);
+  if (r != TW_OK) return r;
+  if (logits_dev)
+    HIPCHK(c, hipMemcpyAsync(logits_dev, c->logits, sizeof(float) * (size_t)B * c->V, hipMemcpyDeviceToDevice, st));
+  HIPCHK(c, launch_advance(c->stt, st));  // pos += 1 on the device (keeps the step graph-compatible)
+  return TW_OK;
+}
+
+int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_prompt, const tw_greedy_opts* o,
+                       int32_t* out_ids, int32_t* out_len, void* stream) {
+  if (!c || !prompt || !o || !out_ids || !out_len) return fail(c, TW_EINVAL, "tw_generate_greedy: null argument");
+  if (B < 1 || B > c->cross_B) return fail(c, TW_ESTATE, "tw_generate_greedy: B=%d but cross K/V holds %d clips", B, c->cross_B);
+  if (n_prompt < 1 || n_prompt >= c->P) return fail(c, TW_EINVAL, "bad n_prompt %d", n_prompt);
+  if (o->n_begin_suppress > 64 || o->n_suppress > 1024) return fail(c, TW_EINVAL, "suppress lists too long");
+  if (o->want_alignment && c->Ha == 0) return fail(c, TW_EINVAL, "want_alignment but the context has no alignment heads");
+  int max_len = n_prompt + o->max_new_tokens;
+  if (o->max_length > 0 && o->max_length < max_len) max_len = o->max_length;
+  if (max_len > c->P) max_len = c->P;
+  if (max_len <= n_prompt) return fail(c, TW_EINVAL, "nothing to generate (max_len %d <= n_prompt %d)", max_len, n_prompt);
+  const int out_ld = o->max_length > 0 ? o->max_length : max_len;
+  hipStream_t st = pick_stream(c, stream);
+  const int P = c->P;
+
+  // ---- initial state ----
+  std::vector<int> hseq((size_t)B * P, o->pad_id), first(B), zeros(B, 0), neg(B, -1);
+  for (int b = 0; b < B; ++b) {
+    for (int i = 0; i < n_prompt; ++i) {
+      const int t = prompt[(size_t)b * n_prompt + i];
+      if (t < 0 || t >= c->V) return fail(c, TW_EINVAL, "prompt token %d out of range", t);
+      hseq[(size_t)b * P + i] = t;
+    }
+    first[b] = prompt[(size_t)b * n_prompt];
+  }
+  HIPCHK(c, hipMemcpyAsync(c->seq, hseq.data(), sizeof(int) * hseq.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->cur_ids, first.data(), sizeof(int) * B, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->finished, zeros.data(), sizeof(int) * B, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->last_ts, neg.data(), sizeof(int) * B, hipMemcpyHostToDevice, st));
+  if (o->n_begin_suppress > 0)
+    HIPCHK(c, hipMemcpyAsync(c->begin_suppress_dev, o->begin_suppress, sizeof(int) * o->n_begin_suppress, hipMemcpyHostToDevice, st));
+  if (o->n_suppress > 0)
+    HIPCHK(c, hipMemcpyAsync(c->suppress_dev, o->suppress, sizeof(int) * o->n_suppress, hipMemcpyHostToDevice, st));
+  DecState s0{0, n_prompt, max_len - 1, B};
+  HIPCHK(c, hipMemcpyAsync(c->stt, &s0, sizeof s0, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipStreamSynchronize(st));  // host staging vectors go out of scope below / pageable copies done
+
+  SamplerArgs sa{};
+  sa.logits = c->logits; sa.V = c->V; sa.B = B; sa.seq = c->seq; sa.seq_ld = P; sa.cur_ids = c->cur_ids;
+  sa.finished = c->finished; sa.last_ts = c->last_ts; sa.stt = c->stt;
+  sa.eos = o->eos_id; sa.pad = o->pad_id; sa.min_new = o->min_new_tokens; sa.timestamps = o->timestamps;
+  sa.no_ts_id = o->no_timestamps_id; sa.max_initial_ts = o->max_initial_timestamp_index;
+  sa.begin_suppress = c->begin_suppress_dev; sa.n_begin_suppress = o->n_begin_suppress;
+  sa.suppress = c->suppress_dev; sa.n_suppress = o->n_suppress;
+
+  // ---- optional graph capture of one full step ----
+  char keybuf[256];
+  snprintf(keybuf, sizeof keybuf, "%d|%d|%d|%d|%d|%d|%d|%d|%d", B, o->eos_id, o->pad_id, o->min_new_tokens, o->timestamps,
+           o->no_timestamps_id, o->max_initial_timestamp_index, o->n_begin_suppress, o->n_suppress);
+  const bool use_graph = c->cfg.use_graph != 0;
+  if (use_graph && (c->step_graph == nullptr || c->step_graph_key != keybuf)) {
+    if (c->step_graph) { (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
+    hipGraph_t g = nullptr;
+    HIPCHK(c, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int r = decode_core(c, B, st);
+    hipError_t es = (r == TW_OK) ? launch_sampler(sa, st) : hipSuccess;
+    hipError_t ee = hipStreamEndCapture(st, &g);
+    if (r != TW_OK) { if (g) (void)hipGraphDestroy(g); return r; }
+    if (es != hipSuccess || ee != hipSuccess) {
+      if (g) (void)hipGraphDestroy(g);
+      return fail(c, TW_EHIP, "decode-step graph capture failed: %s", hipGetErrorString(es != hipSuccess ? es : ee));
+    }
+    hipError_t ei = hipGraphInstantiate(&c->step_graph, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (ei != hipSuccess) { c->step_graph = nullptr; return fail(c, TW_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ei)); }
+    c->step_graph_key = keybuf;
+  }
+
+  // ---- the loop: step s consumes position s and produces the token at position s+1 ----
+  tic(c, 3, st);
+  const int LAG = 4;
+  int steps = 0;
+  bool all_done = false;
+  for (int s = 0; s < max_len - 1 && !all_done; ++s) {
+    if (use_graph) {
+      HIPCHK(c, hipGraphLaunch(c->step_graph, st));
+    } else {
+      int r = decode_core(c, B, st);
+      if (r != TW_OK) return r;
+      HIPCHK(c, launch_sampler(sa, st));
+    }
+    ++steps;
+    const int slot = s % 8;
+    HIPCHK(c, hipMemcpyAsync(c->h_pinned + slot * 16, c->finished, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipEventRecord(c->ring_ev[slot], st));
+    if (s >= LAG) {
+      const int ps = (s - LAG) % 8;
+      HIPCHK(c, hipEventSynchronize(c->ring_ev[ps]));
+      bool done = true;
+      for (int b = 0; b < B; ++b) done &= (c->h_pinned[ps * 16 + b] != 0);
+      all_done = done;
+    }
+  }
+  toc(c, 3, st);
+  c->last_steps = steps;
+  HIPCHK(c, hipMemcpyAsync(hseq.data(), c->seq, sizeof(int) * hseq.size(), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+
+  // common sequence length exactly as HF's loop would have stopped: when the last row hit eos, or at max_len
+  const int produced = steps + 1;  // positions 0..steps are filled
+  int L = n_prompt + 1;
+  for (int b = 0; b < B; ++b) {
+    int lb = produced;
+    for (int i = n_prompt; i < produced; ++i)
+      if (hseq[(size_t)b * P + i] == o->eos_id) { lb = i + 1; break; }
+    if (lb > L) L = lb;
+  }
+  for (int b = 0; b < B; ++b) {
+    bool ended = false;
+    for (int i = 0; i < out_ld; ++i) {
+      int v = o->pad_id;
+      if (i < L) {
+        v = hseq[(size_t)b * P + i];
+        if (ended) v = o->pad_id;
+        if (i >= n_prompt && v == o->eos_id) ended = true;
+      }
+      out_ids[(size_t)b * out_ld + i] = v;
+    }
+  }
+  *out_len = L;
+  c->last_seq_len = L;
+  c->last_n_prompt = n_prompt;
+  return TW_OK;
+}
+
+int tw_get_alignment(tw_ctx* c, int32_t B, int32_t n_rows, float* out_host, void* stream) {
+  if (!c || !out_host) return TW_EINVAL;
+  if (c->Ha == 0) return fail(c, TW_EINVAL, "context has no alignment heads");
+  if (B < 1 || B > c->Bmax || n_rows < 1 || n_rows > c->P) return fail(c, TW_EINVAL, "bad B/n_rows");
+  hipStream_t st = pick_stream(c, stream);
+  const size_t T = c->T, P = c->P, Ha = c->Ha;
+  for (int b = 0; b < B; ++b)
+    for (size_t h = 0; h < Ha; ++h)
+      HIPCHK(c, hipMemcpyAsync(out_host + ((size_t)b * Ha + h) * n_rows * T, c->align + ((size_t)b * Ha + h) * P * T,
+                               sizeof(float) * n_rows * T, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  return TW_OK;
+}
+
+int tw_token_timestamps(tw_ctx* c, int32_t B, int32_t n_prompt, int32_t seq_len, const int32_t* num_frames_host,
+                        double time_precision, float* out_ts_host, void* stream) {
+  if (!c || !out_ts_host) return fail(c, TW_EINVAL, "tw_token_timestamps: null argument");
+  if (c->Ha == 0) return fail(c, TW_EINVAL, "context has no alignment heads");
+  if (B < 1 || B > c->Bmax || seq_len < 2 || seq_len > c->P || n_prompt < 1 || n_prompt >= seq_len)
+    return fail(c, TW_EINVAL, "bad B/n_prompt/seq_len (%d,%d,%d)", B, n_prompt, seq_len);
+  hipStream_t st = pick_stream(c, stream);
+  std::vector<int> cols(B);
+  for (int b = 0; b < B; ++b) {
+    int nc = num_frames_host ? num_frames_host[b] / 2 : c->T;
+    if (nc > c->T) nc = c->T;
+    if (nc < 1) nc = 1;
+    cols[b] = nc;
+  }
+  HIPCHK(c, hipMemcpy(c->n_cols, cols.data(), sizeof(int) * B, hipMemcpyHostToDevice));
+  DtwArgs a{};
+  a.align = c->align; a.Ha = c->Ha; a.P = c->P; a.T = c->T; a.B = B; a.n_prompt = n_prompt; a.n_rows = seq_len - 1;
+  a.n_cols = c->n_cols; a.median_width = 7; a.zbuf = c->zbuf; a.mat = c->mat; a.trace = c->trace; a.out_ts = c->out_ts;
+  // the reference multiplies int64 frame indices by the Python float 0.02 (float64)
+  a.time_precision = time_precision;
+  tic(c, 4, st);
+  HIPCHK(c, launch_token_timestamps(a, st));
+  toc(c, 4, st);
+  HIPCHK(c, hipMemcpyAsync(out_ts_host, c->out_ts, sizeof(float) * (size_t)B * seq_len, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  return TW_OK;
+}
+
+int tw_last_timings(tw_ctx* c, float* ms_out5, int32_t* steps_out) {
+  if (!c || !ms_out5) return TW_EINVAL;
+  for (int i = 0; i < 5; ++i) {
+    ms_out5[i] = -1.f;
+    if (c->ev_valid[i]) {
+      float ms = 0.f;
+      if (hipEventSynchronize(c->ev1[i]) == hipSuccess && hipEventElapsedTime(&ms, c->ev0[i], c->ev1[i]) == hipSuccess)
+        ms_out5[i] = ms;
+    }
+  }
+  if (steps_out) *steps_out = c->last_steps;
+  return TW_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,256 @@
+// MFMA GEMM for the MFMA-bound part of the hot path (A2 conv stem, A3 encoder projections/FFN,
+// A5 cross-K/V projection):  C[M,N] = epilogue(A[M,K] . W[N,K]^T),  both operands K-contiguous
+// (activations token-major, weights in the HF nn.Linear [out,in] layout).
+//
+// gfx950 design
+//  * 256 threads = 4 waves in a 2x2 arrangement; block tile BM (activation rows) x BN (weight rows),
+//    K tile = 8 x 16 B per row (64 bf16 / 32 f32).  128x128 for large M, 64x64 when the grid
+//    would otherwise not cover the 256 CUs.
+//  * LDS image: [k-slot 0..7][row ^ slot] of 16-B vectors.  The global->LDS write (8 lanes cover
+//    one 128-B row segment) and the MFMA fragment read (16 lanes read 16 consecutive rows of one
+//    k-slot with ds_read_b128) are both bank-conflict free with this XOR placement.
+//  * "swapped" MFMA: the weight tile is the A operand and the activation tile the B operand of
+//    v_mfma_f32_16x16x32_bf16 (or 4 x v_mfma_f32_16x16x4_f32 in strict-f32 mode, using a
+//    k-permutation so that the same 16-B fragment feeds both), so every lane ends up with 4
+//    consecutive output columns of one row -> 8/16-B epilogue stores and vector bias loads.
+//  * register-staged double buffering: the next K tile's global loads are issued before the MFMAs
+//    of the current tile and written to the other LDS buffer afterwards (one barrier per tile).
+//  * fused epilogues: bias, exact GELU, residual / positional add, and the head-split / transposed
+//    layouts the attention kernels consume (no separate permute kernels).
+#include "tw_common.h"
+
+namespace {
+
+__device__ __forceinline__ long long rowmap(const RowMap& r, int m) {
+  return (long long)(m / r.rpb) * r.bstride + (long long)(m % r.rpb) * r.rstride;
+}
+
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <typename T> struct Vec4;  // 4 consecutive elements
+template <> struct Vec4<float> {
+  float4 v;
+  __device__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+  __device__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
+  __device__ float get(int i) const { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+  __device__ void set(int i, float f) { if (i == 0) v.x = f; else if (i == 1) v.y = f; else if (i == 2) v.z = f; else v.w = f; }
+  __device__ float elem(int i) const { return get(i); }
+};
+template <> struct Vec4<bf16_t> {
+  bf16_t e[4];
+  __device__ void load(const bf16_t* p) { *reinterpret_cast<uint2*>(e) = *reinterpret_cast<const uint2*>(p); }
+  __device__ void store(bf16_t* p) const { *reinterpret_cast<uint2*>(p) = *reinterpret_cast<const uint2*>(e); }
+  __device__ float get(int i) const { return (float)e[i]; }
+  __device__ void set(int i, float f) { e[i] = (bf16_t)f; }
+  __device__ bf16_t elem(int i) const { return e[i]; }
+};
+
+template <typename T>
+__device__ __forceinline__ f32x4_t mfma_step(const u32x4_t& wfrag, const u32x4_t& afrag, f32x4_t acc);
+
+template <>
+__device__ __forceinline__ f32x4_t mfma_step<bf16_t>(const u32x4_t& wfrag, const u32x4_t& afrag, f32x4_t acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wfrag),
+                                                 __builtin_bit_cast(bf16x8_t, afrag), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4_t mfma_step<float>(const u32x4_t& wfrag, const u32x4_t& afrag, f32x4_t acc) {
+  const f32x4_t w = __builtin_bit_cast(f32x4_t, wfrag);
+  const f32x4_t a = __builtin_bit_cast(f32x4_t, afrag);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0], a[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[1], a[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2], a[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[3], a[3], acc, 0, 0, 0);
+  return acc;
+}
+
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A, RowMap amap, const T* __restrict__ W,
+                                                    int M, int N, int K, GemmEpilogue ep) {
+  constexpr int E = ElemTraits<T>::kPer16B;  // elements per 16-B vector
+  constexpr int BKE = 8 * E;                 // elements per K tile
+  constexpr int AV = BM * 8 / 256;           // 16-B vectors per thread per tile (activations)
+  constexpr int WV = BN * 8 / 256;           // (weights)
+  constexpr int MT = BM / 32;                // 16-row MFMA tiles per wave along M
+  constexpr int NT = BN / 32;                // along N
+  __shared__ u32x4_t lds[2 * 8 * (BM + BN)];
+  u32x4_t* ldsA = lds;                   // [2][8][BM]
+  u32x4_t* ldsW = lds + 2 * 8 * BM;      // [2][8][BN]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wn = wave & 1;   // wave position along N
+  const int wm = wave >> 1;  // along M
+  const int n0 = blockIdx.x * BN;
+  const int m0 = blockIdx.y * BM;
+
+  // per-thread global source pointers (fixed rows, advancing along K)
+  const T* asrc[AV];
+  int adst[AV];
+#pragma unroll
+  for (int i = 0; i < AV; ++i) {
+    const int v = i * 256 + tid;
+    const int row = v >> 3, slot = v & 7;
+    int m = m0 + row;
+    if (m >= M) m = M - 1;
+    asrc[i] = A + rowmap(amap, m) + slot * E;
+    adst[i] = slot * BM + (row ^ slot);
+  }
+  const T* wsrc[WV];
+  int wdst[WV];
+#pragma unroll
+  for (int i = 0; i < WV; ++i) {
+    const int v = i * 256 + tid;
+    const int row = v >> 3, slot = v & 7;
+    wsrc[i] = W + (long long)(n0 + row) * K + slot * E;
+    wdst[i] = slot * BN + (row ^ slot);
+  }
+
+  f32x4_t acc[NT][MT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  u32x4_t areg[AV], wreg[WV];
+  const int nk = K / BKE;
+#pragma unroll
+  for (int i = 0; i < AV; ++i) areg[i] = *reinterpret_cast<const u32x4_t*>(asrc[i]);
+#pragma unroll
+  for (int i = 0; i < WV; ++i) wreg[i] = *reinterpret_cast<const u32x4_t*>(wsrc[i]);
+#pragma unroll
+  for (int i = 0; i < AV; ++i) ldsA[adst[i]] = areg[i];
+#pragma unroll
+  for (int i = 0; i < WV; ++i) ldsW[wdst[i]] = wreg[i];
+  __syncthreads();
+
+  const int fr = lane & 15;  // fragment row within a 16-row tile
+  const int fq = lane >> 4;  // k-slot quad
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = (kt + 1) < nk;
+    if (more) {
+      const int koff = (kt + 1) * BKE;
+#pragma unroll
+      for (int i = 0; i < AV; ++i) areg[i] = *reinterpret_cast<const u32x4_t*>(asrc[i] + koff);
+#pragma unroll
+      for (int i = 0; i < WV; ++i) wreg[i] = *reinterpret_cast<const u32x4_t*>(wsrc[i] + koff);
+    }
+    const u32x4_t* la = ldsA + buf * 8 * BM;
+    const u32x4_t* lw = ldsW + buf * 8 * BN;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int slot = kk * 4 + fq;
+      u32x4_t af[MT], wf[NT];
+#pragma unroll
+      for (int b = 0; b < MT; ++b) {
+        const int row = wm * (BM / 2) + b * 16 + fr;
+        af[b] = la[slot * BM + (row ^ slot)];
+      }
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        const int row = wn * (BN / 2) + a * 16 + fr;
+        wf[a] = lw[slot * BN + (row ^ slot)];
+      }
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc[a][b] = mfma_step<T>(wf[a], af[b], acc[a][b]);
+    }
+    if (more) {
+      u32x4_t* sa = ldsA + (buf ^ 1) * 8 * BM;
+      u32x4_t* sw = ldsW + (buf ^ 1) * 8 * BN;
+#pragma unroll
+      for (int i = 0; i < AV; ++i) sa[adst[i]] = areg[i];
+#pragma unroll
+      for (int i = 0; i < WV; ++i) sw[wdst[i]] = wreg[i];
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // ---- epilogue: lane holds, per (a,b) tile, 4 consecutive columns n of row m ----
+  const T* bias = reinterpret_cast<const T*>(ep.bias);
+  const T* res = reinterpret_cast<const T*>(ep.res);
+  const int dmodel = ep.H * 64;
+#pragma unroll
+  for (int b = 0; b < MT; ++b) {
+    const int m = m0 + wm * (BM / 2) + b * 16 + fr;
+    if (m >= M) continue;
+    long long roff = 0;
+    if (res) roff = rowmap(ep.res_map, ep.res_mod > 0 ? (m % ep.res_mod) : m);
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+      const int n = n0 + wn * (BN / 2) + a * 16 + fq * 4;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r];
+      if (bias) {
+        Vec4<T> bv;
+        bv.load(bias + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bv.get(r);
+      }
+      if (ep.gelu) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_exact(v[r]);
+      }
+      if (res) {
+        Vec4<T> rv;
+        rv.load(res + roff + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += rv.get(r);
+      }
+      Vec4<T> ov;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ov.set(r, v[r]);
+      if (ep.mode == EPI_ROWMAJOR) {
+        ov.store(reinterpret_cast<T*>(ep.out) + rowmap(ep.c_map, m) + n);
+      } else {
+        const int bidx = m / ep.T, t = m % ep.T;
+        int seg = n / dmodel;
+        const int nn = n - seg * dmodel;
+        const int h = nn >> 6, dd = nn & 63;
+        if (ep.mode == EPI_HEADSPLIT) seg = 0;
+        if (ep.mode == EPI_QKV_ENC && seg == 2) {
+          T* o = reinterpret_cast<T*>(ep.out3) + ((long long)(bidx * ep.H + h) * 64 + dd) * ep.Tp + t;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[(long long)r * ep.Tp] = ov.elem(r);
+        } else {
+          T* base = reinterpret_cast<T*>(seg == 0 ? ep.out : ep.out2);
+          ov.store(base + ((long long)(bidx * ep.H + h) * ep.T + t) * 64 + dd);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+template <typename T>
+static hipError_t gemm_dispatch(const void* A, RowMap amap, const void* W, int M, int N, int K,
+                                const GemmEpilogue& ep, hipStream_t st) {
+  constexpr int E = ElemTraits<T>::kPer16B;
+  if (M <= 0) return hipSuccess;
+  if (K % (8 * E) != 0 || N % 64 != 0) return hipErrorInvalidValue;
+  // 128x128 tiles when they already give >= 2 blocks per CU or N only divides by 128-multiples badly;
+  // otherwise 64x64 so that small-M (single stream) GEMMs still spread over the chip.
+  const long long blocks128 = (long long)((M + 127) / 128) * (N / 128);
+  if (N % 128 == 0 && blocks128 >= 384) {
+    dim3 grid(N / 128, (M + 127) / 128);
+    hipLaunchKernelGGL((gemm_kernel<T, 128, 128>), grid, dim3(256), 0, st, reinterpret_cast<const T*>(A), amap,
+                       reinterpret_cast<const T*>(W), M, N, K, ep);
+  } else {
+    dim3 grid(N / 64, (M + 63) / 64);
+    hipLaunchKernelGGL((gemm_kernel<T, 64, 64>), grid, dim3(256), 0, st, reinterpret_cast<const T*>(A), amap,
+                       reinterpret_cast<const T*>(W), M, N, K, ep);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_gemm(int dtype, const void* A, RowMap amap, const void* W, int M, int N, int K,
+                       const GemmEpilogue& ep, hipStream_t st) {
+  if (dtype == 1) return gemm_dispatch<bf16_t>(A, amap, W, M, N, K, ep, st);
+  return gemm_dispatch<float>(A, amap, W, M, N, K, ep, st);
+}

@@ -1,0 +1,144 @@
+// Internal declarations shared by the gfx950 kernel translation units and the C-ABI layer.
+// MI355X (gfx950, CDNA4) only: wave = 64 lanes, MFMA 16x16x32 bf16 / 16x16x4 f32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;  // a 16-B register quad (native vector: stays in VGPRs)
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> { static constexpr int kPer16B = 4; static constexpr int kCode = 0; };
+template <> struct ElemTraits<bf16_t> { static constexpr int kPer16B = 8; static constexpr int kCode = 1; };
+
+// Affine map from a logical GEMM row m to an element offset:  (m / rpb) * bstride + (m % rpb) * rstride.
+// Lets one GEMM read convolution windows as overlapping rows of a padded token-major buffer and
+// write into padded / per-batch layouts without im2col copies.
+struct RowMap {
+  int rpb;            // rows per batch block (>= M for a plain matrix)
+  long long bstride;  // elements between batch blocks
+  long long rstride;  // elements between consecutive rows
+};
+static inline RowMap plain_rows(long long ld) { return RowMap{1 << 30, 0, ld}; }
+
+// GEMM epilogue descriptor: v = acc + bias[n]; GELU?; + res[rmap(m % res_mod) + n]; store by mode.
+enum { EPI_ROWMAJOR = 0, EPI_HEADSPLIT = 1, EPI_QKV_ENC = 2, EPI_KV_CROSS = 3 };
+struct GemmEpilogue {
+  const void* bias;   // [N] in T, may be null
+  int gelu;           // exact erf GELU
+  const void* res;    // residual, element type T, may be null
+  RowMap res_map;     // row map of the residual
+  int res_mod;        // residual row = m % res_mod (positional table broadcast); 0 = m
+  int mode;           // EPI_*
+  // EPI_ROWMAJOR: out + cmap(m) + n
+  RowMap c_map;
+  // head-split modes: rows m = b*T + t.  out index ((b*H + h)*T + t)*64 + dd
+  int T;              // tokens per batch entry
+  int Tp;             // padded T of transposed V
+  int H;
+  void* out;          // primary output (q / k of cross)
+  void* out2;         // k (QKV_ENC) or v (KV_CROSS)
+  void* out3;         // v transposed (QKV_ENC)
+};
+
+// ---- launchers (one per kernel family); all enqueue on `st` and return hipGetLastError() ----
+// C[M,N] = epi(A[M,K] * W[N,K]^T).  T = float or bf16.  K % 64 == 0 (bf16) / % 32 == 0 (f32), N % 64 == 0.
+hipError_t launch_gemm(int dtype, const void* A, RowMap amap, const void* W, int M, int N, int K,
+                       const GemmEpilogue& ep, hipStream_t st);
+
+hipError_t launch_layernorm(int dtype, const void* x, const void* g, const void* b, void* y, int rows, int d,
+                            hipStream_t st);
+// mel [B, n_mels, F] (src dtype) -> melT [B, F+2, C] (ctx dtype), zero pad rows 0 and F+1 and channels >= n_mels
+hipError_t launch_mel_transpose(int dst_dtype, int src_dtype, const void* mel, void* melT, int B, int n_mels, int F,
+                                int C, hipStream_t st);
+hipError_t launch_convert(int dst_dtype, int src_dtype, const void* src, void* dst, long long n, float scale,
+                          hipStream_t st);
+hipError_t launch_fill_zero(void* dst, long long bytes, hipStream_t st);
+// conv weight [co][ci][3] (src dtype) -> [co][3][C] (dst dtype), zero for ci >= n_ci
+hipError_t launch_conv_weight_reorder(int dst_dtype, int src_dtype, const void* src, void* dst, int co, int ci, int C,
+                                      hipStream_t st);
+// positional table [n_old, d] f32-> [n_new, d] ctx dtype by linear interpolation (align_corners=False)
+hipError_t launch_interp_positions(int dst_dtype, int src_dtype, const void* src, void* dst, int n_old, int n_new,
+                                   int d, hipStream_t st);
+
+// log-mel (A1)
+struct LogmelTables {
+  const double* twiddle;  // cos(2*pi*j/400), j in [0,400)
+  const double* window;   // periodic hann(400)
+  const float* bank;      // [201][n_mels] f32 (HF casts the f64 bank to f32)
+  const int* lo;          // per mel: first non-zero bin
+  const int* hi;          // per mel: one past last non-zero bin
+};
+hipError_t launch_logmel(const float* pcm, long long pcm_stride, const int* n_valid_dev, int B, int n_samples,
+                         int n_mels, const LogmelTables& tb, float* logspec_ws, unsigned* max_ws, void* out,
+                         int out_dtype, hipStream_t st);
+
+// encoder self-attention (non-causal, head_dim 64).  q,k: [B,H,T,64]; vt: [B,H,64,Tp]; out: [B*T, H*64]
+hipError_t launch_enc_attention(int dtype, const void* q, const void* k, const void* vt, void* out, int B, int H,
+                                int T, int Tp, hipStream_t st);
+
+// ---- decoder (single new token per stream) ----
+struct DecState {   // lives in device memory so that a captured graph is position independent
+  int pos;          // position of the token being consumed this step
+  int n_prompt;     // begin_index
+  int step_limit;   // last position that may be produced (max_len - 1)
+  int unfinished;   // count of unfinished streams (written by the sampler)
+};
+// x[b] = tok_emb[ids[b]] + pos_emb[pos]
+hipError_t launch_embed(int dtype, const int* ids, const DecState* stt, const void* tok, const void* pos, void* x,
+                        int B, int d, hipStream_t st);
+// y[b, n] = epi( LN?(x[b,:]) . W[n,:] + bias[n] )  for b < B <= 16.
+struct GemvArgs {
+  const void* x; int ldx;        // [B, K] input (T)
+  const void* ln_g; const void* ln_b;  // fused pre-LayerNorm over K (null = none); requires K <= 1280
+  const void* W; const void* bias;     // [N, K], [N]
+  int N, K, B;
+  int gelu;
+  const void* res; int ldres;    // residual [B, N] added after bias/act (may alias-free ping-pong)
+  void* y; int ldy;              // output (T) or
+  float* y_f32;                  // float32 output [B, N] (logits) when non-null
+  // optional KV-cache scatter for the fused self-attention QKV projection: rows [d,2d) -> kcache, [2d,3d) -> vcache
+  void* kcache; void* vcache; long long cache_bstride; int d_model; const DecState* stt;
+};
+hipError_t launch_gemv(int dtype, const GemvArgs& a, hipStream_t st);
+hipError_t init_decode_kernels();  // once per process: dynamic-LDS caps of the gemv instantiations
+// self attention over the growing cache: q [B,d]; kc/vc [B][P][d] (batch stride cache_bstride); out [B,d]
+hipError_t launch_dec_self_attn(int dtype, const void* q, const void* kc, const void* vc, long long cache_bstride,
+                                void* out, int B, int H, const DecState* stt, hipStream_t st);
+// cross attention over cached encoder K/V: ck/cv [B,H,T,64]; out [B,d]; align rows: for head h with
+// align_slot[h] >= 0 write softmax row to align[((b*Ha + slot)*P + pos)*T + t]
+hipError_t launch_dec_cross_attn(int dtype, const void* q, const void* ck, const void* cv, void* out, int B, int H,
+                                 int T, const int* align_slot_for_head, float* align, int Ha, int P,
+                                 const DecState* stt, hipStream_t st);
+
+struct SamplerArgs {   // A10 + argmax + bookkeeping
+  const float* logits; int V; int B;
+  int* seq; int seq_ld;          // [B, seq_ld] token history (prompt included)
+  int* cur_ids;                  // [B] token to feed next step
+  int* finished;                 // [B]
+  int* last_ts;                  // [B] last timestamp token sampled (-1 none)
+  DecState* stt;
+  int eos, pad, min_new, timestamps, no_ts_id, max_initial_ts;  // max_initial_ts < 0: unset
+  const int* begin_suppress; int n_begin_suppress;
+  const int* suppress; int n_suppress;
+};
+hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st);   // sampler + pos advance
+hipError_t launch_advance(DecState* stt, hipStream_t st);            // pos += 1 only (teacher-forced stepping)
+
+// A11: alignment rows -> token timestamps
+struct DtwArgs {
+  const float* align; int Ha; int P; int T;   // [B][Ha][P][T]
+  int B; int n_prompt; int n_rows;            // rows used: [n_prompt, n_rows)
+  const int* n_cols;                          // [B] columns kept (num_frames // 2), device
+  int median_width;
+  float* zbuf;     // [B][Ha][N][T] workspace
+  float* mat;      // [B][N][T] workspace
+  signed char* trace;  // [B][(N+1)*(T+1)]
+  float* out_ts;   // [B][n_rows + 1]
+  double time_precision;
+};
+hipError_t launch_token_timestamps(const DtwArgs& a, hipStream_t st);

@@ -1,0 +1,248 @@
+"""``WhisperEngine`` - thin Python handle on a ``tw_ctx`` (include/thewhisper.h).
+
+PyTorch is used only as plumbing here: it owns the caller-side device tensors (PCM, mel, logits)
+and hands raw device pointers + the current HIP stream to the C ABI.  Every operation of the hot
+path runs in libthewhisper_gfx950.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _cabi
+
+_TORCH2TW = {torch.float32: _cabi.TW_F32, torch.bfloat16: _cabi.TW_BF16, torch.float16: _cabi.TW_F16}
+
+
+def _stream_ptr(device: torch.device) -> C.c_void_p:
+    s = torch.cuda.current_stream(device).cuda_stream
+    return C.c_void_p(int(s) if s else None)
+
+
+class WhisperEngine:
+    """One MI355X context: weights + workspace + KV arenas for up to ``max_batch`` concurrent streams
+    of ``T`` encoder frames (= 50 x chunk seconds)."""
+
+    def __init__(
+        self,
+        dims: Dict[str, int],
+        T: int,
+        max_batch: int = 1,
+        dtype: str = "bf16",
+        alignment_heads: Optional[Sequence[Tuple[int, int]]] = None,
+        device: int = 0,
+        use_graph: bool = True,
+    ):
+        if not torch.cuda.is_available():
+            raise RuntimeError("thewhisper_amd needs an MI355X (torch.cuda is not available); there is no CPU fallback")
+        self.lib = _cabi.load_library()
+        self.dims = dict(dims)
+        self.T = int(T)
+        self.max_batch = int(max_batch)
+        self.device = torch.device("cuda", device)
+        self.dtype_name = dtype
+        self.tw_dtype = {"bf16": _cabi.TW_BF16, "f32": _cabi.TW_F32}[dtype]
+        self.torch_dtype = {"bf16": torch.bfloat16, "f32": torch.float32}[dtype]
+        self.alignment_heads = [tuple(map(int, x)) for x in (alignment_heads or [])]
+        cfg = _cabi.tw_config()
+        cfg.d_model = dims["d_model"]
+        cfg.enc_layers = dims["enc_layers"]
+        cfg.dec_layers = dims["dec_layers"]
+        cfg.heads = dims["heads"]
+        cfg.ffn = dims["ffn"]
+        cfg.vocab = dims["vocab"]
+        cfg.n_mels = dims["n_mels"]
+        cfg.source_positions = self.T
+        cfg.target_positions = dims.get("max_target_positions", 448)
+        cfg.max_batch = self.max_batch
+        cfg.dtype = self.tw_dtype
+        cfg.n_align_heads = len(self.alignment_heads)
+        for i, (l, h) in enumerate(self.alignment_heads):
+            cfg.align_heads[2 * i] = l
+            cfg.align_heads[2 * i + 1] = h
+        cfg.device = device
+        cfg.use_graph = 1 if use_graph else 0
+        self.P = cfg.target_positions
+        self.vocab = cfg.vocab
+        self.n_mels = cfg.n_mels
+        self.d_model = cfg.d_model
+        ctx = C.c_void_p()
+        rc = self.lib.tw_create(C.byref(cfg), C.byref(ctx))
+        if rc != 0:
+            raise RuntimeError(f"tw_create failed ({rc}): {self.lib.tw_last_error(None).decode()}")
+        self.ctx = ctx
+        self._finalized = False
+
+    # ---- lifetime ----------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.tw_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc: int, what: str):
+        _cabi.check(self.lib, self.ctx, rc, what)
+
+    # ---- weights -----------------------------------------------------------------------------
+    def load_weight(self, name: str, tensor: torch.Tensor):
+        t = tensor.detach()
+        if t.device.type != "cuda":
+            t = t.to(self.device, non_blocking=False)
+        t = t.contiguous()
+        if t.dtype not in _TORCH2TW:
+            t = t.float()
+        shape = (C.c_int64 * t.dim())(*t.shape)
+        rc = self.lib.tw_load_weight(self.ctx, name.encode(), C.c_void_p(t.data_ptr()), _TORCH2TW[t.dtype], t.dim(), shape,
+                                     _stream_ptr(self.device))
+        self._chk(rc, f"tw_load_weight({name})")
+        torch.cuda.current_stream(self.device).synchronize()  # `t` may be a temporary
+
+    def finalize(self):
+        self._chk(self.lib.tw_finalize_weights(self.ctx, _stream_ptr(self.device)), "tw_finalize_weights")
+        self._finalized = True
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        for k, v in sd.items():
+            if k == "proj_out.weight":
+                continue
+            self.load_weight(k, v)
+        self.finalize()
+
+    @classmethod
+    def from_numpy_weights(cls, dims, weights: Dict[str, np.ndarray], T: int, **kw) -> "WhisperEngine":
+        eng = cls(dims, T, **kw)
+        eng.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in weights.items()})
+        return eng
+
+    # ---- A1 ----------------------------------------------------------------------------------
+    def logmel(self, pcm: torch.Tensor, n_valid: Optional[Sequence[int]] = None, n_samples: Optional[int] = None,
+               out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        """pcm: float32 CUDA tensor [B, n] -> [B, n_mels, n_samples//160] (zero padded to ``n_samples``)."""
+        if pcm.dim() == 1:
+            pcm = pcm[None]
+        pcm = pcm.to(self.device, torch.float32).contiguous()
+        B, n = pcm.shape
+        n_samples = int(n_samples or n)
+        if n_valid is None and n < n_samples:
+            n_valid = [n] * B
+        nv = None
+        if n_valid is not None:
+            nv = (C.c_int32 * B)(*[int(min(v, n)) for v in n_valid])
+        out_dtype = out_dtype or self.torch_dtype
+        out = torch.empty((B, self.n_mels, n_samples // 160), dtype=out_dtype, device=self.device)
+        rc = self.lib.tw_logmel(self.ctx, C.c_void_p(pcm.data_ptr()), pcm.stride(0), nv, B, n_samples,
+                                C.c_void_p(out.data_ptr()), _TORCH2TW[out_dtype], _stream_ptr(self.device))
+        self._chk(rc, "tw_logmel")
+        return out
+
+    # ---- A2-A5 -------------------------------------------------------------------------------
+    def encode(self, mel: torch.Tensor, return_hidden: bool = False, hidden_dtype: torch.dtype = torch.float32):
+        mel = mel.to(self.device).contiguous()
+        if mel.dtype not in _TORCH2TW:
+            mel = mel.float()
+        B = mel.shape[0]
+        if tuple(mel.shape[1:]) != (self.n_mels, 2 * self.T):
+            # same failure mode as HF:models/whisper/modeling_whisper.py:612-617
+            raise ValueError(
+                f"Whisper expects the mel input features to be of length {2 * self.T}, but found {mel.shape[-1]} "
+                f"(shape {tuple(mel.shape)})")
+        out = None
+        if return_hidden:
+            out = torch.empty((B, self.T, self.d_model), dtype=hidden_dtype, device=self.device)
+        rc = self.lib.tw_encode(self.ctx, C.c_void_p(mel.data_ptr()), _TORCH2TW[mel.dtype], B,
+                                C.c_void_p(out.data_ptr()) if out is not None else None,
+                                _TORCH2TW[hidden_dtype], _stream_ptr(self.device))
+        self._chk(rc, "tw_encode")
+        return out
+
+    def cross_kv(self, B: int):
+        self._chk(self.lib.tw_cross_kv(self.ctx, B, _stream_ptr(self.device)), "tw_cross_kv")
+
+    # ---- A6-A8 (teacher-forced stepping, used by the parity tests) ---------------------------
+    def decoder_reset(self, B: int):
+        self._chk(self.lib.tw_decoder_reset(self.ctx, B, _stream_ptr(self.device)), "tw_decoder_reset")
+
+    def decode_step(self, ids: Sequence[int], want_logits: bool = True) -> Optional[torch.Tensor]:
+        B = len(ids)
+        arr = (C.c_int32 * B)(*[int(i) for i in ids])
+        out = torch.empty((B, self.vocab), dtype=torch.float32, device=self.device) if want_logits else None
+        rc = self.lib.tw_decode_step(self.ctx, B, arr, C.c_void_p(out.data_ptr()) if out is not None else None,
+                                     _stream_ptr(self.device))
+        self._chk(rc, "tw_decode_step")
+        return out
+
+    # ---- A9/A10 ------------------------------------------------------------------------------
+    def generate_greedy(
+        self,
+        prompt: np.ndarray,
+        max_new_tokens: int = 128,
+        min_new_tokens: int = 0,
+        max_length: int = 448,
+        eos_id: int = 50257,
+        pad_id: int = 50257,
+        timestamps: bool = False,
+        no_timestamps_id: int = 50364,
+        max_initial_timestamp_index: Optional[int] = 50,
+        begin_suppress: Iterable[int] = (220, 50257),
+        suppress: Iterable[int] = (),
+        want_alignment: bool = False,
+    ) -> Dict[str, np.ndarray]:
+        prompt = np.ascontiguousarray(prompt, dtype=np.int32)
+        B, n0 = prompt.shape
+        o = _cabi.tw_greedy_opts()
+        o.eos_id, o.pad_id = int(eos_id), int(pad_id)
+        o.max_new_tokens, o.min_new_tokens, o.max_length = int(max_new_tokens), int(min_new_tokens), int(max_length)
+        o.timestamps = 1 if timestamps else 0
+        o.no_timestamps_id = int(no_timestamps_id)
+        o.max_initial_timestamp_index = -1 if max_initial_timestamp_index is None else int(max_initial_timestamp_index)
+        bs = [int(x) for x in begin_suppress]
+        sp = [int(x) for x in suppress]
+        bs_arr = (C.c_int32 * max(1, len(bs)))(*bs)
+        sp_arr = (C.c_int32 * max(1, len(sp)))(*sp)
+        o.n_begin_suppress, o.begin_suppress = len(bs), bs_arr
+        o.n_suppress, o.suppress = len(sp), sp_arr
+        o.want_alignment = 1 if want_alignment else 0
+        out = np.full((B, int(max_length)), pad_id, dtype=np.int32)
+        out_len = C.c_int32(0)
+        rc = self.lib.tw_generate_greedy(self.ctx, B, prompt.ctypes.data_as(C.POINTER(C.c_int32)), n0, C.byref(o),
+                                         out.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(out_len),
+                                         _stream_ptr(self.device))
+        self._chk(rc, "tw_generate_greedy")
+        L = int(out_len.value)
+        return {"sequences": out[:, :L].astype(np.int64), "length": L}
+
+    # ---- A11 ---------------------------------------------------------------------------------
+    def token_timestamps(self, B: int, n_prompt: int, seq_len: int, num_frames: Optional[Sequence[int]] = None,
+                         time_precision: float = 0.02) -> np.ndarray:
+        out = np.zeros((B, seq_len), dtype=np.float32)
+        nf = None
+        if num_frames is not None:
+            nf = (C.c_int32 * B)(*[int(x) for x in num_frames])
+        rc = self.lib.tw_token_timestamps(self.ctx, B, n_prompt, seq_len, nf, float(time_precision),
+                                          out.ctypes.data_as(C.POINTER(C.c_float)), _stream_ptr(self.device))
+        self._chk(rc, "tw_token_timestamps")
+        return out
+
+    def get_alignment(self, B: int, n_rows: int) -> np.ndarray:
+        out = np.zeros((B, len(self.alignment_heads), n_rows, self.T), dtype=np.float32)
+        rc = self.lib.tw_get_alignment(self.ctx, B, n_rows, out.ctypes.data_as(C.POINTER(C.c_float)),
+                                       _stream_ptr(self.device))
+        self._chk(rc, "tw_get_alignment")
+        return out
+
+    def last_timings(self) -> Dict[str, float]:
+        ms = (C.c_float * 5)()
+        steps = C.c_int32(0)
+        self._chk(self.lib.tw_last_timings(self.ctx, ms, C.byref(steps)), "tw_last_timings")
+        names = ["logmel_ms", "encode_ms", "cross_kv_ms", "greedy_ms", "token_timestamps_ms"]
+        d = {n: float(ms[i]) for i, n in enumerate(names)}
+        d["decode_steps"] = int(steps.value)
+        return d
