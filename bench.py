@@ -1,0 +1,316 @@
+#!/usr/bin/env python3
+"""bench.py - BASELINE.json's headline metric on MI355X: transcription tokens/sec, whisper-large-v3, 10 s chunks.
+
+One "step" = one pass of the whole hot path over one batch of synthetic 16 kHz audio that is already
+resident in HBM:  log-mel -> encoder -> cross-K/V -> 128-token greedy decode (timestamp grammar on, as the
+reference's streaming backend always runs it, R:thestage_speechkit/streaming/streaming_pipeline.py:395-410)
+-> alignment DTW (word timestamps).  Per GPU the workload is `--streams` (default 16) concurrent 10 s
+chunks = configs[3]'s per-GPU share (128 streams / 8 GPUs); N GPUs run N independent replicas on
+disjoint streams (weak scaling, no data-path collective - SURVEY.md section 8e).
+
+Launch: `python bench.py` (1 GPU) or
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import dataclasses
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+DIMS = {
+    "large-v3": dict(d_model=1280, enc_layers=32, dec_layers=32, heads=20, ffn=5120, vocab=51866, n_mels=128,
+                     max_source_positions=1500, max_target_positions=448),
+    "large-v3-turbo": dict(d_model=1280, enc_layers=32, dec_layers=4, heads=20, ffn=5120, vocab=51866, n_mels=128,
+                           max_source_positions=1500, max_target_positions=448),
+    "tiny.en": dict(d_model=384, enc_layers=4, dec_layers=4, heads=6, ffn=1536, vocab=51864, n_mels=80,
+                    max_source_positions=1500, max_target_positions=448),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def random_state_dict(dims, device, seed=0):
+    """Random-init weights of the named architecture, generated on the GPU in the HF state_dict layout."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    d, f, v = dims["d_model"], dims["ffn"], dims["vocab"]
+
+    def uni(shape, amp):
+        return (torch.rand(shape, device=device, generator=g, dtype=torch.float32) - 0.5) * (2 * amp)
+
+    sd = {}
+
+    def lin(name, o, i, bias=True):
+        sd[name + ".weight"] = uni((o, i), 1.7 / i ** 0.5)
+        if bias:
+            sd[name + ".bias"] = uni((o,), 0.05)
+
+    def ln(name):
+        sd[name + ".weight"] = 1.0 + uni((d,), 0.1)
+        sd[name + ".bias"] = uni((d,), 0.05)
+
+    def attn(p):
+        lin(p + ".k_proj", d, d, False)
+        lin(p + ".v_proj", d, d)
+        lin(p + ".q_proj", d, d)
+        lin(p + ".out_proj", d, d)
+
+    e = "model.encoder"
+    sd[e + ".conv1.weight"] = uni((d, dims["n_mels"], 3), 1.7 / (3 * dims["n_mels"]) ** 0.5)
+    sd[e + ".conv1.bias"] = uni((d,), 0.05)
+    sd[e + ".conv2.weight"] = uni((d, d, 3), 1.7 / (3 * d) ** 0.5)
+    sd[e + ".conv2.bias"] = uni((d,), 0.05)
+    sd[e + ".embed_positions.weight"] = uni((dims["max_source_positions"], d), 0.5)
+    for i in range(dims["enc_layers"]):
+        p = f"{e}.layers.{i}"
+        attn(p + ".self_attn"); ln(p + ".self_attn_layer_norm"); lin(p + ".fc1", f, d); lin(p + ".fc2", d, f); ln(p + ".final_layer_norm")
+    ln(e + ".layer_norm")
+    dd = "model.decoder"
+    sd[dd + ".embed_tokens.weight"] = uni((v, d), 0.12)
+    sd[dd + ".embed_positions.weight"] = uni((dims["max_target_positions"], d), 0.12)
+    for i in range(dims["dec_layers"]):
+        p = f"{dd}.layers.{i}"
+        attn(p + ".self_attn"); ln(p + ".self_attn_layer_norm"); attn(p + ".encoder_attn"); ln(p + ".encoder_attn_layer_norm")
+        lin(p + ".fc1", f, d); lin(p + ".fc2", d, f); ln(p + ".final_layer_norm")
+    ln(dd + ".layer_norm")
+    return sd
+
+
+def alignment_heads(dims):
+    n = min(10, max(2, dims["dec_layers"] * 2))
+    out = []
+    for j in range(n):
+        layer = dims["dec_layers"] - 1 - (j % max(1, dims["dec_layers"] // 2))
+        head = (3 * j + 1) % dims["heads"]
+        if (layer, head) not in out:
+            out.append((layer, head))
+    return out
+
+
+def algorithmic_decode_bytes(dims, B, T, n_prompt, steps, esz=2):
+    """bytes/step = W + B*163840*(T + t) (large-v3 numbers generalised):
+    W = esz*(Ld*14*d^2 + V*d); per stream and step the cross K/V (2*Ld*T*d*esz) and the self K/V read so far."""
+    d, Ld, V = dims["d_model"], dims["dec_layers"], dims["vocab"]
+    W = esz * (Ld * (4 * d * d + 4 * d * d + 2 * d * dims["ffn"]) + V * d)
+    total = 0
+    for s in range(steps):
+        t = s + 1
+        total += W + B * (2 * Ld * d * esz) * (T + t)
+    return total, W
+
+
+def cpu_baseline(model_name, chunk_s, new_tokens):
+    """The reference's PyTorch-CPU arithmetic (HF transformers generate, fp32, all host cores) on a bounded
+    sample: ONE 10 s chunk, `new_tokens` forced tokens.  oracle/ is imported only here (reported baseline)."""
+    from oracle import hf_reference as hr
+    from oracle import whisper_oracle as wo
+    from transformers import WhisperForConditionalGeneration
+    from transformers.initialization import no_init_weights
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    dims = wo.PRESETS[model_name]
+    t0 = time.time()
+    with no_init_weights():
+        model = WhisperForConditionalGeneration(hr.build_hf_config(dims))
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.dim() >= 2:
+                p.uniform_(-1.7 / p.shape[-1] ** 0.5, 1.7 / p.shape[-1] ** 0.5)
+            elif "layer_norm" in name and name.endswith("weight"):
+                p.fill_(1.0)
+            else:
+                p.zero_()
+    model.eval()
+    hr.fill_generation_config(model.generation_config, dims)
+    hr.patch_chunk_length(model, chunk_s)
+    fe = hr.build_feature_extractor(dims, chunk_s)
+    t_init = time.time() - t0
+    pcm = wo.synth_audio(chunk_s * 16000, 0, "noise")
+    with torch.no_grad():  # untimed warm-up: first-call costs of torch.stft / generate set-up
+        feats = fe(pcm, sampling_rate=16000, return_tensors="pt", return_attention_mask=True)
+        model.generate(input_features=feats.input_features, attention_mask=feats.attention_mask, language="en",
+                       return_timestamps=True, num_beams=1, do_sample=False, use_cache=True, max_new_tokens=1,
+                       force_unique_generate_call=True)
+    t0 = time.time()
+    with torch.no_grad():
+        feats = fe(pcm, sampling_rate=16000, return_tensors="pt", return_attention_mask=True)
+        out = model.generate(input_features=feats.input_features, attention_mask=feats.attention_mask, language="en",
+                             return_timestamps=True, num_beams=1, do_sample=False, use_cache=True,
+                             max_new_tokens=new_tokens, min_new_tokens=new_tokens, force_unique_generate_call=True)
+    dt = time.time() - t0
+    seqs = out["sequences"] if isinstance(out, dict) else out
+    n_tok = int(seqs.shape[0] * new_tokens)
+    return {
+        "value": round(n_tok / dt, 3), "unit": "tok/s", "cores": cores, "kind": "reference",
+        "sample": (f"HF transformers WhisperForConditionalGeneration.generate on CPU fp32 (the arithmetic behind the reference's "
+                   f"nvidia HF branch, R:thestage_speechkit/nvidia/asr_pipeline.py:57-60), {model_name} dims random weights, "
+                   f"1 stream x {chunk_s} s chunk, log-mel+encoder+{new_tokens} forced tokens, {dt:.1f} s wall (+{t_init:.1f} s init)"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="large-v3")
+    ap.add_argument("--chunk-s", type=int, default=10)
+    ap.add_argument("--streams", type=int, default=16, help="concurrent streams per GPU")
+    ap.add_argument("--new-tokens", type=int, default=128)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tokens", type=int, default=16)
+    ap.add_argument("--latency-iters", type=int, default=10)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        dist = dist_mod
+
+    from thewhisper_amd.engine import WhisperEngine
+
+    dims = DIMS[args.model]
+    T = 50 * args.chunk_s
+    B = args.streams
+    dev = torch.device("cuda", local)
+    heads = alignment_heads(dims)
+    eng = WhisperEngine(dims, T, max_batch=B, dtype=args.dtype, alignment_heads=heads, device=local,
+                        use_graph=not args.no_graph)
+    sd = random_state_dict(dims, dev, seed=0)
+    eng.load_state_dict(sd)
+    del sd
+    torch.cuda.empty_cache()
+
+    n_samples = args.chunk_s * 16000
+    g = torch.Generator(device=dev)
+    g.manual_seed(1000 + rank)
+    pcm = (torch.randn((B, n_samples), device=dev, generator=g, dtype=torch.float32) * 0.1).clamp_(-1, 1)
+    prompt = np.tile(np.array([[50258, 50259, 50360]], dtype=np.int32), (B, 1))
+    n_prompt = prompt.shape[1]
+
+    def step(nb=B, pc=pcm, pr=prompt):
+        mel = eng.logmel(pc[:nb])
+        eng.encode(mel)
+        eng.cross_kv(nb)
+        out = eng.generate_greedy(pr[:nb], max_new_tokens=args.new_tokens, min_new_tokens=args.new_tokens,
+                                  timestamps=True, want_alignment=True)
+        L = out["length"]
+        eng.token_timestamps(nb, n_prompt, L, [2 * T] * nb)
+        return L - n_prompt
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    new_tok = 0
+    stage = {"logmel_ms": 0.0, "encode_ms": 0.0, "cross_kv_ms": 0.0, "greedy_ms": 0.0, "token_timestamps_ms": 0.0}
+    dec_steps = 0
+    for _ in range(args.steps):
+        new_tok += step() * B
+        tm = eng.last_timings()  # HIP events recorded on the launch stream inside the library
+        for k in stage:
+            stage[k] += tm[k]
+        dec_steps += tm["decode_steps"]
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        nt = torch.tensor([new_tok], device=dev, dtype=torch.int64)
+        dist.all_reduce(nt, op=dist.ReduceOp.SUM)
+        new_tok = int(nt.item())
+
+    # single-stream chunk latency (config 3 shape): same engine, B = 1
+    lat = []
+    if rank == 0 and args.latency_iters > 0:
+        step(1)
+        for _ in range(args.latency_iters):
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            step(1)
+            torch.cuda.synchronize()
+            lat.append((time.perf_counter() - a) * 1e3)
+
+    if rank == 0:
+        esz = 2 if args.dtype == "bf16" else 4
+        steps_per_call = dec_steps // max(1, args.steps)
+        alg_bytes, W = algorithmic_decode_bytes(dims, B, T, n_prompt, steps_per_call, esz)
+        greedy_ms = stage["greedy_ms"] / args.steps
+        achieved = alg_bytes / (greedy_ms * 1e-3) / 1e9 if greedy_ms > 0 else 0.0
+        result = {
+            "metric": "transcription tokens/sec (node), whisper-large-v3 10s chunks" if args.model == "large-v3" and args.chunk_s == 10
+            else f"transcription tokens/sec (node), whisper-{args.model} {args.chunk_s}s chunks",
+            "value": round(new_tok / dt, 2),
+            "unit": "tok/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic 16 kHz gaussian audio (sigma 0.1), random-init weights of the named architecture",
+            "config": {
+                "workload": f"whisper-{args.model}, {args.chunk_s} s chunks, {B} concurrent streams per GPU (configs[3] per-GPU share), "
+                            f"{args.new_tokens} new tokens/stream forced (min=max), timestamp grammar + word-timestamp DTW on",
+                "streams_per_gpu": B, "chunk_seconds": args.chunk_s, "new_tokens": args.new_tokens,
+                "parallelism": f"replicas x{world} (streams sharded, no collective on the data path)",
+                "decode_step_graph": not args.no_graph,
+            },
+            "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage.items()},
+            "decode_tok_per_s": round(B * args.new_tokens / (greedy_ms * 1e-3), 1) if greedy_ms > 0 else None,
+            "roofline": {
+                "kernel": "decode step (weight-streaming gemv + single-query attention over the KV caches), all steps of one call",
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes_per_call": alg_bytes, "weight_bytes_per_step": W, "launches_per_call": steps_per_call,
+                "avg_launch_ms": round(greedy_ms / max(1, steps_per_call), 4),
+            },
+        }
+        if lat:
+            lat.sort()
+            result["p50_chunk_latency_ms"] = round(lat[len(lat) // 2], 2)
+            result["chunk_latency_note"] = f"1 stream, {args.chunk_s} s chunk, {args.new_tokens} tokens + DTW, {len(lat)} calls"
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(args.model, args.chunk_s, args.cpu_tokens)
+            except Exception as e:  # noqa: BLE001
+                result["cpu_baseline"] = {"value": None, "unit": "tok/s", "cores": os.cpu_count(), "kind": "reference",
+                                          "sample": f"failed: {e!r}"}
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -98,7 +98,7 @@ def build_hf_model(dims: WhisperDims, weights: Dict[str, np.ndarray], dtype=None
     cls = model_cls or WhisperForConditionalGeneration
     cfg = build_hf_config(dims)
     try:
-        from transformers.modeling_utils import no_init_weights
+        from transformers.initialization import no_init_weights
 
         with no_init_weights():
             model = cls(cfg)
@@ -118,6 +118,18 @@ def build_hf_model(dims: WhisperDims, weights: Dict[str, np.ndarray], dtype=None
     return model
 
 
+def _bytes_to_unicode():
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(ord("\u00a1"), ord("\u00ac") + 1)) + list(range(ord("\u00ae"), ord("\u00ff") + 1))
+    cs = bs[:]
+    n = 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b)
+            cs.append(256 + n)
+            n += 1
+    return dict(zip(bs, [chr(c) for c in cs]))
+
+
 def build_tokenizer(dims: WhisperDims):
     """In-memory synthetic ``WhisperTokenizer`` with the large-v3 special-token id layout
     (ctor HF:models/whisper/tokenization_whisper.py:206-276)."""
@@ -125,10 +137,8 @@ def build_tokenizer(dims: WhisperDims):
 
     st = SpecialTokens()
     vocab: Dict[str, int] = {}
-    # byte-level alphabet first (GPT-2 bytes_to_unicode ordering is irrelevant here: any 256 distinct symbols)
-    from transformers.models.whisper.tokenization_whisper import bytes_to_unicode
-
-    for ch in bytes_to_unicode().values():
+    # byte-level alphabet first (the GPT-2 byte<->unicode table used by the ByteLevel pre-tokenizer/decoder)
+    for ch in _bytes_to_unicode().values():
         vocab[ch] = len(vocab)
     i = 0
     while len(vocab) < st.eos:
@@ -150,7 +160,8 @@ def build_tokenizer(dims: WhisperDims):
         merges=[],
         language="en",
         task="transcribe",
-        additional_special_tokens=specials[1:],
+        # timestamps are ordinary added tokens upstream: `timestamp_begin = all_special_ids[-1] + 1`
+        additional_special_tokens=[t for t in specials[1:] if vocab[t] <= st.no_timestamps],
         pad_token="<|endoftext|>",
         bos_token="<|endoftext|>",
         eos_token="<|endoftext|>",

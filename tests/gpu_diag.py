@@ -55,7 +55,7 @@ def check_encoder(preset, T, B, dtype, enc_layers, tol, over=None):
     dims = dims_variant(preset, enc_layers=enc_layers, dec_layers=0, **(over or {}))
     w = wo.make_weights(dims, 1)
     eng = make_engine(dims, w, T=T, max_batch=B, dtype=dtype)
-    pcm = clips(T * 320, ["speechlike", "noise", "sine", "speechlike"][:B])
+    pcm = clips(T * 320, B)
     mel = wo.log_mel(pcm, dims.n_mels)
     om = wo.OracleWhisper(dims, w, T=T)
     t0 = time.time()
@@ -74,7 +74,7 @@ def check_decoder(preset, T, B, dtype, dec_layers, tol, over=None, n_steps=6):
     w = wo.make_weights(dims, 2)
     heads = [(dec_layers - 1, 0), (dec_layers - 1, 1)] if dec_layers > 0 else []
     eng = make_engine(dims, w, T=T, max_batch=B, dtype=dtype, heads=heads)
-    pcm = clips(T * 320, ["speechlike", "noise", "sine", "speechlike"][:B])
+    pcm = clips(T * 320, B)
     mel = wo.log_mel(pcm, dims.n_mels)
     om = wo.OracleWhisper(dims, w, T=T)
     enc = om.encode(mel)
@@ -101,7 +101,7 @@ def check_greedy(preset, T, B, dtype, max_new, use_graph, min_new=0):
     w = wo.make_weights(dims, 0)
     heads = [(dims.dec_layers - 1, 0), (dims.dec_layers - 1, 1)]
     eng = make_engine(dims, w, T=T, max_batch=B, dtype=dtype, heads=heads, use_graph=use_graph)
-    pcm = clips(T * 320, ["speechlike", "noise", "sine", "speechlike"][:B])
+    pcm = clips(T * 320, B)
     mel_ref = wo.log_mel(pcm, dims.n_mels)
     mel = eng.logmel(torch.from_numpy(pcm).cuda(), out_dtype=torch.float32)
     eng.encode(mel)

@@ -1,0 +1,81 @@
+"""CPU stand-in for ``thewhisper_amd.engine.WhisperEngine`` backed by the numpy oracle.
+
+TESTS ONLY.  It lets the HF glue of the product package (``model.py``, ``asr_pipeline.py``, ``streaming.py``,
+``feature_extraction.py``) be exercised on a machine without a GPU and compared with the reference's own
+pipeline; the product never imports it - it is injected through the ``engine_factory`` test seam.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from oracle import whisper_oracle as wo
+
+
+class OracleEngine:
+    def __init__(self, dims: Dict[str, int], T: int, max_batch: int, dtype: str, alignment_heads, device_index: int = 0):
+        self.dims = wo.WhisperDims(**{k: dims[k] for k in ("d_model", "enc_layers", "dec_layers", "heads", "ffn", "vocab", "n_mels")},
+                                   max_target_positions=dims.get("max_target_positions", 448))
+        self.T = T
+        self.max_batch = max_batch
+        self.n_mels = self.dims.n_mels
+        self.vocab = self.dims.vocab
+        self.d_model = self.dims.d_model
+        self.alignment_heads = [tuple(h) for h in alignment_heads]
+        self.model: Optional[wo.OracleWhisper] = None
+        self.calls = {"logmel": 0, "encode": 0, "generate": 0, "dtw": 0}
+
+    def load_state_dict(self, sd):
+        w = {k: v.detach().float().cpu().numpy() for k, v in sd.items()}
+        self.model = wo.OracleWhisper(self.dims, w, T=self.T)
+
+    def logmel(self, pcm: torch.Tensor, n_valid=None, n_samples=None, out_dtype=None) -> torch.Tensor:
+        self.calls["logmel"] += 1
+        x = pcm.detach().cpu().numpy()
+        if x.ndim == 1:
+            x = x[None]
+        if n_valid is not None:
+            x = np.stack([np.where(np.arange(x.shape[1]) < nv, x[i], 0) for i, nv in enumerate(n_valid)])
+        return torch.from_numpy(wo.log_mel(x, self.n_mels, n_samples))
+
+    def encode(self, mel: torch.Tensor, return_hidden=False, hidden_dtype=torch.float32):
+        self.calls["encode"] += 1
+        m = mel.detach().float().cpu().numpy()
+        if m.shape[1:] != (self.n_mels, 2 * self.T):
+            raise ValueError(f"Whisper expects the mel input features to be of length {2 * self.T}, but found {m.shape[-1]}")
+        self._enc = self.model.encode(m)
+        return torch.from_numpy(self._enc) if return_hidden else None
+
+    def cross_kv(self, B: int):
+        assert self._enc.shape[0] >= B
+
+    def decoder_reset(self, B: int):
+        self._cache = self.model.new_cache(self._enc[:B])
+
+    def decode_step(self, ids: Sequence[int], want_logits: bool = True):
+        lg, _ = self.model.decode(np.asarray(ids)[:, None], self._cache)
+        return torch.from_numpy(lg[:, 0].astype(np.float32))
+
+    def generate_greedy(self, prompt, max_new_tokens=128, min_new_tokens=0, max_length=448, eos_id=50257, pad_id=50257,
+                        timestamps=False, no_timestamps_id=50364, max_initial_timestamp_index=50, begin_suppress=(220, 50257),
+                        suppress=(), want_alignment=False):
+        self.calls["generate"] += 1
+        opt = wo.GreedyOptions(eos=eos_id, pad=pad_id, max_new_tokens=max_new_tokens, min_new_tokens=min_new_tokens,
+                               max_length=max_length, begin_suppress=tuple(begin_suppress), suppress=tuple(suppress),
+                               timestamps=timestamps, no_timestamps_id=no_timestamps_id,
+                               max_initial_timestamp_index=max_initial_timestamp_index,
+                               alignment_heads=self.alignment_heads if want_alignment else None)
+        B = prompt.shape[0]
+        res = wo.greedy_generate(self.model, self._enc[:B], np.asarray(prompt), opt)
+        self._cross = res["cross"]
+        return {"sequences": res["sequences"], "length": int(res["sequences"].shape[1])}
+
+    def token_timestamps(self, B, n_prompt, seq_len, num_frames=None, time_precision=0.02):
+        self.calls["dtw"] += 1
+        return wo.token_timestamps(self._cross[:B, :, : seq_len - 1], n_prompt, num_frames, time_precision)
+
+
+def oracle_engine_factory(dims, T, max_batch, dtype, alignment_heads, device_index):
+    return OracleEngine(dims, T, max_batch, dtype, alignment_heads, device_index)

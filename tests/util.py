@@ -27,7 +27,13 @@ def make_engine(dims: wo.WhisperDims, weights: Dict[str, np.ndarray], T: int, ma
                                             alignment_heads=list(heads), use_graph=use_graph)
 
 
-def clips(n_samples: int, kinds: Sequence[str]) -> np.ndarray:
+KINDS = ["speechlike", "noise", "sine", "speechlike"]
+
+
+def clips(n_samples: int, kinds) -> np.ndarray:
+    """`kinds`: list of clip kinds, or an int B (cycles through KINDS with seed = index)."""
+    if isinstance(kinds, int):
+        kinds = [KINDS[i % len(KINDS)] for i in range(kinds)]
     return np.stack([wo.synth_audio(n_samples, seed=i, kind=k) for i, k in enumerate(kinds)])
 
 

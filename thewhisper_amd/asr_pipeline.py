@@ -1,0 +1,85 @@
+"""``thewhisper_amd.ASRPipeline`` - the MI355X sibling of ``thestage_speechkit.nvidia.ASRPipeline``.
+
+Mirrors R:thestage_speechkit/nvidia/asr_pipeline.py:30-92 argument for argument (same constructor
+names and meaning, same ValueErrors, same call contract): a subclass of HF's
+``AutomaticSpeechRecognitionPipeline`` (chunking, batching and the stride-aware LCS merge stay on
+the host, exactly as in the reference), with the model object replaced by
+``AMDWhisperForConditionalGeneration`` and the feature extractor by ``AMDWhisperFeatureExtractor``.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Union
+
+import torch
+from transformers import (
+    AutomaticSpeechRecognitionPipeline,
+    PreTrainedTokenizer,
+    SequenceFeatureExtractor,
+    WhisperFeatureExtractor,
+    WhisperTokenizer,
+)
+from transformers import WhisperForConditionalGeneration as HFWhisperForConditionalGeneration
+
+from . import lcs_patch  # noqa: F401  (installs the reference's chunk-merge fix, R:thestage_speechkit/__init__.py:137-139)
+from .feature_extraction import AMDWhisperFeatureExtractor
+from .model import AMDWhisperForConditionalGeneration
+
+
+class ASRPipeline(AutomaticSpeechRecognitionPipeline):
+    def __init__(
+        self,
+        model: Union[str, HFWhisperForConditionalGeneration],
+        feature_extractor: Optional[SequenceFeatureExtractor] = None,
+        tokenizer: Optional[PreTrainedTokenizer] = None,
+        model_size: str = None,
+        chunk_length_s: int = 30,
+        device: str = "cuda",
+        torch_dtype: Optional[torch.dtype] = None,
+        **kwargs,
+    ):
+        revision = kwargs.pop("revision", "main")
+        engine_factory: Optional[Callable] = kwargs.pop("engine_factory", None)  # test seam only
+        if model_size not in (None, "S", "M", "L", "XL"):
+            raise ValueError(f"Invalid model_size: {model_size}")
+        # model_size selects a TheStage engine flavour on NVIDIA (S = quantised, XL = fp16).  On MI355X every
+        # size currently maps to the bf16 kernels (fp8 weights: SURVEY.md section 8, config 5 - next round).
+
+        if type(model) is str:
+            model_name = model
+            model = AMDWhisperForConditionalGeneration.from_pretrained(model_name, torch_dtype=torch_dtype, revision=revision)
+            if feature_extractor is None:
+                feature_extractor = WhisperFeatureExtractor.from_pretrained(
+                    model_name, torch_dtype=torch_dtype, chunk_length=chunk_length_s
+                )
+            if tokenizer is None:
+                tokenizer = WhisperTokenizer.from_pretrained(model_name, torch_dtype=torch_dtype)
+        else:
+            if feature_extractor is None:
+                raise ValueError("feature_extractor must be provided when passing a model instance")
+            if tokenizer is None:
+                raise ValueError("tokenizer must be provided when passing a model instance")
+            model = AMDWhisperForConditionalGeneration.from_hf(model)
+
+        feature_extractor = AMDWhisperFeatureExtractor.from_hf(feature_extractor)
+        if feature_extractor.chunk_length != chunk_length_s:
+            raise ValueError(
+                f"feature_extractor.chunk_length={feature_extractor.chunk_length} must equal chunk_length_s={chunk_length_s}: "
+                "the encoder sees exactly 50*chunk_length_s frames"
+            )
+
+        super().__init__(
+            model,
+            feature_extractor=feature_extractor,
+            tokenizer=tokenizer,
+            device=device,
+            chunk_length_s=chunk_length_s,
+            torch_dtype=torch_dtype,
+            **kwargs,
+        )
+        # A0 (patch_hf_model) happens inside the library when the engine is built for T = 50*chunk_length_s.
+        batch_size = int(kwargs.get("batch_size") or 1)
+        engine = self.model.build_engine(
+            chunk_length_s=chunk_length_s, max_batch=max(1, min(16, batch_size)), dtype=torch_dtype,
+            engine_factory=engine_factory,
+        )
+        self.feature_extractor.attach_engine(engine)

@@ -26,10 +26,13 @@ __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f +
 
 template <typename T> __device__ __forceinline__ float dot16(const u32x4_t& w, const u32x4_t& x, float acc);
 template <> __device__ __forceinline__ float dot16<bf16_t>(const u32x4_t& w, const u32x4_t& x, float acc) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w[i]), __builtin_bit_cast(bf16x2_t, x[i]), acc,
-                                          false);
+  // NB: written without a loop over w[i]: hipcc (ROCm 7.2) folded `bit_cast<bf16x2>(w[i])` in an unrolled
+  // loop to element 0 for every i (seen in the ISA: four identical v_dot2c), so the pairs are named.
+  const bf16x8_t a = __builtin_bit_cast(bf16x8_t, w), b = __builtin_bit_cast(bf16x8_t, x);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 4, 5), __builtin_shufflevector(b, b, 4, 5), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 6, 7), __builtin_shufflevector(b, b, 6, 7), acc, false);
   return acc;
 }
 template <> __device__ __forceinline__ float dot16<float>(const u32x4_t& w, const u32x4_t& x, float acc) {
@@ -60,135 +63,212 @@ template <> __device__ __forceinline__ u32x4_t pack16<bf16_t>(const float* in) {
   return __builtin_bit_cast(u32x4_t, f);
 }
 
-constexpr int GEMV_KC = 1280;  // K chunk staged in LDS (elements)
+constexpr int GEMV_LDS_BUDGET = 80 * 1024;  // activations staged per workgroup (2 workgroups / CU)
+constexpr int GEMV_D = 4;                    // weight vectors in flight per lane and row (register ring)
+constexpr int GEMV_RG = 8;                   // row groups per workgroup for very tall matrices (logits)
 
-template <typename T, int BT, int R>
+template <typename T, int BT> struct GemvChunk {
+  static constexpr int E = ElemTraits<T>::kPer16B;
+  // largest K chunk (in 16-B vectors, multiple of 64) whose BT activation rows fit the LDS budget
+  static constexpr int kVec = (GEMV_LDS_BUDGET / (BT * 16) / 64) * 64;
+};
+
+// y[b, n] = epi( LN?(x[b, :]) . W[n, :] )   one wavefront = R rows x full K, lanes stride K by 16 B.
+// Latency structure (the decode step is a chain of ~260 such launches, so this matters as much as
+// bandwidth): the first GEMV_D weight vectors of every row and the LayerNorm gain/bias vectors are
+// requested BEFORE the activations are staged, the staging loads are issued in batches of 8 per
+// thread, and the rows a wavefront normalises are independent instruction streams, so the HBM
+// latency of W overlaps the L2 latency of x and the LayerNorm arithmetic.
+template <typename T, int BT, int R, bool MULTI>
 __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
   constexpr int E = ElemTraits<T>::kPer16B;
-  constexpr int MAXV = (GEMV_KC / E + 63) / 64;  // 16-B vectors per lane per chunk
+  constexpr int D = GEMV_D;
+  constexpr int CV = GemvChunk<T, BT>::kVec;  // vectors per chunk in chunked mode
+  constexpr int IPC = CV / 64;
+  constexpr int MAXV = (1280 / E + 63) / 64;  // LayerNorm rows have K <= 1280
+  constexpr int RPW = (BT + 3) / 4;           // LayerNorm rows per wavefront
+  constexpr int RG = MULTI ? GEMV_RG : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u32x4_t* xs = reinterpret_cast<u32x4_t*>(smem);  // [BT][kcv] 16-B vectors
+  u32x4_t* xs = reinterpret_cast<u32x4_t*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = a.K, N = a.N, B = a.B;
   const T* x = reinterpret_cast<const T*>(a.x);
   const T* W = reinterpret_cast<const T*>(a.W);
-  const int row0 = (blockIdx.x * 4 + wave) * R;
+  const int nv_row = K / E;
+  const int n_it = (nv_row + 63) / 64;
+  const bool chunked = nv_row > CV;
+  const int xld = chunked ? CV : nv_row;  // LDS row stride in vectors
+  const bool has_ln = a.ln_g != nullptr;
 
-  float acc[R][BT];
+  int row0 = ((blockIdx.x * RG) * 4 + wave) * R;
+  const T* wrow[R];
+  u32x4_t wq[D][R];
+  auto prime = [&]() {
 #pragma unroll
-  for (int r = 0; r < R; ++r)
+    for (int r = 0; r < R; ++r) wrow[r] = W + (long long)min(row0 + r, N - 1) * K;
 #pragma unroll
-    for (int b = 0; b < BT; ++b) acc[r][b] = 0.f;
+    for (int j = 0; j < D; ++j) {
+      const int vi = j * 64 + lane;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        wq[j][r] = (vi < nv_row) ? *reinterpret_cast<const u32x4_t*>(wrow[r] + (long long)vi * E) : u32x4_t{0u, 0u, 0u, 0u};
+    }
+  };
+  prime();
 
-  for (int k0 = 0; k0 < K; k0 += GEMV_KC) {
-    const int kl = min(GEMV_KC, K - k0);
-    const int kcv = kl / E;  // vectors in this chunk
-    if (k0 > 0) __syncthreads();
-    // ---- stage activations (optionally LayerNorm'ed) into LDS ----
-    if (a.ln_g != nullptr) {
-      const T* g = reinterpret_cast<const T*>(a.ln_g);
-      const T* be = reinterpret_cast<const T*>(a.ln_b);
-      for (int b = wave; b < BT; b += 4) {
-        float v[MAXV][E];
+  // LayerNorm gain / bias for this lane's vectors (requested early, used after the staging barrier)
+  u32x4_t lg[MAXV], lb[MAXV];
+  if (has_ln) {
+    const T* g = reinterpret_cast<const T*>(a.ln_g);
+    const T* be = reinterpret_cast<const T*>(a.ln_b);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int vi = lane + i * 64;
+      lg[i] = (vi < nv_row) ? *reinterpret_cast<const u32x4_t*>(g + vi * E) : u32x4_t{0u, 0u, 0u, 0u};
+      lb[i] = (vi < nv_row) ? *reinterpret_cast<const u32x4_t*>(be + vi * E) : u32x4_t{0u, 0u, 0u, 0u};
+    }
+  }
+
+  // stage `cv` vectors per activation row starting at vector `cbase`; loads issued 8 per thread at a time
+  auto stage = [&](int cbase, int cv) {
+    const int total = BT * cv;
+    for (int i0 = tid; i0 < total; i0 += 256 * 8) {
+      u32x4_t tmp[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 256;
+        const int b = i / cv, vi = i - b * cv;
+        tmp[u] = (i < total && b < B) ? *reinterpret_cast<const u32x4_t*>(x + (long long)b * a.ldx + (long long)(cbase + vi) * E)
+                                       : u32x4_t{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 256;
+        if (i < total) { const int b = i / cv, vi = i - b * cv; xs[b * xld + vi] = tmp[u]; }
+      }
+    }
+  };
+
+  if (!chunked) {
+    stage(0, nv_row);
+    __syncthreads();
+    if (has_ln) {  // two-pass LayerNorm in place (eps 1e-5, biased variance), RPW independent rows per wavefront
+      float v[RPW][MAXV][E];
+      float mean[RPW], rstd[RPW];
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int b = wave + 4 * rr;
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
           const int vi = lane + i * 64;
-          if (vi < kcv && b < B) {
-            unpack16<T>(*reinterpret_cast<const u32x4_t*>(x + (long long)b * a.ldx + vi * E), v[i]);
+          if (vi < nv_row && b < BT) {
+            unpack16<T>(xs[b * xld + vi], v[rr][i]);
 #pragma unroll
-            for (int e = 0; e < E; ++e) s += v[i][e];
+            for (int e = 0; e < E; ++e) s += v[rr][i][e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[rr][i][e] = 0.f;
           }
         }
-        const float mean = wave_sum(s) / (float)K;
+        mean[rr] = s;
+      }
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) mean[rr] = wave_sum(mean[rr]) / (float)K;
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
           const int vi = lane + i * 64;
-          if (vi < kcv && b < B) {
+          if (vi < nv_row) {
 #pragma unroll
-            for (int e = 0; e < E; ++e) { const float c = v[i][e] - mean; q += c * c; }
+            for (int e = 0; e < E; ++e) { const float c = v[rr][i][e] - mean[rr]; q += c * c; }
           }
         }
-        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)K + 1e-5f);
+        rstd[rr] = q;
+      }
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) rstd[rr] = 1.0f / sqrtf(wave_sum(rstd[rr]) / (float)K + 1e-5f);
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int b = wave + 4 * rr;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
           const int vi = lane + i * 64;
-          if (vi < kcv) {
-            float o[E];
-            if (b < B) {
-              float gg[E], bb[E];
-              unpack16<T>(*reinterpret_cast<const u32x4_t*>(g + vi * E), gg);
-              unpack16<T>(*reinterpret_cast<const u32x4_t*>(be + vi * E), bb);
+          if (vi < nv_row && b < B) {
+            float gg[E], bb[E], o[E];
+            unpack16<T>(lg[i], gg);
+            unpack16<T>(lb[i], bb);
 #pragma unroll
-              for (int e = 0; e < E; ++e) o[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
-            } else {
-#pragma unroll
-              for (int e = 0; e < E; ++e) o[e] = 0.f;
-            }
-            xs[b * kcv + vi] = pack16<T>(o);
+            for (int e = 0; e < E; ++e) o[e] = (v[rr][i][e] - mean[rr]) * rstd[rr] * gg[e] + bb[e];
+            xs[b * xld + vi] = pack16<T>(o);
           }
         }
       }
-    } else {
-      for (int i = tid; i < BT * kcv; i += 256) {
-        const int b = i / kcv, vi = i % kcv;
-        u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
-        if (b < B) v = *reinterpret_cast<const u32x4_t*>(x + (long long)b * a.ldx + k0 + vi * E);
-        xs[i] = v;
-      }
-    }
-    __syncthreads();
-
-    // ---- stream the weight rows ----
-    const int nvi = (kcv + 63) / 64;
-    u32x4_t wcur[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int n = min(row0 + r, N - 1);
-      wcur[r] = (lane < kcv) ? *reinterpret_cast<const u32x4_t*>(W + (long long)n * K + k0 + lane * E)
-                             : u32x4_t{0u, 0u, 0u, 0u};
-    }
-    for (int i = 0; i < nvi; ++i) {
-      const int vi = i * 64 + lane;
-      u32x4_t wnext[R];
-      const int vn = vi + 64;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int n = min(row0 + r, N - 1);
-        wnext[r] = (i + 1 < nvi && vn < kcv) ? *reinterpret_cast<const u32x4_t*>(W + (long long)n * K + k0 + vn * E)
-                                              : u32x4_t{0u, 0u, 0u, 0u};
-      }
-      if (vi < kcv) {
-#pragma unroll
-        for (int b = 0; b < BT; ++b) {
-          const u32x4_t xv = xs[b * kcv + vi];
-#pragma unroll
-          for (int r = 0; r < R; ++r) acc[r][b] = dot16<T>(wcur[r], xv, acc[r][b]);
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < R; ++r) wcur[r] = wnext[r];
+      __syncthreads();
     }
   }
 
-  // ---- reduce across the wavefront, epilogue on lane b ----
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int b = 0; b < BT; ++b) acc[r][b] = wave_sum(acc[r][b]);
-
   const T* bias = reinterpret_cast<const T*>(a.bias);
   const T* res = reinterpret_cast<const T*>(a.res);
+  for (int grp = 0; grp < RG; ++grp) {
+    if (grp > 0) {
+      row0 = ((blockIdx.x * RG + grp) * 4 + wave) * R;
+      prime();
+    }
+    float acc[R][BT];
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int n = row0 + r;
-    if (n >= N) continue;
-    const float bv = bias ? (float)bias[n] : 0.f;
+    for (int r = 0; r < R; ++r)
 #pragma unroll
-    for (int b = 0; b < BT; ++b) {
-      if (lane == b && b < B) {
-        float v = acc[r][b] + bv;
+      for (int b = 0; b < BT; ++b) acc[r][b] = 0.f;
+
+    for (int it0 = 0; it0 < n_it; it0 += D) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const int it = it0 + j;
+        if (it < n_it) {
+          int cbase = 0;
+          if (chunked) {
+            cbase = (it / IPC) * CV;
+            if (it % IPC == 0) {
+              if (it > 0) __syncthreads();
+              stage(cbase, min(CV, nv_row - cbase));
+              __syncthreads();
+            }
+          }
+          const int vi = it * 64 + lane;
+          if (vi < nv_row) {
+#pragma unroll
+            for (int b = 0; b < BT; ++b) {
+              const u32x4_t xv = xs[b * xld + (vi - cbase)];
+#pragma unroll
+              for (int r = 0; r < R; ++r) acc[r][b] = dot16<T>(wq[j][r], xv, acc[r][b]);
+            }
+          }
+          const int vn = (it + D) * 64 + lane;
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+            wq[j][r] = (vn < nv_row) ? *reinterpret_cast<const u32x4_t*>(wrow[r] + (long long)vn * E) : u32x4_t{0u, 0u, 0u, 0u};
+        }
+      }
+    }
+
+    // ---- reduce across the wavefront; lane b then owns stream b (one predicated load/store per row, not BT
+    //      serialised divergent branches: those cost ~0.7 us of L2 latency each) ----
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int b = 0; b < BT; ++b) acc[r][b] = wave_sum(acc[r][b]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int n = row0 + r;
+      float mine = 0.f;
+#pragma unroll
+      for (int b = 0; b < BT; ++b) mine = (lane == b) ? acc[r][b] : mine;
+      if (n < N && lane < B) {
+        const int b = lane;
+        float v = mine + (bias ? (float)bias[n] : 0.f);
         if (a.gelu) v = gelu_exact(v);
         if (res) v += (float)res[(long long)b * a.ldres + n];
         if (a.y_f32) {
@@ -206,7 +286,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// single-query attention
+// single-query attention (decoder self-attention over the growing cache, cross-attention over the
+// cached encoder K/V).  One workgroup per (stream, head); thread = (key group kg, dim quad dq):
+// 16 lanes cover one 128-B (bf16) K or V row, NT/16 rows per wave instruction, U rows per thread in
+// flight.  Two passes with all loads of a pass issued back to back (the kernel is latency-, not
+// bandwidth-bound: ~130 KB per head): scores -> LDS, block max / sum, then P.V.
 // ---------------------------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ void load4(const T* p, float* o);
 template <> __device__ __forceinline__ void load4<float>(const float* p, float* o) {
@@ -218,16 +302,6 @@ template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float
   const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(p);
   o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
 }
-template <typename T> __device__ __forceinline__ void store4(T* p, const float* o);
-template <> __device__ __forceinline__ void store4<float>(float* p, const float* o) {
-  *reinterpret_cast<f32x4_t*>(p) = f32x4_t{o[0], o[1], o[2], o[3]};
-}
-template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float* o) {
-  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
-  bf16x4_t v;
-  v[0] = (bf16_t)o[0]; v[1] = (bf16_t)o[1]; v[2] = (bf16_t)o[2]; v[3] = (bf16_t)o[3];
-  *reinterpret_cast<bf16x4_t*>(p) = v;
-}
 
 __device__ __forceinline__ float group16_sum(float v) {
   v += __shfl_xor(v, 1, 64);
@@ -236,122 +310,138 @@ __device__ __forceinline__ float group16_sum(float v) {
   v += __shfl_xor(v, 8, 64);
   return v;
 }
-
-// Streams keys t = t_begin + tg, +4, ... < t_end for lane group tg = lane>>4; each lane owns dims dq*4..+3.
-// kbase/vbase point at row 0; rows are `stride` elements apart.  Produces the group-local (m, l, o[4]).
-template <typename T, bool SAVE>
-__device__ __forceinline__ void attend_range(const float* qv, const T* kbase, const T* vbase, long long stride,
-                                             int t_begin, int t_end, int lane, float& m, float& l, float* o,
-                                             float* score_out /* LDS, indexed by t */) {
-  const int tg = lane >> 4, dq = lane & 15;
-  m = -1.0e30f;
-  l = 0.f;
-  o[0] = o[1] = o[2] = o[3] = 0.f;
-#pragma unroll 4
-  for (int tt = t_begin; tt < t_end; tt += 4) {
-    const int t = tt + tg;
-    const bool valid = t < t_end;
-    const int tc = valid ? t : t_end - 1;
-    float kv[4], vv[4];
-    load4<T>(kbase + (long long)tc * stride + dq * 4, kv);
-    load4<T>(vbase + (long long)tc * stride + dq * 4, vv);
-    float s = qv[0] * kv[0] + qv[1] * kv[1] + qv[2] * kv[2] + qv[3] * kv[3];
-    s = group16_sum(s);
-    if (SAVE) {
-      if (valid && dq == 0) score_out[t] = s;
-    }
-    if (!valid) s = -1.0e30f;
-    const float mn = fmaxf(m, s);
-    const float al = expf(m - mn);
-    const float p = valid ? expf(s - mn) : 0.f;
-    m = mn;
-    l = l * al + p;
+__device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = o[i] * al + p * vv[i];
-  }
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
 }
 
-// merge the 4 lane groups of a wavefront: every lane ends with the combined (m, l, o)
-__device__ __forceinline__ void merge_groups(float& m, float& l, float* o) {
-  float M = fmaxf(m, __shfl_xor(m, 16, 64));
-  M = fmaxf(M, __shfl_xor(M, 32, 64));
-  const float sc = expf(m - M);
-  l *= sc;
-  l += __shfl_xor(l, 16, 64);
-  l += __shfl_xor(l, 32, 64);
+// Shared by both attention kernels.  NT threads; sc: LDS float[n_keys]; red: LDS float[NT/64 * 64 + 16].
+// Returns (in every thread) 1/L; the normalised context vector is written by the first 64 threads.
+template <typename T, int NT>
+__device__ __forceinline__ float attend_block(const T* __restrict__ qptr, const T* __restrict__ kbase,
+                                              const T* __restrict__ vbase, long long stride, int n_keys, float* sc,
+                                              float* red, T* __restrict__ outp) {
+  constexpr int KG = NT / 16;  // key groups
+  constexpr int U = 8;         // keys per thread in flight
+  constexpr int NW = NT / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kg = tid >> 4, dq = tid & 15;
+  float qv[4];
+  load4<T>(qptr + dq * 4, qv);
+  // ---- pass 1: scores ----
+  for (int c = 0; c < n_keys; c += KG * U) {
+    float kv[U][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float v = o[i] * sc;
+    for (int u = 0; u < U; ++u) {
+      int t = c + u * KG + kg;
+      if (t >= n_keys) t = n_keys - 1;
+      load4<T>(kbase + (long long)t * stride + dq * 4, kv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float s = qv[0] * kv[u][0] + qv[1] * kv[u][1] + qv[2] * kv[u][2] + qv[3] * kv[u][3];
+      s = group16_sum(s);
+      const int t = c + u * KG + kg;
+      if (dq == 0 && t < n_keys) sc[t] = s;
+    }
+  }
+  __syncthreads();
+  // ---- block max, exp, block sum ----
+  float m = -1.0e30f;
+  for (int t = tid; t < n_keys; t += NT) m = fmaxf(m, sc[t]);
+  m = wave_max(m);
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  float M = red[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) M = fmaxf(M, red[w]);
+  __syncthreads();
+  float ls = 0.f;
+  for (int t = tid; t < n_keys; t += NT) {
+    const float p = expf(sc[t] - M);
+    sc[t] = p;
+    ls += p;
+  }
+  ls = wave_sum(ls);
+  if (lane == 0) red[wave] = ls;
+  __syncthreads();
+  float L = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) L += red[w];
+  const float inv = 1.0f / L;
+  __syncthreads();
+  // ---- pass 2: context = sum_t p[t] * V[t] ----
+  float o[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < n_keys; c += KG * U) {
+    float vv[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int t = c + u * KG + kg;
+      if (t >= n_keys) t = n_keys - 1;
+      load4<T>(vbase + (long long)t * stride + dq * 4, vv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = c + u * KG + kg;
+      const float p = (t < n_keys) ? sc[t] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = fmaf(p, vv[u][i], o[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // fold the 4 key groups of this wavefront
+    float v = o[i];
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
     o[i] = v;
   }
-  m = M;
+  float* wo = red + 16;  // [NW][64]
+  if (lane < 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wo[wave * 64 + lane * 4 + i] = o[i];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += wo[w * 64 + tid];
+    outp[tid] = (T)(v * inv);
+  }
+  return inv;
 }
 
 template <typename T>
-__global__ __launch_bounds__(64) void dec_self_attn_kernel(const T* __restrict__ q, const T* __restrict__ kc,
-                                                            const T* __restrict__ vc, long long cache_bstride,
-                                                            T* __restrict__ out, int H, const DecState* __restrict__ stt) {
+__global__ __launch_bounds__(256) void dec_self_attn_kernel(const T* __restrict__ q, const T* __restrict__ kc,
+                                                             const T* __restrict__ vc, long long cache_bstride,
+                                                             T* __restrict__ out, int H, const DecState* __restrict__ stt) {
+  __shared__ float sc[512];
+  __shared__ float red[16 + 4 * 64];
   const int h = blockIdx.x, b = blockIdx.y;
-  const int lane = threadIdx.x;
   const int d = H * 64;
   const int n_keys = stt->pos + 1;
-  float qv[4];
-  load4<T>(q + (long long)b * d + h * 64 + (lane & 15) * 4, qv);
-  float m, l, o[4];
-  attend_range<T, false>(qv, kc + (long long)b * cache_bstride + h * 64, vc + (long long)b * cache_bstride + h * 64, d, 0,
-                         n_keys, lane, m, l, o, nullptr);
-  merge_groups(m, l, o);
-  if (lane < 16) {
-    const float inv = 1.0f / l;
-    float r[4] = {o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
-    store4<T>(out + (long long)b * d + h * 64 + lane * 4, r);
-  }
+  attend_block<T, 256>(q + (long long)b * d + h * 64, kc + (long long)b * cache_bstride + h * 64,
+                       vc + (long long)b * cache_bstride + h * 64, d, n_keys, sc, red, out + (long long)b * d + h * 64);
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void dec_cross_attn_kernel(const T* __restrict__ q, const T* __restrict__ ck,
+__global__ __launch_bounds__(512) void dec_cross_attn_kernel(const T* __restrict__ q, const T* __restrict__ ck,
                                                               const T* __restrict__ cv, T* __restrict__ out, int H,
                                                               int Tlen, const int* __restrict__ align_slot,
                                                               float* __restrict__ align, int Ha, int P,
                                                               const DecState* __restrict__ stt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* sc = reinterpret_cast<float*>(smem);  // [Tlen] raw scores (alignment heads only)
-  __shared__ float wm[4], wl[4], wo[4][64];
+  float* sc = reinterpret_cast<float*>(smem);  // [Tlen] scores -> unnormalised probabilities
+  __shared__ float red[16 + 8 * 64];
   const int h = blockIdx.x, b = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int d = H * 64;
-  const int slot = align_slot ? align_slot[h] : -1;
-  float qv[4];
-  load4<T>(q + (long long)b * d + h * 64 + (lane & 15) * 4, qv);
   const long long base = ((long long)b * H + h) * Tlen * 64;
-  int per = (Tlen + 3) / 4;
-  per = (per + 3) & ~3;
-  const int t0 = min(wave * per, Tlen), t1 = min(t0 + per, Tlen);
-  float m, l, o[4];
-  if (slot >= 0)
-    attend_range<T, true>(qv, ck + base, cv + base, 64, t0, t1, lane, m, l, o, sc);
-  else
-    attend_range<T, false>(qv, ck + base, cv + base, 64, t0, t1, lane, m, l, o, nullptr);
-  merge_groups(m, l, o);
-  if (lane == 0) { wm[wave] = m; wl[wave] = l; }
-  if (lane < 16) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) wo[wave][lane * 4 + i] = o[i];
-  }
-  __syncthreads();
-  const float M = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-  const float s0 = expf(wm[0] - M), s1 = expf(wm[1] - M), s2 = expf(wm[2] - M), s3 = expf(wm[3] - M);
-  const float L = wl[0] * s0 + wl[1] * s1 + wl[2] * s2 + wl[3] * s3;
-  const float inv = 1.0f / L;
-  if (tid < 64) {
-    const float v = (wo[0][tid] * s0 + wo[1][tid] * s1 + wo[2][tid] * s2 + wo[3][tid] * s3) * inv;
-    out[(long long)b * d + h * 64 + tid] = (T)v;
-  }
-  if (slot >= 0) {
+  const float inv = attend_block<T, 512>(q + (long long)b * d + h * 64, ck + base, cv + base, 64, Tlen, sc, red,
+                                          out + (long long)b * d + h * 64);
+  const int slot = align_slot ? align_slot[h] : -1;
+  if (slot >= 0) {  // A11 side output: softmax row of an alignment head
     float* row = align + (((long long)b * Ha + slot) * P + stt->pos) * Tlen;
-    for (int t = tid; t < Tlen; t += 256) row[t] = expf(sc[t] - M) * inv;
+    for (int t = threadIdx.x; t < Tlen; t += 512) row[t] = sc[t] * inv;
   }
 }
 
@@ -484,30 +574,37 @@ __global__ void advance_kernel(DecState* stt) { stt->pos += 1; }
 template <typename T, int BT>
 static hipError_t gemv_r(const GemvArgs& a, hipStream_t st) {
   constexpr int E = ElemTraits<T>::kPer16B;
-  if (a.K % E != 0 || (a.ln_g && a.K > GEMV_KC) || a.B > BT) return hipErrorInvalidValue;
-  const int kc = a.K < GEMV_KC ? a.K : GEMV_KC;
-  const size_t lds = (size_t)BT * kc * sizeof(T);
-  // rows per wavefront: keep >= ~2000 wavefronts in flight when N allows it
-  int R = 1;
-  if (a.N >= 16384) R = 4;
-  else if (a.N >= 3072) R = 2;
-  const int rows_per_block = 4 * R;
-  dim3 grid((a.N + rows_per_block - 1) / rows_per_block);
-  if (R == 4) hipLaunchKernelGGL((gemv_kernel<T, BT, 4>), grid, dim3(256), lds, st, a);
-  else if (R == 2) hipLaunchKernelGGL((gemv_kernel<T, BT, 2>), grid, dim3(256), lds, st, a);
-  else hipLaunchKernelGGL((gemv_kernel<T, BT, 1>), grid, dim3(256), lds, st, a);
+  constexpr int CV = GemvChunk<T, BT>::kVec;
+  if (a.K % E != 0 || (a.ln_g && a.K > 1280) || a.B > BT) return hipErrorInvalidValue;
+  const int nv_row = a.K / E;
+  const bool chunked = nv_row > CV;
+  if (chunked && a.ln_g) return hipErrorInvalidValue;
+  const size_t lds = (size_t)BT * (chunked ? CV : nv_row) * 16;
+  // rows per wavefront: keep >= ~1000 wavefronts in flight when N allows it; very tall matrices (the tied
+  // logits projection) additionally walk GEMV_RG row groups per workgroup so x is staged/normalised once per 128 rows
+  if (a.N >= 16384) {
+    const int rows_per_block = 4 * 4 * GEMV_RG;
+    dim3 grid((a.N + rows_per_block - 1) / rows_per_block);
+    hipLaunchKernelGGL((gemv_kernel<T, BT, 4, true>), grid, dim3(256), lds, st, a);
+  } else if (a.N >= 3072) {
+    dim3 grid((a.N + 7) / 8);
+    hipLaunchKernelGGL((gemv_kernel<T, BT, 2, false>), grid, dim3(256), lds, st, a);
+  } else {
+    dim3 grid((a.N + 3) / 4);
+    hipLaunchKernelGGL((gemv_kernel<T, BT, 1, false>), grid, dim3(256), lds, st, a);
+  }
   return hipGetLastError();
 }
 
 template <typename T, int BT>
 static hipError_t gemv_attr() {
-  // the f32 / 16-stream variants stage up to 80 KiB of activations: raise the dynamic-LDS cap once
-  const int cap = 96 * 1024;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<T, BT, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+  // up to 80 KiB of staged activations: raise the dynamic-LDS cap once per instantiation
+  const int cap = GEMV_LDS_BUDGET;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<T, BT, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
   if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<T, BT, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<T, BT, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<T, BT, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<T, BT, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
 }
 
 hipError_t init_decode_kernels() {
@@ -538,10 +635,10 @@ hipError_t launch_gemv(int dtype, const GemvArgs& a, hipStream_t st) {
 hipError_t launch_dec_self_attn(int dtype, const void* q, const void* kc, const void* vc, long long cache_bstride,
                                 void* out, int B, int H, const DecState* stt, hipStream_t st) {
   if (dtype == 1)
-    hipLaunchKernelGGL(dec_self_attn_kernel<bf16_t>, dim3(H, B), dim3(64), 0, st, (const bf16_t*)q, (const bf16_t*)kc,
+    hipLaunchKernelGGL(dec_self_attn_kernel<bf16_t>, dim3(H, B), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)kc,
                        (const bf16_t*)vc, cache_bstride, (bf16_t*)out, H, stt);
   else
-    hipLaunchKernelGGL(dec_self_attn_kernel<float>, dim3(H, B), dim3(64), 0, st, (const float*)q, (const float*)kc,
+    hipLaunchKernelGGL(dec_self_attn_kernel<float>, dim3(H, B), dim3(256), 0, st, (const float*)q, (const float*)kc,
                        (const float*)vc, cache_bstride, (float*)out, H, stt);
   return hipGetLastError();
 }
@@ -551,10 +648,10 @@ hipError_t launch_dec_cross_attn(int dtype, const void* q, const void* ck, const
                                  const DecState* stt, hipStream_t st) {
   const size_t lds = (size_t)T * sizeof(float);
   if (dtype == 1)
-    hipLaunchKernelGGL(dec_cross_attn_kernel<bf16_t>, dim3(H, B), dim3(256), lds, st, (const bf16_t*)q,
+    hipLaunchKernelGGL(dec_cross_attn_kernel<bf16_t>, dim3(H, B), dim3(512), lds, st, (const bf16_t*)q,
                        (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)out, H, T, align_slot_for_head, align, Ha, P, stt);
   else
-    hipLaunchKernelGGL(dec_cross_attn_kernel<float>, dim3(H, B), dim3(256), lds, st, (const float*)q, (const float*)ck,
+    hipLaunchKernelGGL(dec_cross_attn_kernel<float>, dim3(H, B), dim3(512), lds, st, (const float*)q, (const float*)ck,
                        (const float*)cv, (float*)out, H, T, align_slot_for_head, align, Ha, P, stt);
   return hipGetLastError();
 }

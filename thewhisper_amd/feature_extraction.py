@@ -1,0 +1,56 @@
+"""``AMDWhisperFeatureExtractor``: HF ``WhisperFeatureExtractor`` whose log-mel runs in the HIP kernel (A1).
+
+HF's pipeline calls ``feature_extractor(chunk, sampling_rate=..., return_tensors="pt", return_attention_mask=True)``
+per chunk (HF:pipelines/automatic_speech_recognition.py:67-72); everything except the arithmetic
+(padding to n_samples, attention-mask rescaling, BatchFeature packing) is inherited, and
+``_torch_extract_fbank_features`` (HF:models/whisper/feature_extraction_whisper.py:135-168) is replaced by
+``tw_logmel``.  No CPU fallback: without an attached engine the call raises.
+"""
+from __future__ import annotations
+
+import numpy as np
+from transformers import WhisperFeatureExtractor
+
+
+class AMDWhisperFeatureExtractor(WhisperFeatureExtractor):
+    _engine = None
+
+    @classmethod
+    def from_hf(cls, fe: WhisperFeatureExtractor) -> "AMDWhisperFeatureExtractor":
+        if isinstance(fe, cls):
+            return fe
+        if not isinstance(fe, WhisperFeatureExtractor):
+            raise TypeError("expected a WhisperFeatureExtractor")
+        if fe.n_fft != 400 or fe.hop_length != 160 or fe.sampling_rate != 16000 or getattr(fe, "dither", 0.0) != 0.0:
+            raise NotImplementedError("the MI355X log-mel kernel implements n_fft=400, hop=160, 16 kHz, no dither")
+        new = cls(feature_size=fe.feature_size, sampling_rate=fe.sampling_rate, hop_length=fe.hop_length,
+                  chunk_length=fe.chunk_length, n_fft=fe.n_fft, padding_value=fe.padding_value,
+                  return_attention_mask=fe.return_attention_mask)
+        return new
+
+    def attach_engine(self, engine) -> None:
+        if engine.n_mels != self.feature_size:
+            raise ValueError("engine / feature extractor mel-bin mismatch")
+        self._engine = engine
+
+    def _torch_extract_fbank_features(self, waveform: np.ndarray, device: str = "cpu") -> np.ndarray:  # noqa: ARG002
+        if self._engine is None:
+            raise RuntimeError("AMDWhisperFeatureExtractor has no engine attached (no CPU fallback)")
+        import torch
+
+        w = np.asarray(waveform, dtype=np.float32)
+        squeeze = w.ndim == 1
+        if squeeze:
+            w = w[None]
+        outs = []
+        mb = self._engine.max_batch
+        for i in range(0, w.shape[0], mb):
+            x = torch.from_numpy(np.ascontiguousarray(w[i : i + mb]))
+            mel = self._engine.logmel(x, out_dtype=torch.float32)
+            outs.append(mel.cpu().numpy())
+        out = np.concatenate(outs, axis=0)
+        return out[0] if squeeze else out
+
+    # the numpy path must not silently take over either
+    def _np_extract_fbank_features(self, waveform_batch, device):  # noqa: ARG002
+        return self._torch_extract_fbank_features(np.asarray(waveform_batch), device)

@@ -1,0 +1,266 @@
+"""HF-shaped model object whose arithmetic runs in libthewhisper_gfx950.so.
+
+The reference slots a foreign engine under Hugging Face ``generate()`` in two ways: a whole-class
+swap (``elastic_models...WhisperForConditionalGeneration``, R:thestage_speechkit/nvidia/asr_pipeline.py:48-56)
+and an encoder/decoder module swap (R:thestage_speechkit/apple/model.py:601-614).  This backend keeps
+Whisper's *control flow* from HF (``WhisperGenerationMixin.generate``: init tokens, seek loop, segment
+slicing - per chunk, host side) and replaces everything underneath it:
+
+* ``_EngineGreedyMixin.generate`` is inserted in the MRO between ``WhisperGenerationMixin`` and
+  ``GenerationMixin``; it is what ``generate_with_fallback`` reaches through ``super().generate``
+  (HF:models/whisper/generation_whisper.py:1027) and runs encoder + cross-K/V + the whole greedy
+  loop with the Whisper logits processors on the GPU (A2-A10).
+* ``_extract_token_timestamps`` is overridden with the on-device median-filter + DTW (A11).
+
+Unsupported generation options (beam search, sampling, custom processors ...) raise
+``NotImplementedError``: there is no eager/CPU fallback.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from transformers import WhisperConfig, WhisperForConditionalGeneration
+from transformers.generation.logits_process import (
+    SuppressTokensAtBeginLogitsProcessor,
+    SuppressTokensLogitsProcessor,
+    WhisperTimeStampLogitsProcessor,
+)
+from transformers.generation.utils import GenerateEncoderDecoderOutput, GenerationMixin
+from transformers.modeling_outputs import Seq2SeqLMOutput
+
+logger = logging.getLogger(__name__)
+
+
+def dims_from_config(cfg: WhisperConfig) -> Dict[str, int]:
+    if cfg.encoder_attention_heads != cfg.decoder_attention_heads or cfg.encoder_ffn_dim != cfg.decoder_ffn_dim:
+        raise NotImplementedError("encoder/decoder head or FFN sizes differ")
+    return dict(
+        d_model=cfg.d_model, enc_layers=cfg.encoder_layers, dec_layers=cfg.decoder_layers,
+        heads=cfg.encoder_attention_heads, ffn=cfg.encoder_ffn_dim, vocab=cfg.vocab_size, n_mels=cfg.num_mel_bins,
+        max_source_positions=1500, max_target_positions=cfg.max_target_positions,
+    )
+
+
+def _default_engine_factory(dims, T, max_batch, dtype, alignment_heads, device_index):
+    from .engine import WhisperEngine
+
+    return WhisperEngine(dims, T, max_batch=max_batch, dtype=dtype, alignment_heads=alignment_heads, device=device_index)
+
+
+class _EngineGreedyMixin(GenerationMixin):
+    """Replaces ``GenerationMixin.generate`` (-> ``_sample``, HF:generation/utils.py:2783-2946) for the one
+    configuration Whisper transcription uses: greedy, num_beams=1, short-form segment in, token ids out."""
+
+    def generate(  # type: ignore[override]
+        self,
+        inputs: Optional[torch.Tensor] = None,
+        generation_config=None,
+        logits_processor=None,
+        stopping_criteria=None,
+        prefix_allowed_tokens_fn=None,
+        synced_gpus=None,
+        decoder_input_ids: Optional[torch.Tensor] = None,
+        attention_mask: Optional[torch.Tensor] = None,
+        **kwargs,
+    ):
+        eng = self._require_engine()
+        gc = generation_config if generation_config is not None else self.generation_config
+        self._check_supported(gc, stopping_criteria, prefix_allowed_tokens_fn, kwargs)
+        if inputs is None:
+            inputs = kwargs.pop("input_features", None)
+        if inputs is None or decoder_input_ids is None:
+            raise NotImplementedError("the MI355X engine needs `input_features` and `decoder_input_ids`")
+        B = int(inputs.shape[0])
+        if B > eng.max_batch:
+            raise ValueError(f"batch of {B} chunks exceeds the engine capacity max_batch={eng.max_batch}; "
+                             "construct ASRPipeline with a matching batch_size")
+        n_prompt = int(decoder_input_ids.shape[1])
+        opts = self._parse_logits_processors(logits_processor, n_prompt)
+        max_target = int(self.config.max_target_positions)
+        if getattr(gc, "max_new_tokens", None) is not None:
+            max_len = n_prompt + int(gc.max_new_tokens)
+        else:
+            max_len = int(gc.max_length)
+        max_len = min(max_len, max_target)
+        min_new = int(getattr(gc, "min_new_tokens", None) or 0)
+        if getattr(gc, "min_length", 0) and int(gc.min_length) > n_prompt:
+            min_new = max(min_new, int(gc.min_length) - n_prompt)
+        eos = gc.eos_token_id
+        if isinstance(eos, (list, tuple)):
+            if len(eos) != 1:
+                raise NotImplementedError("multiple eos_token_id values")
+            eos = eos[0]
+        pad = gc.pad_token_id if gc.pad_token_id is not None else eos
+
+        eng.encode(inputs)
+        eng.cross_kv(B)
+        want_align = bool(getattr(gc, "return_token_timestamps", False))
+        out = eng.generate_greedy(
+            decoder_input_ids.detach().to("cpu", torch.int32).numpy(),
+            max_new_tokens=max_len - n_prompt,
+            min_new_tokens=min_new,
+            max_length=max_target,
+            eos_id=int(eos),
+            pad_id=int(pad),
+            want_alignment=want_align,
+            **opts,
+        )
+        seq = torch.from_numpy(out["sequences"]).to(decoder_input_ids.device, torch.long)
+        self._last_greedy = {"B": B, "n_prompt": n_prompt, "len": int(seq.shape[1])}
+        if getattr(gc, "return_dict_in_generate", False):
+            return GenerateEncoderDecoderOutput(sequences=seq)
+        return seq
+
+    # -- helpers ---------------------------------------------------------------------------------
+    @staticmethod
+    def _check_supported(gc, stopping_criteria, prefix_allowed_tokens_fn, kwargs):
+        bad = []
+        if getattr(gc, "num_beams", 1) not in (None, 1) or kwargs.get("num_beams", 1) not in (None, 1):
+            bad.append("num_beams > 1")
+        if getattr(gc, "do_sample", False):
+            bad.append("do_sample")
+        if stopping_criteria:
+            bad.append("custom stopping_criteria")
+        if prefix_allowed_tokens_fn is not None:
+            bad.append("prefix_allowed_tokens_fn")
+        for k in ("assistant_model", "encoder_outputs", "decoder_attention_mask", "streamer", "past_key_values"):
+            if kwargs.get(k) is not None:
+                bad.append(k)
+        if getattr(gc, "repetition_penalty", None) not in (None, 1.0):
+            bad.append("repetition_penalty")
+        if getattr(gc, "no_repeat_ngram_size", None) not in (None, 0):
+            bad.append("no_repeat_ngram_size")
+        if getattr(gc, "num_return_sequences", 1) not in (None, 1):
+            bad.append("num_return_sequences > 1")
+        if bad:
+            raise NotImplementedError("not supported by the MI355X greedy engine: " + ", ".join(bad))
+
+    @staticmethod
+    def _parse_logits_processors(processors, n_prompt: int) -> Dict[str, Any]:
+        opts: Dict[str, Any] = dict(timestamps=False, begin_suppress=(), suppress=(), no_timestamps_id=0,
+                                    max_initial_timestamp_index=None)
+        for p in processors or []:
+            if isinstance(p, SuppressTokensAtBeginLogitsProcessor):
+                if p.begin_index != n_prompt:
+                    raise NotImplementedError("begin_index differs from the prompt length")
+                opts["begin_suppress"] = tuple(int(x) for x in p.begin_suppress_tokens.tolist())
+            elif isinstance(p, SuppressTokensLogitsProcessor):
+                opts["suppress"] = tuple(int(x) for x in p.suppress_tokens.tolist())
+            elif isinstance(p, WhisperTimeStampLogitsProcessor):
+                if p.begin_index != n_prompt or not p._detect_timestamp_from_logprob:
+                    raise NotImplementedError("unsupported WhisperTimeStampLogitsProcessor configuration")
+                opts["timestamps"] = True
+                opts["no_timestamps_id"] = int(p.no_timestamps_token_id)
+                opts["max_initial_timestamp_index"] = p.max_initial_timestamp_index
+            else:
+                raise NotImplementedError(f"logits processor {type(p).__name__} is not implemented on the MI355X engine")
+        return opts
+
+
+class AMDWhisperForConditionalGeneration(WhisperForConditionalGeneration, _EngineGreedyMixin):
+    """``WhisperForConditionalGeneration`` with the hot path on the MI355X engine.
+
+    MRO: AMDWhisper -> WhisperForConditionalGeneration -> WhisperGenerationMixin -> _EngineGreedyMixin ->
+    GenerationMixin -> ...; the HF torch modules are kept only as the container the checkpoint loads
+    into - after ``build_engine`` their storage is released.
+    """
+
+    _engine = None
+    _engine_factory: Callable = staticmethod(_default_engine_factory)
+
+    # -- engine lifetime ---------------------------------------------------------------------------
+    def build_engine(self, chunk_length_s: int = 30, max_batch: int = 1, dtype: Optional[torch.dtype] = None,
+                     engine_factory: Optional[Callable] = None, release_torch_weights: bool = True):
+        """Create the context for T = 50*chunk_length_s encoder frames and upload the weights (A0 is applied by
+        the library: tw_finalize_weights interpolates the positional table like patch_hf_model)."""
+        if chunk_length_s > 30 or chunk_length_s < 1:
+            raise ValueError("chunk_length_s must be in [1, 30]")
+        T = int(1500 * (chunk_length_s / 30))  # same expression as R:thestage_speechkit/nvidia/asr_pipeline.py:16
+        p0 = next(self.parameters())
+        dt = dtype or p0.dtype
+        if dt == torch.float16:
+            logger.warning("fp16 requested: the MI355X engine computes in bf16 (same MFMA rate, wider range)")
+        eng_dtype = "f32" if dt == torch.float32 else "bf16"
+        heads = getattr(self.generation_config, "alignment_heads", None) or []
+        factory = engine_factory or type(self)._engine_factory
+        dev_index = p0.device.index if p0.device.type == "cuda" and p0.device.index is not None else 0
+        eng = factory(dims_from_config(self.config), T, int(max_batch), eng_dtype, [tuple(h) for h in heads], dev_index)
+        sd = {k: v for k, v in self.state_dict().items() if k != "proj_out.weight"}
+        eng.load_state_dict(sd)
+        self._engine = eng
+        self._engine_T = T
+        # mirror what patch_hf_model leaves behind, so HF's short-form test `frames <= 2*max_source_positions` holds
+        self.config.max_source_positions = T
+        if release_torch_weights:
+            for p in self.parameters():
+                p.data = torch.empty(0, dtype=p.dtype, device=p.device)
+        return eng
+
+    def _require_engine(self):
+        if self._engine is None:
+            raise RuntimeError("AMDWhisperForConditionalGeneration has no engine: call build_engine() "
+                               "(thewhisper_amd.ASRPipeline does it); there is no eager fallback")
+        return self._engine
+
+    @property
+    def engine(self):
+        return self._require_engine()
+
+    # -- teacher-forced forward (language detection, parity tests) ---------------------------------
+    def forward(self, input_features=None, decoder_input_ids=None, encoder_outputs=None, **kwargs):  # type: ignore[override]
+        eng = self._require_engine()
+        if decoder_input_ids is None:
+            raise NotImplementedError("forward() needs decoder_input_ids")
+        if input_features is not None:
+            B = int(input_features.shape[0])
+            eng.encode(input_features)
+            eng.cross_kv(B)
+        elif encoder_outputs is None:
+            raise NotImplementedError("forward() needs input_features")
+        B = int(decoder_input_ids.shape[0])
+        eng.decoder_reset(B)
+        ids = decoder_input_ids.detach().to("cpu").numpy()
+        cols = []
+        for j in range(ids.shape[1]):
+            cols.append(eng.decode_step(ids[:, j].tolist()))
+        logits = torch.stack(cols, dim=1)
+        return Seq2SeqLMOutput(logits=logits)
+
+    # -- A11 -------------------------------------------------------------------------------------
+    def _extract_token_timestamps(self, generate_outputs, alignment_heads, time_precision=0.02, num_frames=None,
+                                  num_input_ids=None):
+        """On-device replacement of HF:models/whisper/generation_whisper.py:241-381 (5.15.0 semantics)."""
+        eng = self._require_engine()
+        st = self._last_greedy
+        seq = generate_outputs["sequences"]
+        B, L = int(seq.shape[0]), int(seq.shape[1])
+        if st["B"] != B or st["len"] != L:
+            raise RuntimeError("token timestamps requested for a generate() call the engine no longer holds")
+        n_in = int(num_input_ids if num_input_ids is not None else st["n_prompt"])
+        if num_frames is None:
+            nf = None
+        elif isinstance(num_frames, int):
+            nf = [num_frames] * B
+        else:
+            nf = [int(x) for x in (num_frames.tolist() if hasattr(num_frames, "tolist") else list(num_frames))]
+            if len(nf) != B:
+                nf = list(np.repeat(nf, B // len(nf)))
+        if L - 1 <= n_in:  # one generated token: no cross-attention rows after the prompt -> zeros (HF :341-344)
+            return torch.zeros((B, L), dtype=torch.float32, device=seq.device)
+        ts = eng.token_timestamps(B, n_in, L, nf, time_precision)
+        return torch.from_numpy(ts).to(seq.device)
+
+    # -- construction helpers --------------------------------------------------------------------
+    @classmethod
+    def from_hf(cls, hf_model: WhisperForConditionalGeneration) -> "AMDWhisperForConditionalGeneration":
+        """Re-class an already loaded HF model (weights shared, no copy)."""
+        if isinstance(hf_model, cls):
+            return hf_model
+        if not isinstance(hf_model, WhisperForConditionalGeneration):
+            raise TypeError("expected a transformers WhisperForConditionalGeneration")
+        hf_model.__class__ = cls
+        hf_model._engine = None
+        return hf_model

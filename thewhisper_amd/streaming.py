@@ -1,0 +1,95 @@
+"""``AMDWhisperBackend`` - the ``platform="amd"`` transcription backend for the reference's StreamingPipeline.
+
+Implements the ``TranscriptionBackend.transcribe(audio, buffer_start_time, sample_rate) -> [{"text","start","end"}]``
+contract (R:thestage_speechkit/streaming/streaming_pipeline.py:51-64) exactly as ``LocalWhisperBackend`` does
+for the other platforms (R:...:340-435): fixed greedy generate kwargs with ``max_new_tokens=128``, word
+timestamps always on, the zlib gibberish filter (>2.2 -> ``[]``) and the open-ended last-word fix-up.
+Use it through the reference's injection seam ``StreamingPipeline(backend=AMDWhisperBackend(...))`` or via the
+three-line ``platform == "amd"`` patch shown in INTEGRATION.md.
+"""
+from __future__ import annotations
+
+import zlib
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+
+
+def _compression_ratio(text: str) -> float:
+    """R:thestage_speechkit/streaming/streaming_pipeline.py:41-43."""
+    text_bytes = text.encode("utf-8")
+    return len(text_bytes) / len(zlib.compress(text_bytes))
+
+
+class AMDWhisperBackend:
+    """Duck-typed ``TranscriptionBackend`` (the ABC lives in the reference package)."""
+
+    def __init__(
+        self,
+        model,
+        model_size: str = "S",
+        chunk_length_s: int = 10,
+        torch_dtype: "torch.dtype | None" = None,
+        language: str = "en",
+        feature_extractor=None,
+        tokenizer=None,
+        revision: str = "main",
+        asr_pipeline=None,
+        **pipeline_kwargs,
+    ):
+        from .asr_pipeline import ASRPipeline
+
+        if torch_dtype is None:
+            # the reference defaults to fp16 (R:...:369-370); the MI355X engine's production dtype is bf16
+            torch_dtype = torch.bfloat16
+        self.chunk_length_s: float = chunk_length_s
+        self.sample_rate: int = 16000
+        self.device: str = "cuda"  # ROCm exposes MI355X as "cuda", as on the nvidia platform (R:...:365)
+        self.language: str = language
+        self.asr_pipeline = asr_pipeline or ASRPipeline(
+            model,
+            model_size=model_size,
+            chunk_length_s=chunk_length_s,
+            torch_dtype=torch_dtype,
+            device=pipeline_kwargs.pop("device", self.device),
+            feature_extractor=feature_extractor,
+            tokenizer=tokenizer,
+            revision=revision,
+            **pipeline_kwargs,
+        )
+
+    def transcribe(self, audio: np.ndarray, buffer_start_time: float, sample_rate: int) -> List[Dict[str, Any]]:
+        audio_duration: float = len(audio) / sample_rate
+        max_new_tokens = 128
+        generate_kwargs: Dict[str, Any] = {
+            "use_cache": True,
+            "num_beams": 1,
+            "do_sample": False,
+            "max_new_tokens": max_new_tokens,
+            "language": self.language,
+        }
+        result: Dict[str, Any] = self.asr_pipeline(
+            audio,
+            return_timestamps="word",
+            generate_kwargs=generate_kwargs,
+            chunk_length_s=self.chunk_length_s,
+        )
+        if _compression_ratio(result["text"]) > 2.2:
+            return []
+        generated_tokens: List[Dict[str, Any]] = []
+        max_word_duration: float = 1.0
+        for token in result["chunks"]:
+            if token["timestamp"][1] is None:
+                if audio_duration - token["timestamp"][0] < max_word_duration:
+                    token["timestamp"] = (token["timestamp"][0], audio_duration)
+                else:
+                    token["timestamp"] = (token["timestamp"][0], token["timestamp"][0] + max_word_duration)
+            generated_tokens.append(
+                {
+                    "text": token["text"],
+                    "start": token["timestamp"][0] + buffer_start_time,
+                    "end": token["timestamp"][1] + buffer_start_time,
+                }
+            )
+        return generated_tokens
