@@ -1,0 +1,112 @@
+"""Host-side glue of the drop-in (ASRPipeline / AMDWhisperForConditionalGeneration / feature extractor / streaming
+backend) on CPU, with the numpy oracle injected as the engine (tests/oracle_engine.py).  Outputs are compared with the
+golden JSON the REFERENCE's own nvidia.ASRPipeline + StreamingPipeline produced (oracle/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hf_reference as hr
+from oracle import whisper_oracle as wo
+from tests.oracle_engine import oracle_engine_factory
+
+torch.set_grad_enabled(False)
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "pipeline_golden.json")
+
+
+def golden():
+    with open(GOLD) as f:
+        return json.load(f)
+
+
+def build_amd_pipeline(preset, chunk_s, batch_size, device="cpu", engine_factory=oracle_engine_factory,
+                       dtype=torch.float32):
+    from thewhisper_amd import ASRPipeline
+
+    dims = wo.PRESETS[preset]
+    w = wo.make_weights(dims, 0)
+    model = hr.build_hf_model(dims, w)
+    kw = {} if engine_factory is None else {"engine_factory": engine_factory}
+    return ASRPipeline(model, feature_extractor=hr.build_feature_extractor(dims, chunk_s), tokenizer=hr.build_tokenizer(dims),
+                       chunk_length_s=chunk_s, device=device, torch_dtype=dtype, batch_size=batch_size, **kw)
+
+
+def normalise(out):
+    return json.loads(json.dumps(out))
+
+
+@pytest.mark.parametrize("name", ["micro_c10", "micro_c10_noise", "micro80_c30"])
+def test_offline_pipeline_matches_reference_golden(name):
+    g = golden()[name]
+    pipe = build_amd_pipeline(g["preset"], g["chunk_s"], g["batch_size"])
+    audio = wo.synth_audio(16000 * g["seconds"], g["seed"], g["kind"])
+    gk = {"num_beams": 1, "do_sample": False, "use_cache": True, "language": "en", "max_new_tokens": g["max_new_tokens"]}
+    for rt in (False, True, "word"):
+        out = pipe(audio.copy(), generate_kwargs=dict(gk), chunk_length_s=g["chunk_s"] - 1, return_timestamps=rt)
+        assert normalise(out) == g["outputs"][str(rt)], f"return_timestamps={rt}"
+    eng = pipe.model.engine
+    assert eng.calls["logmel"] > 0 and eng.calls["generate"] > 0 and eng.calls["dtw"] > 0  # all stages went through the engine
+
+
+def test_streaming_backend_replays_reference_calls():
+    """AMDWhisperBackend.transcribe == the reference's LocalWhisperBackend.transcribe on every rolling buffer the
+    reference scheduler produced (ragged lengths, advancing buffer_start_time)."""
+    from thewhisper_amd import AMDWhisperBackend
+
+    g = golden()["streaming_micro_c10"]
+    pipe = build_amd_pipeline("micro", 10, 1)
+    backend = AMDWhisperBackend(None, chunk_length_s=10, asr_pipeline=pipe)
+    audio = wo.synth_audio(16000 * g["seconds"], g["seed"], g["kind"])
+    picks = g["calls"][::3] + g["calls"][-2:]
+    for c in picks:
+        buf = audio[c["offset"] : c["offset"] + c["n"]]
+        got = backend.transcribe(buf, c["t0"], 16000)
+        assert normalise(got) == c["result"], (c["n"], c["offset"], c["t0"])
+
+
+def test_constructor_contract_mirrors_reference():
+    from thewhisper_amd import ASRPipeline
+
+    dims = wo.PRESETS["micro"]
+    model = hr.build_hf_model(dims, wo.make_weights(dims, 0))
+    with pytest.raises(ValueError, match="feature_extractor must be provided when passing a model instance"):
+        ASRPipeline(model, tokenizer=hr.build_tokenizer(dims), device="cpu", engine_factory=oracle_engine_factory)
+    with pytest.raises(ValueError, match="tokenizer must be provided when passing a model instance"):
+        ASRPipeline(model, feature_extractor=hr.build_feature_extractor(dims, 30), device="cpu",
+                    engine_factory=oracle_engine_factory)
+
+
+def test_unsupported_generation_options_fail_loudly():
+    pipe = build_amd_pipeline("micro", 10, 1)
+    audio = wo.synth_audio(16000 * 5, 1, "speechlike")
+    with pytest.raises(NotImplementedError, match="num_beams"):
+        pipe(audio, generate_kwargs={"num_beams": 2, "language": "en", "max_new_tokens": 8})
+
+
+def test_wrong_feature_length_raises_like_hf():
+    pipe = build_amd_pipeline("micro", 10, 1)
+    bad = torch.zeros(1, 128, 3000)
+    with pytest.raises(ValueError, match="mel input features"):
+        pipe.model.engine.encode(bad)
+
+
+def test_no_engine_no_fallback():
+    from thewhisper_amd.model import AMDWhisperForConditionalGeneration
+
+    dims = wo.PRESETS["micro"]
+    m = AMDWhisperForConditionalGeneration.from_hf(hr.build_hf_model(dims, wo.make_weights(dims, 0)))
+    with pytest.raises(RuntimeError, match="no eager fallback"):
+        m.generate(input_features=torch.zeros(1, 128, 3000), language="en")
+
+
+def test_lcs_patch_is_the_reference_compare():
+    from transformers.models.whisper import tokenization_whisper as tw
+
+    import thewhisper_amd.lcs_patch as lp
+
+    assert getattr(tw._find_longest_common_sequence, "_thewhisper_patched", False) or "thestage_speechkit" in __import__("sys").modules
+    assert lp._ordered((1.0, None), (0.5, 0.7)) is True       # open-ended left token: in order
+    assert lp._ordered((1.0, 1.2), (0.5, 0.7)) is False
+    assert lp._ordered((0.2, 0.4), (0.5, 0.7)) is True
