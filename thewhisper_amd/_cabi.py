@@ -66,6 +66,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
+    # torch bundles its own HIP runtime: import it FIRST so that libthewhisper's libamdhip64 dependency resolves to the
+    # runtime torch already mapped (one runtime per process - device pointers and streams are shared with torch).
+    import torch  # noqa: F401
+
     p = path or os.environ.get("THEWHISPER_LIB") or _build.library_path()
     if not os.path.exists(p):
         raise RuntimeError(

@@ -15,6 +15,8 @@
 //    per stream (HF:generation/logits_process.py:1816-2047, HF:generation/utils.py:2925).
 #include "tw_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -279,6 +281,182 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
           dst[(long long)b * a.cache_bstride + (long long)a.stt->pos * a.d_model + (n - seg * a.d_model)] = (T)v;
         } else {
           reinterpret_cast<T*>(a.y)[(long long)b * a.ldy + n] = (T)v;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Skinny MFMA GEMM for 5..16 concurrent streams:  y[b, n0..n0+15] for one 16-row weight tile per
+// workgroup, K split over the NW wavefronts.  With 16 streams the activation block is exactly one
+// MFMA tile (v_mfma_f32_16x16x32_bf16: A = 16 weight rows x 32 k, B = 16 streams x 32 k), so each
+// 1-KiB weight fragment costs ONE matrix instruction and ONE 16-B activation fragment instead of
+// 16 LDS reads + 64 dot2 + a 96-shuffle wave reduction in the VALU formulation; the contraction
+// over k happens inside the MFMA and only NW partial 16x16 tiles are summed through LDS.
+// All weight fragments of a wavefront (<= SK_MAXS) are requested up front; LayerNorm'ed activations
+// come from LDS rows padded by one vector (conflict-free ds_read_b128), plain activations straight
+// from L2.  Deterministic: fixed summation order, no atomics.
+// ---------------------------------------------------------------------------------------------
+constexpr int SK_MAXS = 10;
+
+template <typename T>
+__device__ __forceinline__ f32x4_t sk_mfma(const u32x4_t& w, const u32x4_t& x, f32x4_t acc);
+template <>
+__device__ __forceinline__ f32x4_t sk_mfma<bf16_t>(const u32x4_t& w, const u32x4_t& x, f32x4_t acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4_t sk_mfma<float>(const u32x4_t& w, const u32x4_t& x, f32x4_t acc) {
+  const f32x4_t a = __builtin_bit_cast(f32x4_t, w), b = __builtin_bit_cast(f32x4_t, x);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
+  return acc;
+}
+
+template <typename T, int NW, bool MULTI>
+__global__ __launch_bounds__(NW * 64) void skinny_mfma_kernel(GemvArgs a) {
+  constexpr int E = ElemTraits<T>::kPer16B;
+  constexpr int NT = NW * 64;
+  constexpr int MAXV = (1280 / E + 63) / 64;
+  constexpr int RPW = (16 + NW - 1) / NW;  // LayerNorm rows per wavefront
+  constexpr int RG = MULTI ? GEMV_RG : 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, kq = lane >> 4;
+  const int K = a.K, N = a.N, B = a.B;
+  const T* x = reinterpret_cast<const T*>(a.x);
+  const T* W = reinterpret_cast<const T*>(a.W);
+  const int nv_row = K / E;          // 16-B vectors per row
+  const int S = nv_row / 4;          // 64-B steps per row
+  const int s_lo = (int)((long long)wave * S / NW), s_hi = (int)((long long)(wave + 1) * S / NW);
+  const bool has_ln = a.ln_g != nullptr;
+  const int xld = nv_row + 1;        // padded LDS row stride (vectors)
+  float* red = reinterpret_cast<float*>(smem);                       // [NW][256]
+  u32x4_t* xs = reinterpret_cast<u32x4_t*>(smem + NW * 256 * 4);     // [16][xld] (LayerNorm case only)
+
+  int n0 = blockIdx.x * RG * 16;
+  const T* wrow = W + (long long)min(n0 + fr, N - 1) * K;
+  u32x4_t wq[SK_MAXS];
+  auto load_w = [&](int s0) {
+#pragma unroll
+    for (int i = 0; i < SK_MAXS; ++i) {
+      const int st = s0 + i;
+      wq[i] = (st < s_hi) ? *reinterpret_cast<const u32x4_t*>(wrow + (long long)(st * 4 + kq) * E) : u32x4_t{0u, 0u, 0u, 0u};
+    }
+  };
+  load_w(s_lo);
+
+  if (has_ln) {
+    const T* g = reinterpret_cast<const T*>(a.ln_g);
+    const T* be = reinterpret_cast<const T*>(a.ln_b);
+    u32x4_t lg[MAXV], lb[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int vi = lane + i * 64;
+      lg[i] = (vi < nv_row) ? *reinterpret_cast<const u32x4_t*>(g + vi * E) : u32x4_t{0u, 0u, 0u, 0u};
+      lb[i] = (vi < nv_row) ? *reinterpret_cast<const u32x4_t*>(be + vi * E) : u32x4_t{0u, 0u, 0u, 0u};
+    }
+    // every wavefront normalises its own rows straight from global memory (rows >= B become zeros)
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int b = wave + NW * rr;
+      if (b < 16) {
+        float v[MAXV][E];
+        float sm = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+          const int vi = lane + i * 64;
+          if (vi < nv_row && b < B) {
+            unpack16<T>(*reinterpret_cast<const u32x4_t*>(x + (long long)b * a.ldx + vi * E), v[i]);
+#pragma unroll
+            for (int e = 0; e < E; ++e) sm += v[i][e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[i][e] = 0.f;
+          }
+        }
+        const float mean = wave_sum(sm) / (float)K;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+          const int vi = lane + i * 64;
+          if (vi < nv_row) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) { const float c = v[i][e] - mean; q += c * c; }
+          }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)K + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+          const int vi = lane + i * 64;
+          if (vi < nv_row) {
+            float gg[E], bb[E], o[E];
+            unpack16<T>(lg[i], gg);
+            unpack16<T>(lb[i], bb);
+#pragma unroll
+            for (int e = 0; e < E; ++e) o[e] = (b < B) ? (v[i][e] - mean) * rstd * gg[e] + bb[e] : 0.f;
+            xs[b * xld + vi] = pack16<T>(o);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  const T* xrow = x + (long long)min(fr, B - 1) * a.ldx;  // plain case: B-operand rows straight from L2
+  const T* bias = reinterpret_cast<const T*>(a.bias);
+  const T* res = reinterpret_cast<const T*>(a.res);
+  for (int grp = 0; grp < RG; ++grp) {
+    if (grp > 0) {
+      n0 = (blockIdx.x * RG + grp) * 16;
+      if (n0 >= N) break;
+      wrow = W + (long long)min(n0 + fr, N - 1) * K;
+      load_w(s_lo);
+    }
+    f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int s0 = s_lo; s0 < s_hi; s0 += SK_MAXS) {
+      if (s0 > s_lo) load_w(s0);
+      u32x4_t xq[SK_MAXS];
+#pragma unroll
+      for (int i = 0; i < SK_MAXS; ++i) {
+        const int st = s0 + i;
+        if (st < s_hi) {
+          xq[i] = has_ln ? xs[fr * xld + st * 4 + kq]
+                         : *reinterpret_cast<const u32x4_t*>(xrow + (long long)(st * 4 + kq) * E);
+        } else {
+          xq[i] = u32x4_t{0u, 0u, 0u, 0u};
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < SK_MAXS; ++i)
+        if (s0 + i < s_hi) acc = sk_mfma<T>(wq[i], xq[i], acc);
+    }
+    // D[i = weight row (lane>>4)*4 + reg][j = stream lane&15]
+    if (grp > 0) __syncthreads();  // previous group's readers are done with `red`
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave * 256 + (kq * 4 + r) * 16 + fr] = acc[r];
+    __syncthreads();
+    if (tid < 256) {
+      const int j = tid >> 4, i = tid & 15;  // stream, row: 16 consecutive rows of one stream per 16 threads
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) v += red[w * 256 + i * 16 + j];
+      const int n = n0 + i;
+      if (n < N && j < B) {
+        if (bias) v += (float)bias[n];
+        if (a.gelu) v = gelu_exact(v);
+        if (res) v += (float)res[(long long)j * a.ldres + n];
+        if (a.y_f32) {
+          a.y_f32[(long long)j * N + n] = v;
+        } else if (a.kcache && n >= a.d_model) {
+          const int seg = n / a.d_model;
+          T* dst = reinterpret_cast<T*>(seg == 1 ? a.kcache : a.vcache);
+          dst[(long long)j * a.cache_bstride + (long long)a.stt->pos * a.d_model + (n - seg * a.d_model)] = (T)v;
+        } else {
+          reinterpret_cast<T*>(a.y)[(long long)j * a.ldy + n] = (T)v;
         }
       }
     }
@@ -620,7 +798,35 @@ hipError_t init_decode_kernels() {
 }
 
 template <typename T>
+static hipError_t skinny_launch(const GemvArgs& a, hipStream_t st) {
+  constexpr int E = ElemTraits<T>::kPer16B;
+  constexpr int NW = 8;
+  if (a.K % (4 * E) != 0 || (a.ln_g && a.K > 1280) || a.B > 16) return hipErrorInvalidValue;
+  size_t lds = (size_t)NW * 256 * 4;
+  if (a.ln_g) lds += (size_t)16 * (a.K / E + 1) * 16;
+  if (a.N >= 16384) {
+    dim3 grid((a.N + 16 * GEMV_RG - 1) / (16 * GEMV_RG));
+    hipLaunchKernelGGL((skinny_mfma_kernel<T, NW, true>), grid, dim3(NW * 64), lds, st, a);
+  } else {
+    dim3 grid((a.N + 15) / 16);
+    hipLaunchKernelGGL((skinny_mfma_kernel<T, NW, false>), grid, dim3(NW * 64), lds, st, a);
+  }
+  return hipGetLastError();
+}
+
+static int gemv_mfma_min_b() {  // streams from which the MFMA formulation is used (TW_SKINNY_MIN_B overrides, for A/B runs)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("TW_SKINNY_MIN_B");
+    v = e ? atoi(e) : 5;
+    if (v < 1) v = 1;
+  }
+  return v;
+}
+
+template <typename T>
 static hipError_t gemv_b(const GemvArgs& a, hipStream_t st) {
+  if (a.B >= gemv_mfma_min_b() && a.B <= 16) return skinny_launch<T>(a, st);
   if (a.B <= 1) return gemv_r<T, 1>(a, st);
   if (a.B <= 4) return gemv_r<T, 4>(a, st);
   if (a.B <= 8) return gemv_r<T, 8>(a, st);
