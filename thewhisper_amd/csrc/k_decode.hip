@@ -797,10 +797,17 @@ hipError_t init_decode_kernels() {
   return gemv_attr<float, 16>();
 }
 
-template <typename T>
-static hipError_t skinny_launch(const GemvArgs& a, hipStream_t st) {
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+template <typename T, int NW>
+static hipError_t skinny_launch_nw(const GemvArgs& a0, hipStream_t st) {
   constexpr int E = ElemTraits<T>::kPer16B;
-  constexpr int NW = 8;
+  GemvArgs a = a0;
+  static const int dbg_noln = env_int("TW_DBG_NOLN", 0);  // timing experiments only (wrong results)
+  if (dbg_noln) { a.ln_g = nullptr; a.ln_b = nullptr; }
   if (a.K % (4 * E) != 0 || (a.ln_g && a.K > 1280) || a.B > 16) return hipErrorInvalidValue;
   size_t lds = (size_t)NW * 256 * 4;
   if (a.ln_g) lds += (size_t)16 * (a.K / E + 1) * 16;
@@ -812,6 +819,12 @@ static hipError_t skinny_launch(const GemvArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((skinny_mfma_kernel<T, NW, false>), grid, dim3(NW * 64), lds, st, a);
   }
   return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t skinny_launch(const GemvArgs& a, hipStream_t st) {
+  static const int nw = env_int("TW_SK_NW", 8);
+  return nw == 4 ? skinny_launch_nw<T, 4>(a, st) : skinny_launch_nw<T, 8>(a, st);
 }
 
 static int gemv_mfma_min_b() {  // streams from which the MFMA formulation is used (TW_SKINNY_MIN_B overrides, for A/B runs)
