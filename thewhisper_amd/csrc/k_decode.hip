@@ -19,9 +19,30 @@
 
 namespace {
 
+// Cross-lane reductions: the four steps inside a 16-lane DPP row are single v_add_f32_dpp / v_max_f32_dpp
+// instructions (quad_perm xor 1, xor 2, row_ror 4, row_ror 8); only the two cross-row steps go through
+// ds_bpermute.  (A plain __shfl_xor butterfly is six dependent ds_bpermute round trips.)
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {  // every lane gets the sum over its 16-lane row
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x124>(v);  // row_ror:4
+  v += dpp_mov<0x128>(v);  // row_ror:8
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_mov<0xB1>(v));
+  v = fmaxf(v, dpp_mov<0x4E>(v));
+  v = fmaxf(v, dpp_mov<0x124>(v));
+  v = fmaxf(v, dpp_mov<0x128>(v));
+  return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v = row16_sum(v);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
   return v;
 }
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -416,6 +437,14 @@ __global__ __launch_bounds__(NW * 64) void skinny_mfma_kernel(GemvArgs a) {
       wrow = W + (long long)min(n0 + fr, N - 1) * K;
       load_w(s_lo);
     }
+    // epilogue operands of this thread's (stream, row) output are requested before the matrix work
+    const int ej = tid >> 4, ei = tid & 15;
+    const bool e_on = tid < 256 && (n0 + ei) < N && ej < B;
+    float e_bias = 0.f, e_res = 0.f;
+    if (e_on) {
+      if (bias) e_bias = (float)bias[n0 + ei];
+      if (res) e_res = (float)res[(long long)ej * a.ldres + n0 + ei];
+    }
     f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
     for (int s0 = s_lo; s0 < s_hi; s0 += SK_MAXS) {
       if (s0 > s_lo) load_w(s0);
@@ -445,10 +474,10 @@ __global__ __launch_bounds__(NW * 64) void skinny_mfma_kernel(GemvArgs a) {
 #pragma unroll
       for (int w = 0; w < NW; ++w) v += red[w * 256 + i * 16 + j];
       const int n = n0 + i;
-      if (n < N && j < B) {
-        if (bias) v += (float)bias[n];
+      if (e_on) {
+        v += e_bias;
         if (a.gelu) v = gelu_exact(v);
-        if (res) v += (float)res[(long long)j * a.ldres + n];
+        v += e_res;
         if (a.y_f32) {
           a.y_f32[(long long)j * N + n] = v;
         } else if (a.kcache && n >= a.d_model) {
@@ -481,16 +510,11 @@ template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float
   o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
 }
 
-__device__ __forceinline__ float group16_sum(float v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 8, 64);
-  return v;
-}
+__device__ __forceinline__ float group16_sum(float v) { return row16_sum(v); }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  v = row16_max(v);
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
   return v;
 }
 
@@ -589,6 +613,90 @@ __device__ __forceinline__ float attend_block(const T* __restrict__ qptr, const 
   return inv;
 }
 
+// Single-round-trip variant for n_keys <= (NT/16)*U: every thread requests its U K rows AND U V rows back to
+// back (one memory latency for the whole head), scores and probabilities stay in registers, two barriers.
+template <typename T, int NT, int U>
+__device__ __forceinline__ float attend_block_fused(const T* __restrict__ qptr, const T* __restrict__ kbase,
+                                                    const T* __restrict__ vbase, long long stride, int n_keys, float* sc,
+                                                    float* red, T* __restrict__ outp, bool want_probs) {
+  constexpr int KG = NT / 16;
+  constexpr int NW = NT / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kg = tid >> 4, dq = tid & 15;
+  float qv[4];
+  load4<T>(qptr + dq * 4, qv);
+  float kv[U][4], vv[U][4];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    int t = u * KG + kg;
+    if (t >= n_keys) t = n_keys - 1;
+    load4<T>(kbase + (long long)t * stride + dq * 4, kv[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    int t = u * KG + kg;
+    if (t >= n_keys) t = n_keys - 1;
+    load4<T>(vbase + (long long)t * stride + dq * 4, vv[u]);
+  }
+  float sv[U];
+  float m = -1.0e30f;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    float s = qv[0] * kv[u][0] + qv[1] * kv[u][1] + qv[2] * kv[u][2] + qv[3] * kv[u][3];
+    s = group16_sum(s);
+    const bool valid = (u * KG + kg) < n_keys;
+    sv[u] = valid ? s : -1.0e30f;
+    m = fmaxf(m, sv[u]);
+  }
+  m = fmaxf(m, __shfl_xor(m, 16, 64));  // rows of the wavefront hold different key groups
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  float M = red[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) M = fmaxf(M, red[w]);
+  float o[4] = {0.f, 0.f, 0.f, 0.f};
+  float ls = 0.f;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int t = u * KG + kg;
+    const float p = (t < n_keys) ? expf(sv[u] - M) : 0.f;
+    ls += p;
+    if (want_probs && dq == 0 && t < n_keys) sc[t] = p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = fmaf(p, vv[u][i], o[i]);
+  }
+  // all 16 lanes of a key group carry the same p: fold the 4 groups of the wavefront, one partial per wave
+  ls += __shfl_xor(ls, 16, 64);
+  ls += __shfl_xor(ls, 32, 64);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float v = o[i];
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    o[i] = v;
+  }
+  float* wl = red + 8;    // [NW]
+  float* wo = red + 16;   // [NW][64]
+  if (lane == 0) wl[wave] = ls;
+  if (lane < 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wo[wave * 64 + lane * 4 + i] = o[i];
+  }
+  __syncthreads();
+  float L = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) L += wl[w];
+  const float inv = 1.0f / L;
+  if (tid < 64) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += wo[w * 64 + tid];
+    outp[tid] = (T)(v * inv);
+  }
+  return inv;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void dec_self_attn_kernel(const T* __restrict__ q, const T* __restrict__ kc,
                                                              const T* __restrict__ vc, long long cache_bstride,
@@ -598,8 +706,13 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const T* __restrict_
   const int h = blockIdx.x, b = blockIdx.y;
   const int d = H * 64;
   const int n_keys = stt->pos + 1;
-  attend_block<T, 256>(q + (long long)b * d + h * 64, kc + (long long)b * cache_bstride + h * 64,
-                       vc + (long long)b * cache_bstride + h * 64, d, n_keys, sc, red, out + (long long)b * d + h * 64);
+  if (n_keys <= 16 * 16)
+    attend_block_fused<T, 256, 16>(q + (long long)b * d + h * 64, kc + (long long)b * cache_bstride + h * 64,
+                                   vc + (long long)b * cache_bstride + h * 64, d, n_keys, sc, red,
+                                   out + (long long)b * d + h * 64, false);
+  else
+    attend_block<T, 256>(q + (long long)b * d + h * 64, kc + (long long)b * cache_bstride + h * 64,
+                         vc + (long long)b * cache_bstride + h * 64, d, n_keys, sc, red, out + (long long)b * d + h * 64);
 }
 
 template <typename T>
@@ -614,9 +727,15 @@ __global__ __launch_bounds__(512) void dec_cross_attn_kernel(const T* __restrict
   const int h = blockIdx.x, b = blockIdx.y;
   const int d = H * 64;
   const long long base = ((long long)b * H + h) * Tlen * 64;
-  const float inv = attend_block<T, 512>(q + (long long)b * d + h * 64, ck + base, cv + base, 64, Tlen, sc, red,
-                                          out + (long long)b * d + h * 64);
   const int slot = align_slot ? align_slot[h] : -1;
+  float inv;
+  if (Tlen <= 32 * 16)
+    inv = attend_block_fused<T, 512, 16>(q + (long long)b * d + h * 64, ck + base, cv + base, 64, Tlen, sc, red,
+                                         out + (long long)b * d + h * 64, slot >= 0);
+  else
+    inv = attend_block<T, 512>(q + (long long)b * d + h * 64, ck + base, cv + base, 64, Tlen, sc, red,
+                               out + (long long)b * d + h * 64);
+  if (slot >= 0) __syncthreads();
   if (slot >= 0) {  // A11 side output: softmax row of an alignment head
     float* row = align + (((long long)b * Ha + slot) * P + stt->pos) * Tlen;
     for (int t = threadIdx.x; t < Tlen; t += 512) row[t] = sc[t] * inv;
