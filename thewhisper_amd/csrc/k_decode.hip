@@ -337,16 +337,16 @@ __device__ __forceinline__ f32x4_t sk_mfma<float>(const u32x4_t& w, const u32x4_
   return acc;
 }
 
-template <typename T, int NW, bool MULTI>
+template <typename T, int NW>
 __global__ __launch_bounds__(NW * 64) void skinny_mfma_kernel(GemvArgs a) {
   constexpr int E = ElemTraits<T>::kPer16B;
   constexpr int NT = NW * 64;
   constexpr int MAXV = (1280 / E + 63) / 64;
   constexpr int RPW = (16 + NW - 1) / NW;  // LayerNorm rows per wavefront
-  constexpr int RG = MULTI ? GEMV_RG : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, kq = lane >> 4;
+  const int RG = a.rg;
   const int K = a.K, N = a.N, B = a.B;
   const T* x = reinterpret_cast<const T*>(a.x);
   const T* W = reinterpret_cast<const T*>(a.W);
@@ -930,13 +930,13 @@ static hipError_t skinny_launch_nw(const GemvArgs& a0, hipStream_t st) {
   if (a.K % (4 * E) != 0 || (a.ln_g && a.K > 1280) || a.B > 16) return hipErrorInvalidValue;
   size_t lds = (size_t)NW * 256 * 4;
   if (a.ln_g) lds += (size_t)16 * (a.K / E + 1) * 16;
-  if (a.N >= 16384) {
-    dim3 grid((a.N + 16 * GEMV_RG - 1) / (16 * GEMV_RG));
-    hipLaunchKernelGGL((skinny_mfma_kernel<T, NW, true>), grid, dim3(NW * 64), lds, st, a);
-  } else {
-    dim3 grid((a.N + 15) / 16);
-    hipLaunchKernelGGL((skinny_mfma_kernel<T, NW, false>), grid, dim3(NW * 64), lds, st, a);
-  }
+  const int tiles = (a.N + 15) / 16;
+  // tall matrices (the tied logits projection) walk several tiles per workgroup so that x is normalised once per group
+  static const int max_blocks = env_int("TW_SK_MAX_BLOCKS", 256);
+  a.rg = (tiles + max_blocks - 1) / max_blocks;
+  if (a.rg < 1) a.rg = 1;
+  dim3 grid((tiles + a.rg - 1) / a.rg);
+  hipLaunchKernelGGL((skinny_mfma_kernel<T, NW>), grid, dim3(NW * 64), lds, st, a);
   return hipGetLastError();
 }
 

@@ -103,6 +103,7 @@ struct GemvArgs {
   float* y_f32;                  // float32 output [B, N] (logits) when non-null
   // optional KV-cache scatter for the fused self-attention QKV projection: rows [d,2d) -> kcache, [2d,3d) -> vcache
   void* kcache; void* vcache; long long cache_bstride; int d_model; const DecState* stt;
+  int rg;  // skinny path: 16-row tiles walked per workgroup (set by the launcher)
 };
 hipError_t launch_gemv(int dtype, const GemvArgs& a, hipStream_t st);
 hipError_t init_decode_kernels();  // once per process: dynamic-LDS caps of the gemv instantiations
