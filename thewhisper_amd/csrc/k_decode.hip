@@ -821,12 +821,54 @@ __global__ __launch_bounds__(1024) void sampler_kernel(SamplerArgs a) {
     for (int i = 0; i < a.n_suppress; ++i) masked |= (v == a.suppress[i]);
     return masked ? -INFINITY : lg[v];
   };
+  // ---- the row is read ONCE into registers (2 consecutive floats per thread and iteration, all loads in
+  //      flight together: the row is 207 KB, the kernel is latency-bound), then both passes run on registers ----
+  constexpr int MAXIT = 26;  // 26 * 1024 * 2 = 53248 >= vocab
+  const bool vec_ok = (V <= MAXIT * 2048) && ((V & 1) == 0);
+  float s0[MAXIT], s1[MAXIT];
+  if (vec_ok) {
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int v = (it * 1024 + tid) * 2;
+      float2 x2 = make_float2(-INFINITY, -INFINITY);
+      if (v < V) x2 = *reinterpret_cast<const float2*>(lg + v);
+      s0[it] = x2.x;
+      s1[it] = x2.y;
+    }
+  }
+  auto masked_at = [&](int v) -> bool {
+    bool masked = false;
+    if (mask_eos && v == a.eos) masked = true;
+    if (a.timestamps && v == a.no_ts_id) masked = true;
+    if (v >= b_lo && v < b_hi) masked = true;
+    if (v >= c_lo && v < c_hi) masked = true;
+    if (v < d_hi) masked = true;
+    if (v >= e_lo) masked = true;
+    if (first)
+      for (int i = 0; i < a.n_begin_suppress; ++i) masked |= (v == a.begin_suppress[i]);
+    for (int i = 0; i < a.n_suppress; ++i) masked |= (v == a.suppress[i]);
+    return masked;
+  };
   // ---- pass 1: best text token, best timestamp token ----
   MaxIdx bt{-INFINITY, 0x7fffffff}, bs{-INFINITY, 0x7fffffff};
-  for (int v = tid; v < V; v += 1024) {
-    const float s = score(v);
-    MaxIdx c{s, v};
-    if (v < ts_begin) bt = better(bt, c); else bs = better(bs, c);
+  if (vec_ok) {
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int v = (it * 1024 + tid) * 2;
+      if (v < V) {
+        if (masked_at(v)) s0[it] = -INFINITY;
+        if (masked_at(v + 1)) s1[it] = -INFINITY;
+        MaxIdx c0{s0[it], v}, c1{s1[it], v + 1};
+        if (v < ts_begin) bt = better(bt, c0); else bs = better(bs, c0);
+        if (v + 1 < ts_begin) bt = better(bt, c1); else bs = better(bs, c1);
+      }
+    }
+  } else {
+    for (int v = tid; v < V; v += 1024) {
+      const float sc_ = score(v);
+      MaxIdx c{sc_, v};
+      if (v < ts_begin) bt = better(bt, c); else bs = better(bs, c);
+    }
   }
   bt = wave_best(bt);
   bs = wave_best(bs);
@@ -839,9 +881,17 @@ __global__ __launch_bounds__(1024) void sampler_kernel(SamplerArgs a) {
   bool force_ts = false;
   if (a.timestamps && bs.v > -INFINITY) {
     float sum = 0.f;
-    for (int v = ts_begin + tid; v < V; v += 1024) {
-      const float s = score(v);
-      sum += expf(s - bs.v);
+    if (vec_ok) {
+#pragma unroll
+      for (int it = 0; it < MAXIT; ++it) {
+        const int v = (it * 1024 + tid) * 2;
+        if (v < V) {
+          if (v >= ts_begin) sum += expf(s0[it] - bs.v);
+          if (v + 1 >= ts_begin) sum += expf(s1[it] - bs.v);
+        }
+      }
+    } else {
+      for (int v = ts_begin + tid; v < V; v += 1024) sum += expf(score(v) - bs.v);
     }
     sum = wave_sum(sum);
     if (lane == 0) red_sum[wave] = sum;
