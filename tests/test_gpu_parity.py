@@ -166,6 +166,8 @@ def test_greedy_ids_alignment_and_timestamps(preset, T, B, max_new, graph, min_n
     assert np.abs(al - ref["cross"]).max() < 1e-4
     assert np.abs(al.sum(-1) - 1.0).max() < 1e-4                            # softmax rows
     nf = [max(2 * T - 8 * i, 40) for i in range(B)]                          # ragged valid-frame counts
+    if B >= 2:
+        nf[1] = -(T // 2) - 1                                              # negative bound: HF slices from the end (seek loop)
     ts = eng.token_timestamps(B, 3, L, nf)
     assert np.abs(ts - wo.token_timestamps(ref["cross"], 3, nf)).max() <= 0.0201
     eng.close()

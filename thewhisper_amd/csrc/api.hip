@@ -812,7 +812,15 @@ int tw_token_timestamps(tw_ctx* c, int32_t B, int32_t n_prompt, int32_t seq_len,
   hipStream_t st = pick_stream(c, stream);
   std::vector<int> cols(B);
   for (int b = 0; b < B; ++b) {
-    int nc = num_frames_host ? num_frames_host[b] / 2 : c->T;
+    // HF crops with the Python slice `weights[..., : num_frames // 2]` (HF:models/whisper/generation_whisper.py:346-349):
+    // floor division, and a NEGATIVE bound (num_frames - seek < 0 happens in the seek loop for clips shorter than the
+    // chunk) counts from the end.  Reproduced literally so token timestamps stay identical to the reference.
+    int nc = c->T;
+    if (num_frames_host) {
+      const int nf = num_frames_host[b];
+      nc = (nf >= 0) ? nf / 2 : -((-nf + 1) / 2);   // floor(nf / 2)
+      if (nc < 0) nc += c->T;
+    }
     if (nc > c->T) nc = c->T;
     if (nc < 1) nc = 1;
     cols[b] = nc;
