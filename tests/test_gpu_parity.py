@@ -282,3 +282,39 @@ def test_large_v3_full_size_properties():
     assert np.abs(a4.sum(-1) - 1.0).max() < 2e-3
     assert (np.diff(t4[:, 3:], axis=1) >= -1e-6).all() and t4.min() >= 0 and t4.max() <= 10.0
     eng.close()
+
+
+def test_batching_hub_on_gpu_matches_reference_golden():
+    """§8f row 1: four concurrent sessions share one MI355X engine through the BatchingHub; every session still gets the
+    reference's per-stream result, and requests from different sessions are executed as one batch."""
+    import threading
+
+    from tests.test_pipeline_glue import build_amd_pipeline, normalise
+    from thewhisper_amd import AMDWhisperBackend
+    from thewhisper_amd.serving import BatchingHub
+
+    g = json.load(open(os.path.join(GOLD, "pipeline_golden.json")))["streaming_micro_c10"]
+    pipe = build_amd_pipeline("micro", 10, 4, device="cuda", engine_factory=None)
+    hub = BatchingHub(AMDWhisperBackend(None, chunk_length_s=10, asr_pipeline=pipe), max_batch=4, max_wait_s=0.5)
+    audio = wo.synth_audio(16000 * g["seconds"], g["seed"], g["kind"])
+    picks = g["calls"][::5]
+    out = [[None] * len(picks) for _ in range(4)]
+    barrier = threading.Barrier(4)
+
+    def session(k):
+        be = hub.stream_backend()
+        for i, c in enumerate(picks):
+            barrier.wait()
+            out[k][i] = be.transcribe(audio[c["offset"] : c["offset"] + c["n"]], c["t0"], 16000)
+
+    th = [threading.Thread(target=session, args=(k,)) for k in range(4)]
+    [t.start() for t in th]
+    [t.join(300) for t in th]
+    hub.close()
+    for k in range(4):
+        for i, c in enumerate(picks):
+            got = normalise(out[k][i])
+            assert [w["text"] for w in got] == [w["text"] for w in c["result"]]
+            for a, b in zip(got, c["result"]):
+                assert abs(a["start"] - b["start"]) <= 0.0201 and abs(a["end"] - b["end"]) <= 0.0201
+    assert max(hub.batches) > 1

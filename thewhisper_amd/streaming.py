@@ -59,22 +59,30 @@ class AMDWhisperBackend:
             **pipeline_kwargs,
         )
 
+    def _generate_kwargs(self) -> Dict[str, Any]:
+        return {"use_cache": True, "num_beams": 1, "do_sample": False, "max_new_tokens": 128, "language": self.language}
+
     def transcribe(self, audio: np.ndarray, buffer_start_time: float, sample_rate: int) -> List[Dict[str, Any]]:
-        audio_duration: float = len(audio) / sample_rate
-        max_new_tokens = 128
-        generate_kwargs: Dict[str, Any] = {
-            "use_cache": True,
-            "num_beams": 1,
-            "do_sample": False,
-            "max_new_tokens": max_new_tokens,
-            "language": self.language,
-        }
         result: Dict[str, Any] = self.asr_pipeline(
             audio,
             return_timestamps="word",
-            generate_kwargs=generate_kwargs,
+            generate_kwargs=self._generate_kwargs(),
             chunk_length_s=self.chunk_length_s,
         )
+        return self._to_tokens(result, len(audio) / sample_rate, buffer_start_time)
+
+    def transcribe_many(self, requests, batch_size: Optional[int] = None) -> List[List[Dict[str, Any]]]:
+        """Several streams' rolling buffers in ONE pipeline call: [(audio, buffer_start_time, sample_rate), ...].
+        HF collates the chunks of different buffers into batched engine calls; per-stream results are unchanged."""
+        audios = [np.asarray(a) for a, _, _ in requests]
+        kw = {} if batch_size is None else {"batch_size": int(batch_size)}
+        results = self.asr_pipeline(
+            audios, return_timestamps="word", generate_kwargs=self._generate_kwargs(), chunk_length_s=self.chunk_length_s, **kw
+        )
+        return [self._to_tokens(res, len(a) / sr, t0) for res, (a, t0, sr) in zip(results, requests)]
+
+    @staticmethod
+    def _to_tokens(result: Dict[str, Any], audio_duration: float, buffer_start_time: float) -> List[Dict[str, Any]]:
         if _compression_ratio(result["text"]) > 2.2:
             return []
         generated_tokens: List[Dict[str, Any]] = []
