@@ -174,8 +174,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ q, 
           s[t][kt][r] = v;
           mx = fmaxf(mx, v);
         }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = tw_xor32_max(tw_xor16_max(mx));
       const float mnew = fmaxf(mrun[t], mx);
       alpha[t] = expf(mrun[t] - mnew);
       mrun[t] = mnew;
@@ -240,8 +239,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ q, 
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     float l = lrun[t];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l = tw_xor32_sum(tw_xor16_sum(l));
     const float inv = 1.0f / l;
     const int qi = qblock + (wave * QT + t) * 16 + fr;
     if (qi >= Tlen) continue;

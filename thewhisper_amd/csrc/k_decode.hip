@@ -19,32 +19,8 @@
 
 namespace {
 
-// Cross-lane reductions: the four steps inside a 16-lane DPP row are single v_add_f32_dpp / v_max_f32_dpp
-// instructions (quad_perm xor 1, xor 2, row_ror 4, row_ror 8); only the two cross-row steps go through
-// ds_bpermute.  (A plain __shfl_xor butterfly is six dependent ds_bpermute round trips.)
-template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float row16_sum(float v) {  // every lane gets the sum over its 16-lane row
-  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
-  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
-  v += dpp_mov<0x124>(v);  // row_ror:4
-  v += dpp_mov<0x128>(v);  // row_ror:8
-  return v;
-}
-__device__ __forceinline__ float row16_max(float v) {
-  v = fmaxf(v, dpp_mov<0xB1>(v));
-  v = fmaxf(v, dpp_mov<0x4E>(v));
-  v = fmaxf(v, dpp_mov<0x124>(v));
-  v = fmaxf(v, dpp_mov<0x128>(v));
-  return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-  v = row16_sum(v);
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
-}
+__device__ __forceinline__ float row16_sum(float v) { return tw_row16_sum(v); }
+__device__ __forceinline__ float wave_sum(float v) { return tw_wave_sum(v); }
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 template <typename T> __device__ __forceinline__ float dot16(const u32x4_t& w, const u32x4_t& x, float acc);
@@ -346,7 +322,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_mfma_kernel(GemvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, kq = lane >> 4;
-  const int RG = a.rg;
+  const int RG = a.rg & 0xff;
   const int K = a.K, N = a.N, B = a.B;
   const T* x = reinterpret_cast<const T*>(a.x);
   const T* W = reinterpret_cast<const T*>(a.W);
@@ -399,7 +375,8 @@ __global__ __launch_bounds__(NW * 64) void skinny_mfma_kernel(GemvArgs a) {
             for (int e = 0; e < E; ++e) v[i][e] = 0.f;
           }
         }
-        const float mean = wave_sum(sm) / (float)K;
+        const bool dbg_nored = (a.rg & 0x100) != 0;  // timing experiments only
+        const float mean = dbg_nored ? sm : wave_sum(sm) / (float)K;
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
@@ -409,7 +386,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_mfma_kernel(GemvArgs a) {
             for (int e = 0; e < E; ++e) { const float c = v[i][e] - mean; q += c * c; }
           }
         }
-        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)K + 1e-5f);
+        const float rstd = dbg_nored ? q : 1.0f / sqrtf(wave_sum(q) / (float)K + 1e-5f);
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
           const int vi = lane + i * 64;
@@ -511,12 +488,7 @@ template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float
 }
 
 __device__ __forceinline__ float group16_sum(float v) { return row16_sum(v); }
-__device__ __forceinline__ float wave_max(float v) {
-  v = row16_max(v);
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  v = fmaxf(v, __shfl_xor(v, 32, 64));
-  return v;
-}
+__device__ __forceinline__ float wave_max(float v) { return tw_wave_max(v); }
 
 // Shared by both attention kernels.  NT threads; sc: LDS float[n_keys]; red: LDS float[NT/64 * 64 + 16].
 // Returns (in every thread) 1/L; the normalised context vector is written by the first 64 threads.
@@ -593,10 +565,7 @@ __device__ __forceinline__ float attend_block(const T* __restrict__ qptr, const 
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {  // fold the 4 key groups of this wavefront
-    float v = o[i];
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    o[i] = v;
+    o[i] = tw_xor32_sum(tw_xor16_sum(o[i]));
   }
   float* wo = red + 16;  // [NW][64]
   if (lane < 16) {
@@ -648,8 +617,7 @@ __device__ __forceinline__ float attend_block_fused(const T* __restrict__ qptr, 
     sv[u] = valid ? s : -1.0e30f;
     m = fmaxf(m, sv[u]);
   }
-  m = fmaxf(m, __shfl_xor(m, 16, 64));  // rows of the wavefront hold different key groups
-  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  m = tw_xor32_max(tw_xor16_max(m));  // rows of the wavefront hold different key groups
   if (lane == 0) red[wave] = m;
   __syncthreads();
   float M = red[0];
@@ -667,14 +635,10 @@ __device__ __forceinline__ float attend_block_fused(const T* __restrict__ qptr, 
     for (int i = 0; i < 4; ++i) o[i] = fmaf(p, vv[u][i], o[i]);
   }
   // all 16 lanes of a key group carry the same p: fold the 4 groups of the wavefront, one partial per wave
-  ls += __shfl_xor(ls, 16, 64);
-  ls += __shfl_xor(ls, 32, 64);
+  ls = tw_xor32_sum(tw_xor16_sum(ls));
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    float v = o[i];
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    o[i] = v;
+    o[i] = tw_xor32_sum(tw_xor16_sum(o[i]));
   }
   float* wl = red + 8;    // [NW]
   float* wo = red + 16;   // [NW][64]
@@ -986,6 +950,8 @@ static hipError_t skinny_launch_nw(const GemvArgs& a0, hipStream_t st) {
   a.rg = (tiles + max_blocks - 1) / max_blocks;
   if (a.rg < 1) a.rg = 1;
   dim3 grid((tiles + a.rg - 1) / a.rg);
+  static const int dbg_nored = env_int("TW_DBG_LN_NORED", 0);
+  if (dbg_nored) a.rg |= 0x100;
   hipLaunchKernelGGL((skinny_mfma_kernel<T, NW>), grid, dim3(NW * 64), lds, st, a);
   return hipGetLastError();
 }

@@ -4,11 +4,7 @@
 
 namespace {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return tw_wave_sum(v); }
 
 template <typename T> __device__ __forceinline__ float ldf(const T* p) { return (float)*p; }
 

@@ -11,6 +11,38 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;  // a 16-B register quad (native vector: stays in VGPRs)
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
+// ---- cross-lane reductions without LDS traffic (gfx950) ----------------------------------------------------------
+// Inside a 16-lane DPP row: v_add/v_max_f32_dpp with quad_perm xor-1, xor-2, row_ror:4, row_ror:8.  Across rows:
+// v_permlane16_swap / v_permlane32_swap with both operands = v leave {v.rowA, v.rowA..} / {v.rowB, v.rowB..} in the two
+// registers, so their sum (max) is the xor-16 / xor-32 butterfly step.  (A __shfl_xor butterfly is six dependent
+// ds_bpermute round trips through the LDS crossbar.)  The swaps are issued through inline asm: with hipcc 7.2 the
+// __builtin_amdgcn_permlane{16,32}_swap builtins fed with one value combine the two results as r[0]+r[0].
+template <int CTRL> __device__ __forceinline__ float tw_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ void tw_swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void tw_swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float tw_row16_sum(float v) {
+  v += tw_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += tw_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += tw_dpp<0x124>(v);  // row_ror:4
+  v += tw_dpp<0x128>(v);  // row_ror:8
+  return v;
+}
+__device__ __forceinline__ float tw_row16_max(float v) {
+  v = fmaxf(v, tw_dpp<0xB1>(v));
+  v = fmaxf(v, tw_dpp<0x4E>(v));
+  v = fmaxf(v, tw_dpp<0x124>(v));
+  v = fmaxf(v, tw_dpp<0x128>(v));
+  return v;
+}
+__device__ __forceinline__ float tw_xor16_sum(float v) { float a = v, b = v; tw_swap16(a, b); return a + b; }
+__device__ __forceinline__ float tw_xor32_sum(float v) { float a = v, b = v; tw_swap32(a, b); return a + b; }
+__device__ __forceinline__ float tw_xor16_max(float v) { float a = v, b = v; tw_swap16(a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float tw_xor32_max(float v) { float a = v, b = v; tw_swap32(a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float tw_wave_sum(float v) { return tw_xor32_sum(tw_xor16_sum(tw_row16_sum(v))); }
+__device__ __forceinline__ float tw_wave_max(float v) { return tw_xor32_max(tw_xor16_max(tw_row16_max(v))); }
+
 template <typename T> struct ElemTraits;
 template <> struct ElemTraits<float> { static constexpr int kPer16B = 4; static constexpr int kCode = 0; };
 template <> struct ElemTraits<bf16_t> { static constexpr int kPer16B = 8; static constexpr int kCode = 1; };
