@@ -106,8 +106,8 @@ int tw_destroy(tw_ctx* ctx);
  * the context dtype and copied/repacked; the caller may free it afterwards. */
 int tw_load_weight(tw_ctx* ctx, const char* name, const void* dev_ptr, int32_t dtype, int32_t ndim,
                    const int64_t* shape, void* stream);
-/* Checks that every tensor arrived, interpolates the encoder positions (A0), folds the 1/8
- * query scale into q_proj, builds fused QKV blocks. */
+/* Checks that every tensor arrived, interpolates the encoder positions (A0) and folds each decoder pre-LayerNorm
+ * into the projection that consumes it (W <- W*gain plus two per-row vectors).  Call exactly once. */
 int tw_finalize_weights(tw_ctx* ctx, void* stream);
 
 /* A1.  Replaces: WhisperFeatureExtractor._torch_extract_fbank_features

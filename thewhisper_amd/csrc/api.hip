@@ -25,6 +25,8 @@ struct LayerW {
   void *wo_c = nullptr, *bo_c = nullptr;
   void *ln2_g = nullptr, *ln2_b = nullptr;  // final_layer_norm
   void *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
+  // folded pre-LayerNorm companions of the decoder's LN'd projections (float32 [N]): see k_decode.hip
+  float *qkv_gw = nullptr, *qkv_cb = nullptr, *qc_gw = nullptr, *qc_cb = nullptr, *fc1_gw = nullptr, *fc1_cb = nullptr;
 };
 
 }  // namespace
@@ -42,6 +44,8 @@ struct tw_ctx {
   void *conv1_w = nullptr, *conv1_b = nullptr, *conv2_w = nullptr, *conv2_b = nullptr;
   void *enc_pos_raw = nullptr, *enc_pos = nullptr, *enc_ln_g = nullptr, *enc_ln_b = nullptr;
   void *tok_emb = nullptr, *dec_pos = nullptr, *dec_ln_g = nullptr, *dec_ln_b = nullptr;
+  void* logit_w = nullptr;  // tok_emb with the final LayerNorm gain folded in (the lookup table itself stays unscaled)
+  float *logit_gw = nullptr, *logit_cb = nullptr;
   std::vector<LayerW> enc, dec;
   std::set<std::string> loaded;
   bool finalized = false;
@@ -69,6 +73,7 @@ struct tw_ctx {
   int* h_pinned = nullptr;  // pinned host scratch: finished ring [8][Bmax] + misc
   hipEvent_t ring_ev[8]{};
   int last_seq_len = 0, last_n_prompt = 0;
+  int dec_key_bound = 0;  // upper bound of decoder positions for the current decode (prompt + max new tokens)
   int enc_pos_rows = 0;  // rows of the encoder positional table as loaded (1500 upstream)
 
   // dtw workspace
@@ -243,6 +248,9 @@ int tw_create(const tw_config* cfg, tw_ctx** out) {
   CALLOC(c->dec_pos, P * d * e, true);
   CALLOC(c->dec_ln_g, d * e, true);
   CALLOC(c->dec_ln_b, d * e, true);
+  CALLOC(c->logit_w, V * d * e, false);
+  CALLOC(c->logit_gw, V * 4, true);
+  CALLOC(c->logit_cb, V * 4, true);
   c->enc.resize(c->Le);
   c->dec.resize(c->Ld);
   auto alloc_layer = [&](LayerW& L, bool decoder) -> int {
@@ -251,6 +259,12 @@ int tw_create(const tw_config* cfg, tw_ctx** out) {
     LA(L.ln1_g, d); LA(L.ln1_b, d); LA(L.wqkv, 3 * d * d); LA(L.bqkv, 3 * d); LA(L.wo, d * d); LA(L.bo, d);
     LA(L.ln2_g, d); LA(L.ln2_b, d); LA(L.w1, F * d); LA(L.b1, F); LA(L.w2, d * F); LA(L.b2, d);
     if (decoder) {
+      if ((r = dalloc(c, &L.qkv_gw, 3 * d * 4, true)) != TW_OK) return r;
+      if ((r = dalloc(c, &L.qkv_cb, 3 * d * 4, true)) != TW_OK) return r;
+      if ((r = dalloc(c, &L.qc_gw, d * 4, true)) != TW_OK) return r;
+      if ((r = dalloc(c, &L.qc_cb, d * 4, true)) != TW_OK) return r;
+      if ((r = dalloc(c, &L.fc1_gw, F * 4, true)) != TW_OK) return r;
+      if ((r = dalloc(c, &L.fc1_cb, F * 4, true)) != TW_OK) return r;
       LA(L.lnx_g, d); LA(L.lnx_b, d); LA(L.wq_c, d * d); LA(L.bq_c, d); LA(L.wkv_c, 2 * d * d); LA(L.bkv_c, 2 * d);
       LA(L.wo_c, d * d); LA(L.bo_c, d);
     }
@@ -444,6 +458,16 @@ int tw_finalize_weights(tw_ctx* c, void* stream) {
   if (c->T > n_old) return fail(c, TW_EINVAL, "source_positions %d exceeds the positional table (%d rows)", c->T, n_old);
   // A0: patch_hf_model (R:thestage_speechkit/nvidia/asr_pipeline.py:15-27)
   HIPCHK(c, launch_interp_positions(c->dtype, TW_F32, c->enc_pos_raw, c->enc_pos, n_old, c->T, c->d, st));
+  if (c->finalized) return fail(c, TW_ESTATE, "tw_finalize_weights called twice");
+  // fold every decoder pre-LayerNorm into the projection that consumes it (k_decode.hip): W <- W*g, gw, cb
+  for (int l = 0; l < c->Ld; ++l) {
+    LayerW& L = c->dec[l];
+    HIPCHK(c, launch_fold_ln(c->dtype, L.wqkv, L.wqkv, L.ln1_g, L.ln1_b, L.bqkv, L.qkv_gw, L.qkv_cb, 3 * c->d, c->d, st));
+    HIPCHK(c, launch_fold_ln(c->dtype, L.wq_c, L.wq_c, L.lnx_g, L.lnx_b, L.bq_c, L.qc_gw, L.qc_cb, c->d, c->d, st));
+    HIPCHK(c, launch_fold_ln(c->dtype, L.w1, L.w1, L.ln2_g, L.ln2_b, L.b1, L.fc1_gw, L.fc1_cb, c->ffn, c->d, st));
+  }
+  HIPCHK(c, launch_fold_ln(c->dtype, c->logit_w, c->tok_emb, c->dec_ln_g, c->dec_ln_b, nullptr, c->logit_gw, c->logit_cb,
+                           c->V, c->d, st));
   HIPCHK(c, hipStreamSynchronize(st));
   c->finalized = true;
   return TW_OK;
@@ -581,11 +605,12 @@ int decode_core(tw_ctx* c, int B, hipStream_t st) {
     void* sv = at(c->self_v, self_layer * l, e);
     {  // LN + fused QKV; k,v rows go straight into the cache at position pos
       GemvArgs a{};
-      a.x = xin; a.ldx = d; a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.W = L.wqkv; a.bias = L.bqkv; a.N = 3 * d; a.K = d; a.B = B;
+      a.x = xin; a.ldx = d; a.ln_gw = L.qkv_gw; a.ln_cb = L.qkv_cb; a.W = L.wqkv; a.N = 3 * d; a.K = d; a.B = B;
       a.y = c->dq; a.ldy = d; a.kcache = sk; a.vcache = sv; a.cache_bstride = (long long)P * d; a.d_model = d; a.stt = c->stt;
       HIPCHK(c, launch_gemv(dt, a, st));
     }
-    HIPCHK(c, launch_dec_self_attn(dt, c->dq, sk, sv, (long long)P * d, c->datt, B, H, c->stt, st));
+    HIPCHK(c, launch_dec_self_attn(dt, c->dq, sk, sv, (long long)P * d, c->datt, B, H, c->dec_key_bound > 0 ? c->dec_key_bound : P,
+                                   c->stt, st));
     {
       GemvArgs a{};
       a.x = c->datt; a.ldx = d; a.W = L.wo; a.bias = L.bo; a.N = d; a.K = d; a.B = B; a.res = xin; a.ldres = d;
@@ -594,7 +619,7 @@ int decode_core(tw_ctx* c, int B, hipStream_t st) {
     }
     {
       GemvArgs a{};
-      a.x = xmid; a.ldx = d; a.ln_g = L.lnx_g; a.ln_b = L.lnx_b; a.W = L.wq_c; a.bias = L.bq_c; a.N = d; a.K = d; a.B = B;
+      a.x = xmid; a.ldx = d; a.ln_gw = L.qc_gw; a.ln_cb = L.qc_cb; a.W = L.wq_c; a.N = d; a.K = d; a.B = B;
       a.y = c->dq; a.ldy = d;
       HIPCHK(c, launch_gemv(dt, a, st));
     }
@@ -609,7 +634,7 @@ int decode_core(tw_ctx* c, int B, hipStream_t st) {
     }
     {
       GemvArgs a{};
-      a.x = xin; a.ldx = d; a.ln_g = L.ln2_g; a.ln_b = L.ln2_b; a.W = L.w1; a.bias = L.b1; a.N = F; a.K = d; a.B = B;
+      a.x = xin; a.ldx = d; a.ln_gw = L.fc1_gw; a.ln_cb = L.fc1_cb; a.W = L.w1; a.N = F; a.K = d; a.B = B;
       a.gelu = 1; a.y = c->dh; a.ldy = F;
       HIPCHK(c, launch_gemv(dt, a, st));
     }
@@ -623,7 +648,7 @@ int decode_core(tw_ctx* c, int B, hipStream_t st) {
   }
   {
     GemvArgs a{};
-    a.x = xin; a.ldx = d; a.ln_g = c->dec_ln_g; a.ln_b = c->dec_ln_b; a.W = c->tok_emb; a.N = c->V; a.K = d; a.B = B;
+    a.x = xin; a.ldx = d; a.ln_gw = c->logit_gw; a.ln_cb = c->logit_cb; a.W = c->logit_w; a.N = c->V; a.K = d; a.B = B;
     a.y_f32 = c->logits;
     HIPCHK(c, launch_gemv(dt, a, st));
   }
@@ -647,6 +672,7 @@ int tw_decoder_reset(tw_ctx* c, int32_t B, void* stream) {
   hipStream_t st = pick_stream(c, stream);
   int r = reset_state(c, 0, st);
   if (r != TW_OK) return r;
+  c->dec_key_bound = c->P;
   HIPCHK(c, hipStreamSynchronize(st));
   return TW_OK;
 }
@@ -676,6 +702,7 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
   if (max_len > c->P) max_len = c->P;
   if (max_len <= n_prompt) return fail(c, TW_EINVAL, "nothing to generate (max_len %d <= n_prompt %d)", max_len, n_prompt);
   const int out_ld = o->max_length > 0 ? o->max_length : max_len;
+  c->dec_key_bound = max_len;
   hipStream_t st = pick_stream(c, stream);
   const int P = c->P;
 
@@ -711,8 +738,8 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
 
   // ---- optional graph capture of one full step ----
   char keybuf[256];
-  snprintf(keybuf, sizeof keybuf, "%d|%d|%d|%d|%d|%d|%d|%d|%d", B, o->eos_id, o->pad_id, o->min_new_tokens, o->timestamps,
-           o->no_timestamps_id, o->max_initial_timestamp_index, o->n_begin_suppress, o->n_suppress);
+  snprintf(keybuf, sizeof keybuf, "%d|%d|%d|%d|%d|%d|%d|%d|%d|%d", B, o->eos_id, o->pad_id, o->min_new_tokens, o->timestamps,
+           o->no_timestamps_id, o->max_initial_timestamp_index, o->n_begin_suppress, o->n_suppress, max_len <= 256 ? 1 : 0);
   const bool use_graph = c->cfg.use_graph != 0;
   if (use_graph && (c->step_graph == nullptr || c->step_graph_key != keybuf)) {
     if (c->step_graph) { (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }

@@ -72,12 +72,19 @@ template <typename T, int BT> struct GemvChunk {
   static constexpr int kVec = (GEMV_LDS_BUDGET / (BT * 16) / 64) * 64;
 };
 
-// y[b, n] = epi( LN?(x[b, :]) . W[n, :] )   one wavefront = R rows x full K, lanes stride K by 16 B.
-// Latency structure (the decode step is a chain of ~260 such launches, so this matters as much as
-// bandwidth): the first GEMV_D weight vectors of every row and the LayerNorm gain/bias vectors are
-// requested BEFORE the activations are staged, the staging loads are issued in batches of 8 per
-// thread, and the rows a wavefront normalises are independent instruction streams, so the HBM
-// latency of W overlaps the L2 latency of x and the LayerNorm arithmetic.
+// Folded pre-LayerNorm.  For y = LN(x) . W^T + bias with LN(x) = (x - mean) * rstd * g + beta:
+//     y[n] = rstd * ( x . W'[n]  -  mean * gW[n] )  +  cb[n],
+//     W'[n,k] = g[k] W[n,k],   gW[n] = sum_k g[k] W[n,k],   cb[n] = sum_k beta[k] W[n,k] + bias[n]
+// W', gW and cb are prepared once at weight-finalisation time (fold_ln_kernel below), so the projection streams W'
+// against the RAW residual stream exactly like a projection without LayerNorm, and only the two per-stream scalars
+// (mean, rstd) have to be known when the epilogue runs - they are computed off the critical path while the weight
+// loads are in flight.  No normalised copy of x is ever materialised.
+
+// y[b, n] = epi( x[b, :] . W[n, :] )   one wavefront = R rows x full K, lanes stride K by 16 B  (1..4 streams).
+// Latency structure (the decode step is a chain of ~260 such launches, so this matters as much as bandwidth): the
+// first GEMV_D weight vectors of every row and the epilogue operands are requested BEFORE the activations are staged,
+// the staging loads are issued in batches of 8 per thread, LayerNorm statistics are reduced between the staging
+// barrier and the (already in flight) weight data, and the wave reduction uses DPP/permlane steps only.
 template <typename T, int BT, int R, bool MULTI>
 __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
   constexpr int E = ElemTraits<T>::kPer16B;
@@ -85,9 +92,9 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
   constexpr int CV = GemvChunk<T, BT>::kVec;  // vectors per chunk in chunked mode
   constexpr int IPC = CV / 64;
   constexpr int MAXV = (1280 / E + 63) / 64;  // LayerNorm rows have K <= 1280
-  constexpr int RPW = (BT + 3) / 4;           // LayerNorm rows per wavefront
   constexpr int RG = MULTI ? GEMV_RG : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float stat[16][2];               // (mean, rstd) per stream
   u32x4_t* xs = reinterpret_cast<u32x4_t*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int K = a.K, N = a.N, B = a.B;
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
   const int n_it = (nv_row + 63) / 64;
   const bool chunked = nv_row > CV;
   const int xld = chunked ? CV : nv_row;  // LDS row stride in vectors
-  const bool has_ln = a.ln_g != nullptr;
+  const bool has_ln = a.ln_gw != nullptr;
 
   int row0 = ((blockIdx.x * RG) * 4 + wave) * R;
   const T* wrow[R];
@@ -109,112 +116,121 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
     for (int j = 0; j < D; ++j) {
       const int vi = j * 64 + lane;
 #pragma unroll
-      for (int r = 0; r < R; ++r)
-        wq[j][r] = (vi < nv_row) ? *reinterpret_cast<const u32x4_t*>(wrow[r] + (long long)vi * E) : u32x4_t{0u, 0u, 0u, 0u};
+      for (int r = 0; r < R; ++r)  // unconditional (clamped): lanes past the row end re-read the last vector, unused
+        wq[j][r] = *reinterpret_cast<const u32x4_t*>(wrow[r] + (long long)min(vi, nv_row - 1) * E);
     }
   };
-  prime();
-
-  // LayerNorm gain / bias for this lane's vectors (requested early, used after the staging barrier)
-  u32x4_t lg[MAXV], lb[MAXV];
-  if (has_ln) {
-    const T* g = reinterpret_cast<const T*>(a.ln_g);
-    const T* be = reinterpret_cast<const T*>(a.ln_b);
+  // NB on ordering: the vector-memory counter retires loads IN ORDER and a load inside a conditional block gets its own
+  // wait, so every operand is requested unconditionally (clamped addresses, dummy pointers for absent operands) and in
+  // the order it is needed: epilogue scalars, then the activation staging loads, and only then the HBM weight prefetch
+  // (otherwise the LDS staging store would have to wait for the whole weight prefetch as well).
+  const T* bias = reinterpret_cast<const T*>(a.bias);
+  const T* res = reinterpret_cast<const T*>(a.res);
+  const float* gw_p = has_ln ? a.ln_gw : reinterpret_cast<const float*>(W);
+  const float* cb_p = has_ln ? a.ln_cb : reinterpret_cast<const float*>(W);
+  const T* bias_p = bias ? bias : W;
+  const T* res_p = res ? res : W;
+  const DecState* stt_p = a.stt ? a.stt : reinterpret_cast<const DecState*>(W);
+  const int cur_pos = stt_p->pos;  // only meaningful when a.stt != null (KV-cache scatter)
+  auto load_epi = [&](int row0_, float (&e_c)[R], float (&e_gw)[R], float (&e_res)[R]) {
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int vi = lane + i * 64;
-      lg[i] = (vi < nv_row) ? *reinterpret_cast<const u32x4_t*>(g + vi * E) : u32x4_t{0u, 0u, 0u, 0u};
-      lb[i] = (vi < nv_row) ? *reinterpret_cast<const u32x4_t*>(be + vi * E) : u32x4_t{0u, 0u, 0u, 0u};
+    for (int r = 0; r < R; ++r) {
+      const int n = min(row0_ + r, N - 1);
+      const float v_gw = gw_p[has_ln ? n : 0];
+      const float v_cb = cb_p[has_ln ? n : 0];
+      const float v_b = (float)bias_p[bias ? n : 0];
+      const float v_r = (float)res_p[res ? (long long)min(lane, B - 1) * a.ldres + n : 0];
+      e_gw[r] = v_gw;
+      e_c[r] = has_ln ? v_cb : (bias ? v_b : 0.f);
+      e_res[r] = res ? v_r : 0.f;
     }
-  }
-
+  };
+  float e_c0[R], e_gw0[R], e_res0[R];
+  load_epi(row0, e_c0, e_gw0, e_res0);
   // stage `cv` vectors per activation row starting at vector `cbase`; loads issued 8 per thread at a time
+  constexpr int NB = BT <= 4 ? 4 : 8;  // staging loads per thread and batch (one batch covers K <= 8192/BT... see launcher)
+  auto stage_load = [&](int cbase, int cv, int i0, u32x4_t (&tmp)[NB]) {
+    const int total = BT * cv;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int i = i0 + u * 256;
+      const int b = min(i / cv, BT - 1), vi = i - (i / cv) * cv;
+      const bool on = (i < total) && (i / cv) < B;
+      const T* src = x + (long long)min(b, B - 1) * a.ldx + (long long)(cbase + vi) * E;
+      const u32x4_t v = *reinterpret_cast<const u32x4_t*>(src);  // unconditional (clamped) so the loads batch
+      tmp[u] = on ? v : u32x4_t{0u, 0u, 0u, 0u};
+    }
+  };
+  auto stage_store = [&](int cv, int i0, const u32x4_t (&tmp)[NB]) {
+    const int total = BT * cv;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int i = i0 + u * 256;
+      if (i < total) { const int b = i / cv, vi = i - b * cv; xs[b * xld + vi] = tmp[u]; }
+    }
+  };
   auto stage = [&](int cbase, int cv) {
     const int total = BT * cv;
-    for (int i0 = tid; i0 < total; i0 += 256 * 8) {
-      u32x4_t tmp[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = i0 + u * 256;
-        const int b = i / cv, vi = i - b * cv;
-        tmp[u] = (i < total && b < B) ? *reinterpret_cast<const u32x4_t*>(x + (long long)b * a.ldx + (long long)(cbase + vi) * E)
-                                       : u32x4_t{0u, 0u, 0u, 0u};
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int i = i0 + u * 256;
-        if (i < total) { const int b = i / cv, vi = i - b * cv; xs[b * xld + vi] = tmp[u]; }
-      }
+    for (int i0 = tid; i0 < total; i0 += 256 * NB) {
+      u32x4_t tmp[NB];
+      stage_load(cbase, cv, i0, tmp);
+      stage_store(cv, i0, tmp);
     }
   };
 
   if (!chunked) {
-    stage(0, nv_row);
+    u32x4_t first[NB];
+    stage_load(0, nv_row, tid, first);   // first (usually only) staging batch: requested before the weights
+    prime();
+    stage_store(nv_row, tid, first);
+    for (int i0 = tid + 256 * NB; i0 < BT * nv_row; i0 += 256 * NB) {
+      u32x4_t tmp[NB];
+      stage_load(0, nv_row, i0, tmp);
+      stage_store(nv_row, i0, tmp);
+    }
     __syncthreads();
-    if (has_ln) {  // two-pass LayerNorm in place (eps 1e-5, biased variance), RPW independent rows per wavefront
-      float v[RPW][MAXV][E];
-      float mean[RPW], rstd[RPW];
-#pragma unroll
-      for (int rr = 0; rr < RPW; ++rr) {
-        const int b = wave + 4 * rr;
+    if (has_ln) {  // statistics of the raw rows (two-pass, eps 1e-5, biased variance); wave w owns streams w, w+4, ..
+      for (int b = wave; b < B; b += 4) {
+        float v[MAXV][E];
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
           const int vi = lane + i * 64;
-          if (vi < nv_row && b < BT) {
-            unpack16<T>(xs[b * xld + vi], v[rr][i]);
+          if (vi < nv_row) {
+            unpack16<T>(xs[b * xld + vi], v[i]);
 #pragma unroll
-            for (int e = 0; e < E; ++e) s += v[rr][i][e];
-          } else {
-#pragma unroll
-            for (int e = 0; e < E; ++e) v[rr][i][e] = 0.f;
+            for (int e = 0; e < E; ++e) s += v[i][e];
           }
         }
-        mean[rr] = s;
-      }
-#pragma unroll
-      for (int rr = 0; rr < RPW; ++rr) mean[rr] = wave_sum(mean[rr]) / (float)K;
-#pragma unroll
-      for (int rr = 0; rr < RPW; ++rr) {
+        const float mean = wave_sum(s) / (float)K;
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
           const int vi = lane + i * 64;
           if (vi < nv_row) {
 #pragma unroll
-            for (int e = 0; e < E; ++e) { const float c = v[rr][i][e] - mean[rr]; q += c * c; }
+            for (int e = 0; e < E; ++e) { const float c = v[i][e] - mean; q += c * c; }
           }
         }
-        rstd[rr] = q;
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)K + 1e-5f);
+        if (lane == 0) { stat[b][0] = mean; stat[b][1] = rstd; }
       }
-#pragma unroll
-      for (int rr = 0; rr < RPW; ++rr) rstd[rr] = 1.0f / sqrtf(wave_sum(rstd[rr]) / (float)K + 1e-5f);
-#pragma unroll
-      for (int rr = 0; rr < RPW; ++rr) {
-        const int b = wave + 4 * rr;
-#pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-          const int vi = lane + i * 64;
-          if (vi < nv_row && b < B) {
-            float gg[E], bb[E], o[E];
-            unpack16<T>(lg[i], gg);
-            unpack16<T>(lb[i], bb);
-#pragma unroll
-            for (int e = 0; e < E; ++e) o[e] = (v[rr][i][e] - mean[rr]) * rstd[rr] * gg[e] + bb[e];
-            xs[b * xld + vi] = pack16<T>(o);
-          }
-        }
-      }
-      __syncthreads();
     }
+  } else {
+    prime();
   }
 
-  const T* bias = reinterpret_cast<const T*>(a.bias);
-  const T* res = reinterpret_cast<const T*>(a.res);
   for (int grp = 0; grp < RG; ++grp) {
     if (grp > 0) {
       row0 = ((blockIdx.x * RG + grp) * 4 + wave) * R;
       prime();
+    }
+    float e_c[R], e_gw[R], e_res[R];
+    if (grp == 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) { e_c[r] = e_c0[r]; e_gw[r] = e_gw0[r]; e_res[r] = e_res0[r]; }
+    } else {
+      load_epi(row0, e_c, e_gw, e_res);
     }
     float acc[R][BT];
 #pragma unroll
@@ -248,17 +264,19 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
           const int vn = (it + D) * 64 + lane;
 #pragma unroll
           for (int r = 0; r < R; ++r)
-            wq[j][r] = (vn < nv_row) ? *reinterpret_cast<const u32x4_t*>(wrow[r] + (long long)vn * E) : u32x4_t{0u, 0u, 0u, 0u};
+            wq[j][r] = *reinterpret_cast<const u32x4_t*>(wrow[r] + (long long)min(vn, nv_row - 1) * E);
         }
       }
     }
 
-    // ---- reduce across the wavefront; lane b then owns stream b (one predicated load/store per row, not BT
-    //      serialised divergent branches: those cost ~0.7 us of L2 latency each) ----
+    // ---- reduce across the wavefront; lane b then owns stream b (one predicated store per row) ----
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int b = 0; b < BT; ++b) acc[r][b] = wave_sum(acc[r][b]);
+    if (has_ln && grp == 0) __syncthreads();  // statistics written by the owning wavefronts are visible
+    float mean = 0.f, rstd = 1.f;
+    if (has_ln && lane < B) { mean = stat[lane][0]; rstd = stat[lane][1]; }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int n = row0 + r;
@@ -267,15 +285,15 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
       for (int b = 0; b < BT; ++b) mine = (lane == b) ? acc[r][b] : mine;
       if (n < N && lane < B) {
         const int b = lane;
-        float v = mine + (bias ? (float)bias[n] : 0.f);
+        float v = has_ln ? rstd * (mine - mean * e_gw[r]) + e_c[r] : mine + e_c[r];
         if (a.gelu) v = gelu_exact(v);
-        if (res) v += (float)res[(long long)b * a.ldres + n];
+        v += e_res[r];
         if (a.y_f32) {
           a.y_f32[(long long)b * N + n] = v;
         } else if (a.kcache && n >= a.d_model) {
           const int seg = n / a.d_model;
           T* dst = reinterpret_cast<T*>(seg == 1 ? a.kcache : a.vcache);
-          dst[(long long)b * a.cache_bstride + (long long)a.stt->pos * a.d_model + (n - seg * a.d_model)] = (T)v;
+          dst[(long long)b * a.cache_bstride + (long long)cur_pos * a.d_model + (n - seg * a.d_model)] = (T)v;
         } else {
           reinterpret_cast<T*>(a.y)[(long long)b * a.ldy + n] = (T)v;
         }
@@ -289,13 +307,14 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
 // workgroup, K split over the NW wavefronts.  With 16 streams the activation block is exactly one
 // MFMA tile (v_mfma_f32_16x16x32_bf16: A = 16 weight rows x 32 k, B = 16 streams x 32 k), so each
 // 1-KiB weight fragment costs ONE matrix instruction and ONE 16-B activation fragment instead of
-// 16 LDS reads + 64 dot2 + a 96-shuffle wave reduction in the VALU formulation; the contraction
+// 16 LDS reads + 64 dot2 + a wave reduction per stream in the VALU formulation; the contraction
 // over k happens inside the MFMA and only NW partial 16x16 tiles are summed through LDS.
-// All weight fragments of a wavefront (<= SK_MAXS) are requested up front; LayerNorm'ed activations
-// come from LDS rows padded by one vector (conflict-free ds_read_b128), plain activations straight
-// from L2.  Deterministic: fixed summation order, no atomics.
+// All weight and activation fragments of a wavefront are requested up front (activations straight
+// from L2 - the residual stream is 40 KB); with the folded LayerNorm (above) the per-stream
+// (mean, rstd) are reduced by the wavefronts while those loads are in flight and meet the
+// accumulators at the one barrier the partial-tile reduction needs anyway.
+// Deterministic: fixed summation order, no atomics.
 // ---------------------------------------------------------------------------------------------
-constexpr int SK_MAXS = 10;
 
 template <typename T>
 __device__ __forceinline__ f32x4_t sk_mfma(const u32x4_t& w, const u32x4_t& x, f32x4_t acc);
@@ -313,132 +332,140 @@ __device__ __forceinline__ f32x4_t sk_mfma<float>(const u32x4_t& w, const u32x4_
   return acc;
 }
 
-template <typename T, int NW>
-__global__ __launch_bounds__(NW * 64) void skinny_mfma_kernel(GemvArgs a) {
+// SK_MAXS = weight/activation fragments a wavefront keeps in flight (5 covers K = 1280 in bf16 with 8 wavefronts)
+template <typename T, int NW, int SK_MAXS>
+__global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (SK_MAXS <= 5 ? 4 : 2))) void skinny_mfma_kernel(GemvArgs a) {
   constexpr int E = ElemTraits<T>::kPer16B;
-  constexpr int NT = NW * 64;
   constexpr int MAXV = (1280 / E + 63) / 64;
-  constexpr int RPW = (16 + NW - 1) / NW;  // LayerNorm rows per wavefront
+  constexpr int RPW = (16 + NW - 1) / NW;  // LayerNorm-statistics rows per wavefront
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ float stat[16][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, kq = lane >> 4;
-  const int RG = a.rg & 0xff;
+  const int RG = a.rg;
   const int K = a.K, N = a.N, B = a.B;
   const T* x = reinterpret_cast<const T*>(a.x);
   const T* W = reinterpret_cast<const T*>(a.W);
   const int nv_row = K / E;          // 16-B vectors per row
   const int S = nv_row / 4;          // 64-B steps per row
   const int s_lo = (int)((long long)wave * S / NW), s_hi = (int)((long long)(wave + 1) * S / NW);
-  const bool has_ln = a.ln_g != nullptr;
-  const int xld = nv_row + 1;        // padded LDS row stride (vectors)
-  float* red = reinterpret_cast<float*>(smem);                       // [NW][256]
-  u32x4_t* xs = reinterpret_cast<u32x4_t*>(smem + NW * 256 * 4);     // [16][xld] (LayerNorm case only)
+  const bool has_ln = a.ln_gw != nullptr;
+  float* red = reinterpret_cast<float*>(smem);  // [NW][256]
 
   int n0 = blockIdx.x * RG * 16;
   const T* wrow = W + (long long)min(n0 + fr, N - 1) * K;
-  u32x4_t wq[SK_MAXS];
+  const T* xrow = x + (long long)min(fr, B - 1) * a.ldx;  // B operand: 16 streams x 64 B per step, straight from L2
+  constexpr int XS = 5;  // activation fragments requested per sub-batch (L2-resident: short latency)
+  u32x4_t wq[SK_MAXS], xq[XS];
   auto load_w = [&](int s0) {
 #pragma unroll
     for (int i = 0; i < SK_MAXS; ++i) {
-      const int st = s0 + i;
-      wq[i] = (st < s_hi) ? *reinterpret_cast<const u32x4_t*>(wrow + (long long)(st * 4 + kq) * E) : u32x4_t{0u, 0u, 0u, 0u};
+      const int st = min(s0 + i, S - 1);  // unconditional (clamped to the row): conditional loads would each get their own wait
+      wq[i] = *reinterpret_cast<const u32x4_t*>(wrow + (long long)(st * 4 + kq) * E);
     }
   };
-  load_w(s_lo);
-
-  if (has_ln) {
-    const T* g = reinterpret_cast<const T*>(a.ln_g);
-    const T* be = reinterpret_cast<const T*>(a.ln_b);
-    u32x4_t lg[MAXV], lb[MAXV];
+  auto load_x = [&](int s0) {
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int vi = lane + i * 64;
-      lg[i] = (vi < nv_row) ? *reinterpret_cast<const u32x4_t*>(g + vi * E) : u32x4_t{0u, 0u, 0u, 0u};
-      lb[i] = (vi < nv_row) ? *reinterpret_cast<const u32x4_t*>(be + vi * E) : u32x4_t{0u, 0u, 0u, 0u};
+    for (int i = 0; i < XS; ++i) {
+      const int st = min(s0 + i, S - 1);
+      xq[i] = *reinterpret_cast<const u32x4_t*>(xrow + (long long)(st * 4 + kq) * E);
     }
-    // every wavefront normalises its own rows straight from global memory (rows >= B become zeros)
-#pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-      const int b = wave + NW * rr;
-      if (b < 16) {
-        float v[MAXV][E];
-        float sm = 0.f;
-#pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-          const int vi = lane + i * 64;
-          if (vi < nv_row && b < B) {
-            unpack16<T>(*reinterpret_cast<const u32x4_t*>(x + (long long)b * a.ldx + vi * E), v[i]);
-#pragma unroll
-            for (int e = 0; e < E; ++e) sm += v[i][e];
-          } else {
-#pragma unroll
-            for (int e = 0; e < E; ++e) v[i][e] = 0.f;
-          }
-        }
-        const bool dbg_nored = (a.rg & 0x100) != 0;  // timing experiments only
-        const float mean = dbg_nored ? sm : wave_sum(sm) / (float)K;
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-          const int vi = lane + i * 64;
-          if (vi < nv_row) {
-#pragma unroll
-            for (int e = 0; e < E; ++e) { const float c = v[i][e] - mean; q += c * c; }
-          }
-        }
-        const float rstd = dbg_nored ? q : 1.0f / sqrtf(wave_sum(q) / (float)K + 1e-5f);
-#pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-          const int vi = lane + i * 64;
-          if (vi < nv_row) {
-            float gg[E], bb[E], o[E];
-            unpack16<T>(lg[i], gg);
-            unpack16<T>(lb[i], bb);
-#pragma unroll
-            for (int e = 0; e < E; ++e) o[e] = (b < B) ? (v[i][e] - mean) * rstd * gg[e] + bb[e] : 0.f;
-            xs[b * xld + vi] = pack16<T>(o);
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-
-  const T* xrow = x + (long long)min(fr, B - 1) * a.ldx;  // plain case: B-operand rows straight from L2
+  };
+  // NB on ordering: the vector-memory counter retires loads in order, and a load inside a conditional block gets its own
+  // wait.  So every operand is requested unconditionally (clamped addresses, dummy pointers for absent operands), in the
+  // order it is needed: epilogue scalars and the (L2-resident) rows for the LayerNorm statistics FIRST, then the HBM
+  // weight fragments, then the activation fragments - the statistics are reduced while the weights are in flight.
   const T* bias = reinterpret_cast<const T*>(a.bias);
   const T* res = reinterpret_cast<const T*>(a.res);
+  const int ej = tid >> 4, ei = tid & 15;  // epilogue role of threads 0..255: stream ej, tile row ei
+  const float* gw_p = has_ln ? a.ln_gw : reinterpret_cast<const float*>(W);
+  const float* cb_p = has_ln ? a.ln_cb : reinterpret_cast<const float*>(W);
+  const T* bias_p = bias ? bias : W;
+  const T* res_p = res ? res : W;
+  const DecState* stt_p = a.stt ? a.stt : reinterpret_cast<const DecState*>(W);
+  const int cur_pos = stt_p->pos;  // only meaningful when a.stt != null (KV-cache scatter)
+  auto load_epi = [&](int n0_, float& e_c, float& e_gw, float& e_res) {
+    const int n = min(n0_ + ei, N - 1);
+    const float v_gw = gw_p[has_ln ? n : 0];
+    const float v_cb = cb_p[has_ln ? n : 0];
+    const float v_b = (float)bias_p[bias ? n : 0];
+    const float v_r = (float)res_p[res ? (long long)min(ej, B - 1) * a.ldres + n : 0];
+    e_gw = v_gw;
+    e_c = has_ln ? v_cb : (bias ? v_b : 0.f);
+    e_res = res ? v_r : 0.f;
+  };
+  float e_c0, e_gw0, e_res0;
+  load_epi(blockIdx.x * RG * 16, e_c0, e_gw0, e_res0);
+  u32x4_t srow[RPW][MAXV];
+  if (has_ln) {
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int b = min(wave + NW * rr, B - 1);
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        const int vi = min(lane + i * 64, nv_row - 1);
+        srow[rr][i] = *reinterpret_cast<const u32x4_t*>(x + (long long)b * a.ldx + vi * E);  // unconditional, clamped
+      }
+    }
+  }
+  load_w(s_lo);
+  load_x(s_lo);
+
+  if (has_ln) {  // (mean, rstd) of the raw rows: wavefront w owns streams w, w+NW (both in flight together)
+    float v[RPW][MAXV][E];
+    float sm[RPW], sq[RPW];
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      sm[rr] = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        unpack16<T>(srow[rr][i], v[rr][i]);
+        const bool on = (lane + i * 64) < nv_row;
+#pragma unroll
+        for (int e = 0; e < E; ++e) { v[rr][i][e] = on ? v[rr][i][e] : 0.f; sm[rr] += v[rr][i][e]; }
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) sm[rr] = wave_sum(sm[rr]) / (float)K;
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      sq[rr] = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        const bool on = (lane + i * 64) < nv_row;
+#pragma unroll
+        for (int e = 0; e < E; ++e) { const float c = on ? v[rr][i][e] - sm[rr] : 0.f; sq[rr] += c * c; }
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const float rstd = 1.0f / sqrtf(wave_sum(sq[rr]) / (float)K + 1e-5f);
+      const int b = wave + NW * rr;
+      if (lane == 0 && b < B) { stat[b][0] = sm[rr]; stat[b][1] = rstd; }
+    }
+  }
+
   for (int grp = 0; grp < RG; ++grp) {
+    float e_c = e_c0, e_gw = e_gw0, e_res = e_res0;
     if (grp > 0) {
       n0 = (blockIdx.x * RG + grp) * 16;
       if (n0 >= N) break;
       wrow = W + (long long)min(n0 + fr, N - 1) * K;
+      load_epi(n0, e_c, e_gw, e_res);
       load_w(s_lo);
+      load_x(s_lo);
     }
-    // epilogue operands of this thread's (stream, row) output are requested before the matrix work
-    const int ej = tid >> 4, ei = tid & 15;
     const bool e_on = tid < 256 && (n0 + ei) < N && ej < B;
-    float e_bias = 0.f, e_res = 0.f;
-    if (e_on) {
-      if (bias) e_bias = (float)bias[n0 + ei];
-      if (res) e_res = (float)res[(long long)ej * a.ldres + n0 + ei];
-    }
     f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
     for (int s0 = s_lo; s0 < s_hi; s0 += SK_MAXS) {
-      if (s0 > s_lo) load_w(s0);
-      u32x4_t xq[SK_MAXS];
+      if (s0 > s_lo) { load_w(s0); load_x(s0); }
 #pragma unroll
-      for (int i = 0; i < SK_MAXS; ++i) {
-        const int st = s0 + i;
-        if (st < s_hi) {
-          xq[i] = has_ln ? xs[fr * xld + st * 4 + kq]
-                         : *reinterpret_cast<const u32x4_t*>(xrow + (long long)(st * 4 + kq) * E);
-        } else {
-          xq[i] = u32x4_t{0u, 0u, 0u, 0u};
-        }
+      for (int h = 0; h < SK_MAXS / XS; ++h) {
+        if (h > 0) load_x(s0 + h * XS);
+#pragma unroll
+        for (int i = 0; i < XS; ++i)
+          if (s0 + h * XS + i < s_hi) acc = sk_mfma<T>(wq[h * XS + i], xq[i], acc);
       }
-#pragma unroll
-      for (int i = 0; i < SK_MAXS; ++i)
-        if (s0 + i < s_hi) acc = sk_mfma<T>(wq[i], xq[i], acc);
     }
     // D[i = weight row (lane>>4)*4 + reg][j = stream lane&15]
     if (grp > 0) __syncthreads();  // previous group's readers are done with `red`
@@ -446,13 +473,14 @@ __global__ __launch_bounds__(NW * 64) void skinny_mfma_kernel(GemvArgs a) {
     for (int r = 0; r < 4; ++r) red[wave * 256 + (kq * 4 + r) * 16 + fr] = acc[r];
     __syncthreads();
     if (tid < 256) {
-      const int j = tid >> 4, i = tid & 15;  // stream, row: 16 consecutive rows of one stream per 16 threads
+      const int j = ej, i = ei;  // stream, row: 16 consecutive rows of one stream per 16 threads
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) v += red[w * 256 + i * 16 + j];
       const int n = n0 + i;
       if (e_on) {
-        v += e_bias;
+        if (has_ln) v = stat[j][1] * (v - stat[j][0] * e_gw) + e_c;
+        else v += e_c;
         if (a.gelu) v = gelu_exact(v);
         v += e_res;
         if (a.y_f32) {
@@ -460,12 +488,36 @@ __global__ __launch_bounds__(NW * 64) void skinny_mfma_kernel(GemvArgs a) {
         } else if (a.kcache && n >= a.d_model) {
           const int seg = n / a.d_model;
           T* dst = reinterpret_cast<T*>(seg == 1 ? a.kcache : a.vcache);
-          dst[(long long)j * a.cache_bstride + (long long)a.stt->pos * a.d_model + (n - seg * a.d_model)] = (T)v;
+          dst[(long long)j * a.cache_bstride + (long long)cur_pos * a.d_model + (n - seg * a.d_model)] = (T)v;
         } else {
           reinterpret_cast<T*>(a.y)[(long long)j * a.ldy + n] = (T)v;
         }
       }
     }
+  }
+}
+
+// W[n,:] *= g (in place, rounded to T); gw[n] = sum_k g[k] W[n,k]; cb[n] = sum_k beta[k] W[n,k] + bias[n]   (one wave per row)
+template <typename T>
+__global__ __launch_bounds__(256) void fold_ln_kernel(T* __restrict__ W, const T* __restrict__ Wsrc, const T* __restrict__ g,
+                                                       const T* __restrict__ beta, const T* __restrict__ bias,
+                                                       float* __restrict__ gw, float* __restrict__ cb, int N, int K) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (n >= N) return;
+  float sg = 0.f, sb = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float w = (float)Wsrc[(long long)n * K + k];
+    const float gk = (float)g[k];
+    sg += gk * w;
+    sb += (float)beta[k] * w;
+    W[(long long)n * K + k] = (T)(gk * w);
+  }
+  sg = wave_sum(sg);
+  sb = wave_sum(sb);
+  if (lane == 0) {
+    gw[n] = sg;
+    cb[n] = sb + (bias ? (float)bias[n] : 0.f);
   }
 }
 
@@ -586,27 +638,23 @@ __device__ __forceinline__ float attend_block(const T* __restrict__ qptr, const 
 // back (one memory latency for the whole head), scores and probabilities stay in registers, two barriers.
 template <typename T, int NT, int U>
 __device__ __forceinline__ float attend_block_fused(const T* __restrict__ qptr, const T* __restrict__ kbase,
-                                                    const T* __restrict__ vbase, long long stride, int n_keys, float* sc,
-                                                    float* red, T* __restrict__ outp, bool want_probs) {
+                                                    const T* __restrict__ vbase, long long stride, int n_keys,
+                                                    int max_rows, float* sc, float* red, T* __restrict__ outp,
+                                                    bool want_probs) {
+  // `max_rows` (a launch constant) bounds the addresses so that the K/V requests do not depend on `n_keys`, which
+  // for the self-attention cache is itself loaded from device memory (DecState.pos): all 2U+1 loads leave at once.
   constexpr int KG = NT / 16;
   constexpr int NW = NT / 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kg = tid >> 4, dq = tid & 15;
-  float qv[4];
-  load4<T>(qptr + dq * 4, qv);
+  typedef __attribute__((ext_vector_type(4))) float f4;
   float kv[U][4], vv[U][4];
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    int t = u * KG + kg;
-    if (t >= n_keys) t = n_keys - 1;
-    load4<T>(kbase + (long long)t * stride + dq * 4, kv[u]);
-  }
+  for (int u = 0; u < U; ++u) load4<T>(kbase + (long long)min(u * KG + kg, max_rows - 1) * stride + dq * 4, kv[u]);
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    int t = u * KG + kg;
-    if (t >= n_keys) t = n_keys - 1;
-    load4<T>(vbase + (long long)t * stride + dq * 4, vv[u]);
-  }
+  for (int u = 0; u < U; ++u) load4<T>(vbase + (long long)min(u * KG + kg, max_rows - 1) * stride + dq * 4, vv[u]);
+  float qv[4];
+  load4<T>(qptr + dq * 4, qv);
   float sv[U];
   float m = -1.0e30f;
 #pragma unroll
@@ -661,18 +709,19 @@ __device__ __forceinline__ float attend_block_fused(const T* __restrict__ qptr, 
   return inv;
 }
 
-template <typename T>
+template <typename T, bool FUSED>
 __global__ __launch_bounds__(256) void dec_self_attn_kernel(const T* __restrict__ q, const T* __restrict__ kc,
                                                              const T* __restrict__ vc, long long cache_bstride,
-                                                             T* __restrict__ out, int H, const DecState* __restrict__ stt) {
+                                                             T* __restrict__ out, int H, int max_rows,
+                                                             const DecState* __restrict__ stt) {
   __shared__ float sc[512];
   __shared__ float red[16 + 4 * 64];
   const int h = blockIdx.x, b = blockIdx.y;
   const int d = H * 64;
   const int n_keys = stt->pos + 1;
-  if (n_keys <= 16 * 16)
+  if (FUSED)  // the host guarantees pos < max_rows <= 256 for this call (single round trip, loads do not wait for `pos`)
     attend_block_fused<T, 256, 16>(q + (long long)b * d + h * 64, kc + (long long)b * cache_bstride + h * 64,
-                                   vc + (long long)b * cache_bstride + h * 64, d, n_keys, sc, red,
+                                   vc + (long long)b * cache_bstride + h * 64, d, n_keys, max_rows, sc, red,
                                    out + (long long)b * d + h * 64, false);
   else
     attend_block<T, 256>(q + (long long)b * d + h * 64, kc + (long long)b * cache_bstride + h * 64,
@@ -694,7 +743,7 @@ __global__ __launch_bounds__(512) void dec_cross_attn_kernel(const T* __restrict
   const int slot = align_slot ? align_slot[h] : -1;
   float inv;
   if (Tlen <= 32 * 16)
-    inv = attend_block_fused<T, 512, 16>(q + (long long)b * d + h * 64, ck + base, cv + base, 64, Tlen, sc, red,
+    inv = attend_block_fused<T, 512, 16>(q + (long long)b * d + h * 64, ck + base, cv + base, 64, Tlen, Tlen, sc, red,
                                          out + (long long)b * d + h * 64, slot >= 0);
   else
     inv = attend_block<T, 512>(q + (long long)b * d + h * 64, ck + base, cv + base, 64, Tlen, sc, red,
@@ -886,10 +935,10 @@ template <typename T, int BT>
 static hipError_t gemv_r(const GemvArgs& a, hipStream_t st) {
   constexpr int E = ElemTraits<T>::kPer16B;
   constexpr int CV = GemvChunk<T, BT>::kVec;
-  if (a.K % E != 0 || (a.ln_g && a.K > 1280) || a.B > BT) return hipErrorInvalidValue;
+  if (a.K % E != 0 || (a.ln_gw && a.K > 1280) || a.B > BT) return hipErrorInvalidValue;
   const int nv_row = a.K / E;
   const bool chunked = nv_row > CV;
-  if (chunked && a.ln_g) return hipErrorInvalidValue;
+  if (chunked && a.ln_gw) return hipErrorInvalidValue;
   const size_t lds = (size_t)BT * (chunked ? CV : nv_row) * 16;
   // rows per wavefront: keep >= ~1000 wavefronts in flight when N allows it; very tall matrices (the tied
   // logits projection) additionally walk GEMV_RG row groups per workgroup so x is staged/normalised once per 128 rows
@@ -939,27 +988,27 @@ template <typename T, int NW>
 static hipError_t skinny_launch_nw(const GemvArgs& a0, hipStream_t st) {
   constexpr int E = ElemTraits<T>::kPer16B;
   GemvArgs a = a0;
-  static const int dbg_noln = env_int("TW_DBG_NOLN", 0);  // timing experiments only (wrong results)
-  if (dbg_noln) { a.ln_g = nullptr; a.ln_b = nullptr; }
-  if (a.K % (4 * E) != 0 || (a.ln_g && a.K > 1280) || a.B > 16) return hipErrorInvalidValue;
-  size_t lds = (size_t)NW * 256 * 4;
-  if (a.ln_g) lds += (size_t)16 * (a.K / E + 1) * 16;
+  if (a.K % (4 * E) != 0 || (a.ln_gw && a.K > 1280) || a.B > 16) return hipErrorInvalidValue;
+  const size_t lds = (size_t)NW * 256 * 4;
   const int tiles = (a.N + 15) / 16;
-  // tall matrices (the tied logits projection) walk several tiles per workgroup so that x is normalised once per group
-  static const int max_blocks = env_int("TW_SK_MAX_BLOCKS", 256);
+  // at most `max_blocks` workgroups: tall matrices (the tied logits projection) walk several tiles per workgroup
+  static const int max_blocks = env_int("TW_SK_MAX_BLOCKS", 512);
   a.rg = (tiles + max_blocks - 1) / max_blocks;
   if (a.rg < 1) a.rg = 1;
   dim3 grid((tiles + a.rg - 1) / a.rg);
-  static const int dbg_nored = env_int("TW_DBG_LN_NORED", 0);
-  if (dbg_nored) a.rg |= 0x100;
-  hipLaunchKernelGGL((skinny_mfma_kernel<T, NW>), grid, dim3(NW * 64), lds, st, a);
+  const int steps_per_wave = (a.K / E / 4 + NW - 1) / NW;
+  if (steps_per_wave <= 5)
+    hipLaunchKernelGGL((skinny_mfma_kernel<T, NW, 5>), grid, dim3(NW * 64), lds, st, a);
+  else
+    hipLaunchKernelGGL((skinny_mfma_kernel<T, NW, 10>), grid, dim3(NW * 64), lds, st, a);
   return hipGetLastError();
 }
 
 template <typename T>
 static hipError_t skinny_launch(const GemvArgs& a, hipStream_t st) {
-  static const int nw = env_int("TW_SK_NW", 8);
-  return nw == 4 ? skinny_launch_nw<T, 4>(a, st) : skinny_launch_nw<T, 8>(a, st);
+  static const int nw_big = env_int("TW_SK_NW_BIGK", 8);  // wavefronts per tile when K is long (fc2: K = 5120)
+  if (a.K >= 4096 && nw_big == 16) return skinny_launch_nw<T, 16>(a, st);
+  return skinny_launch_nw<T, 8>(a, st);
 }
 
 static int gemv_mfma_min_b() {  // streams from which the MFMA formulation is used (TW_SKINNY_MIN_B overrides, for A/B runs)
@@ -987,13 +1036,24 @@ hipError_t launch_gemv(int dtype, const GemvArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_dec_self_attn(int dtype, const void* q, const void* kc, const void* vc, long long cache_bstride,
-                                void* out, int B, int H, const DecState* stt, hipStream_t st) {
-  if (dtype == 1)
-    hipLaunchKernelGGL(dec_self_attn_kernel<bf16_t>, dim3(H, B), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)kc,
-                       (const bf16_t*)vc, cache_bstride, (bf16_t*)out, H, stt);
-  else
-    hipLaunchKernelGGL(dec_self_attn_kernel<float>, dim3(H, B), dim3(256), 0, st, (const float*)q, (const float*)kc,
-                       (const float*)vc, cache_bstride, (float*)out, H, stt);
+                                void* out, int B, int H, int key_bound, const DecState* stt, hipStream_t st) {
+  // key_bound: an upper bound of pos+1 for this call known on the host (prompt + max new tokens), also <= cache rows
+  const bool fused = key_bound <= 256;
+  if (dtype == 1) {
+    if (fused)
+      hipLaunchKernelGGL((dec_self_attn_kernel<bf16_t, true>), dim3(H, B), dim3(256), 0, st, (const bf16_t*)q,
+                         (const bf16_t*)kc, (const bf16_t*)vc, cache_bstride, (bf16_t*)out, H, key_bound, stt);
+    else
+      hipLaunchKernelGGL((dec_self_attn_kernel<bf16_t, false>), dim3(H, B), dim3(256), 0, st, (const bf16_t*)q,
+                         (const bf16_t*)kc, (const bf16_t*)vc, cache_bstride, (bf16_t*)out, H, key_bound, stt);
+  } else {
+    if (fused)
+      hipLaunchKernelGGL((dec_self_attn_kernel<float, true>), dim3(H, B), dim3(256), 0, st, (const float*)q,
+                         (const float*)kc, (const float*)vc, cache_bstride, (float*)out, H, key_bound, stt);
+    else
+      hipLaunchKernelGGL((dec_self_attn_kernel<float, false>), dim3(H, B), dim3(256), 0, st, (const float*)q,
+                         (const float*)kc, (const float*)vc, cache_bstride, (float*)out, H, key_bound, stt);
+  }
   return hipGetLastError();
 }
 
@@ -1020,5 +1080,17 @@ hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st) {
 
 hipError_t launch_advance(DecState* stt, hipStream_t st) {
   hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, stt);
+  return hipGetLastError();
+}
+
+hipError_t launch_fold_ln(int dtype, void* W, const void* Wsrc, const void* g, const void* beta, const void* bias, float* gw,
+                          float* cb, int N, int K, hipStream_t st) {
+  dim3 grid((N + 3) / 4);
+  if (dtype == 1)
+    hipLaunchKernelGGL(fold_ln_kernel<bf16_t>, grid, dim3(256), 0, st, (bf16_t*)W, (const bf16_t*)Wsrc, (const bf16_t*)g,
+                       (const bf16_t*)beta, (const bf16_t*)bias, gw, cb, N, K);
+  else
+    hipLaunchKernelGGL(fold_ln_kernel<float>, grid, dim3(256), 0, st, (float*)W, (const float*)Wsrc, (const float*)g,
+                       (const float*)beta, (const float*)bias, gw, cb, N, K);
   return hipGetLastError();
 }

@@ -126,7 +126,9 @@ hipError_t launch_embed(int dtype, const int* ids, const DecState* stt, const vo
 // y[b, n] = epi( LN?(x[b,:]) . W[n,:] + bias[n] )  for b < B <= 16.
 struct GemvArgs {
   const void* x; int ldx;        // [B, K] input (T)
-  const void* ln_g; const void* ln_b;  // fused pre-LayerNorm over K (null = none); requires K <= 1280
+  // folded pre-LayerNorm (see k_decode.hip): W already carries the gain, ln_gw[n] = sum_k g[k] W[n,k],
+  // ln_cb[n] = sum_k beta[k] W[n,k] + bias[n]  (float32, null = no LayerNorm); requires K <= 1280
+  const float* ln_gw; const float* ln_cb;
   const void* W; const void* bias;     // [N, K], [N]
   int N, K, B;
   int gelu;
@@ -138,10 +140,14 @@ struct GemvArgs {
   int rg;  // skinny path: 16-row tiles walked per workgroup (set by the launcher)
 };
 hipError_t launch_gemv(int dtype, const GemvArgs& a, hipStream_t st);
-hipError_t init_decode_kernels();  // once per process: dynamic-LDS caps of the gemv instantiations
+hipError_t init_decode_kernels();
+// weight preparation for the folded pre-LayerNorm: W <- Wsrc * g (may alias), gw, cb as above
+hipError_t launch_fold_ln(int dtype, void* W, const void* Wsrc, const void* g, const void* beta, const void* bias, float* gw,
+                          float* cb, int N, int K, hipStream_t st);  // once per process: dynamic-LDS caps of the gemv instantiations
 // self attention over the growing cache: q [B,d]; kc/vc [B][P][d] (batch stride cache_bstride); out [B,d]
+// key_bound: host-known upper bound of pos+1 for this call (<= cache rows); <= 256 selects the single-round-trip kernel
 hipError_t launch_dec_self_attn(int dtype, const void* q, const void* kc, const void* vc, long long cache_bstride,
-                                void* out, int B, int H, const DecState* stt, hipStream_t st);
+                                void* out, int B, int H, int key_bound, const DecState* stt, hipStream_t st);
 // cross attention over cached encoder K/V: ck/cv [B,H,T,64]; out [B,d]; align rows: for head h with
 // align_slot[h] >= 0 write softmax row to align[((b*Ha + slot)*P + pos)*T + t]
 hipError_t launch_dec_cross_attn(int dtype, const void* q, const void* ck, const void* cv, void* out, int B, int H,

@@ -1,0 +1,58 @@
+// Standalone probe of the decode projections: includes the product kernel source and replays a dependent chain of
+// launches from a hipGraph (like one decode step does), printing microseconds per launch per shape.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DTW_TIMING] tools/dbg/probe_gemv.hip -o tools/dbg/probe_gemv
+#include "../../thewhisper_amd/csrc/k_decode.hip"
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+  const size_t pool_bytes = 768ull << 20;
+  char* pool; CK(hipMalloc(&pool, pool_bytes)); CK(hipMemset(pool, 0x11, pool_bytes));
+  bf16_t *x, *y, *res, *bias, *g, *b; float* logits; float *gw, *cb;
+  CK(hipMalloc(&x, 16 * 5120 * 2)); CK(hipMalloc(&y, 16 * 5120 * 2)); CK(hipMalloc(&res, 16 * 5120 * 2));
+  CK(hipMalloc(&bias, 52000 * 2)); CK(hipMalloc(&g, 1280 * 2)); CK(hipMalloc(&b, 1280 * 2)); CK(hipMalloc(&logits, 16 * 52000 * 4)); CK(hipMalloc(&gw, 52000 * 4)); CK(hipMalloc(&cb, 52000 * 4)); CK(hipMemset(gw, 0, 52000 * 4)); CK(hipMemset(cb, 0, 52000 * 4));
+  CK(hipMemset(x, 0, 16 * 5120 * 2)); CK(hipMemset(res, 0, 16 * 5120 * 2)); CK(hipMemset(bias, 0, 52000 * 2));
+  CK(hipMemset(g, 0, 2560)); CK(hipMemset(b, 0, 2560));
+  DecState* stt; CK(hipMalloc(&stt, sizeof(DecState))); CK(hipMemset(stt, 0, sizeof(DecState)));
+  CK(init_decode_kernels());
+  hipStream_t st; CK(hipStreamCreate(&st));
+  struct Shape { const char* name; int N, K; bool ln, resid, gelu; };
+  const Shape shapes[] = {
+      {"o-proj  1280x1280      ", 1280, 1280, false, true, false},
+      {"q_c     1280x1280 LN   ", 1280, 1280, true, false, false},
+      {"qkv     3840x1280 LN   ", 3840, 1280, true, false, false},
+      {"fc1     5120x1280 LN G ", 5120, 1280, true, false, true},
+      {"fc2     1280x5120      ", 1280, 5120, false, true, false},
+  };
+  const int NL = 128;
+  for (int B : {1, 4, 16}) {
+    for (const Shape& s : shapes) {
+      const size_t wbytes = (size_t)s.N * s.K * 2;
+      hipGraph_t gr; hipGraphExec_t ge;
+      CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      for (int i = 0; i < NL; ++i) {
+        GemvArgs a{};
+        a.x = (i & 1) ? y : x; a.ldx = s.K; a.W = pool + ((size_t)i * wbytes) % (pool_bytes - wbytes); a.bias = bias;
+        a.N = s.N; a.K = s.K; a.B = B; a.gelu = s.gelu; a.y = (i & 1) ? x : y; a.ldy = s.N;
+        if (s.ln) { a.ln_gw = gw; a.ln_cb = cb; }
+        if (s.resid) { a.res = res; a.ldres = s.N; }
+        a.stt = stt;
+        CK(launch_gemv(1, a, st));
+      }
+      CK(hipStreamEndCapture(st, &gr));
+      CK(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+      CK(hipGraphLaunch(ge, st)); CK(hipStreamSynchronize(st));
+      hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      CK(hipEventRecord(e0, st));
+      const int R = 10;
+      for (int r = 0; r < R; ++r) CK(hipGraphLaunch(ge, st));
+      CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      const double us = ms * 1e3 / (R * NL);
+      printf("B=%2d %s: %6.2f us/launch  (%.2f TB/s of weights)\n", B, s.name, us, wbytes / us * 1e-6);
+      hipGraphExecDestroy(ge); hipGraphDestroy(gr);
+    }
+  }
+  return 0;
+}
