@@ -248,7 +248,7 @@ int tw_create(const tw_config* cfg, tw_ctx** out) {
   CALLOC(c->dec_pos, P * d * e, true);
   CALLOC(c->dec_ln_g, d * e, true);
   CALLOC(c->dec_ln_b, d * e, true);
-  CALLOC(c->logit_w, V * d * e, false);
+  CALLOC(c->logit_w, ((V + 15) / 16 * 16) * d * e, false);  // padded to whole 16-row tiles
   CALLOC(c->logit_gw, V * 4, true);
   CALLOC(c->logit_cb, V * 4, true);
   c->enc.resize(c->Le);
@@ -313,8 +313,9 @@ int tw_create(const tw_config* cfg, tw_ctx** out) {
   CALLOC(c->self_v, Ld * B * P * d * e, true);
   CALLOC(c->cross_k, Ld * B * T * d * e, false);
   CALLOC(c->cross_v, Ld * B * T * d * e, false);
-  CALLOC(c->dx0, B * d * e, true); CALLOC(c->dx1, B * d * e, true); CALLOC(c->dq, B * d * e, true);
-  CALLOC(c->datt, B * d * e, true); CALLOC(c->dh, B * F * e, true);
+  // per-token decoder activations that feed a projection are fragment-major and always 16 streams wide (tw_xt_index)
+  CALLOC(c->dx0, 16 * d * e, true); CALLOC(c->dx1, 16 * d * e, true); CALLOC(c->dq, B * d * e, true);
+  CALLOC(c->datt, 16 * d * e, true); CALLOC(c->dh, 16 * F * e, true);
   CALLOC(c->logits, B * V * 4, true);
   const size_t Ha = c->Ha > 0 ? c->Ha : 1;
   CALLOC(c->align, B * Ha * P * T * 4, true);
@@ -468,7 +469,36 @@ int tw_finalize_weights(tw_ctx* c, void* stream) {
   }
   HIPCHK(c, launch_fold_ln(c->dtype, c->logit_w, c->tok_emb, c->dec_ln_g, c->dec_ln_b, nullptr, c->logit_gw, c->logit_cb,
                            c->V, c->d, st));
-  HIPCHK(c, hipStreamSynchronize(st));
+  // decoder projections are consumed by launch_gemv in the fragment-major layout (k_decode.hip: tile_weights_kernel)
+  {
+    const size_t e = c->esz;
+    const size_t Vp = (size_t)(c->V + 15) / 16 * 16;
+    size_t mx = Vp * c->d;
+    if ((size_t)3 * c->d * c->d > mx) mx = (size_t)3 * c->d * c->d;
+    if ((size_t)c->ffn * c->d > mx) mx = (size_t)c->ffn * c->d;
+    void* scratch = nullptr;
+    HIPCHK(c, hipMalloc(&scratch, mx * e));
+    auto retile = [&](void* w, int N, int K) -> int {
+      HIPCHK(c, launch_tile_weights(c->dtype, w, scratch, N, K, st));
+      HIPCHK(c, hipMemcpyAsync(w, scratch, (size_t)((N + 15) / 16 * 16) * K * e, hipMemcpyDeviceToDevice, st));
+      return TW_OK;
+    };
+    int r = TW_OK;
+    for (int l = 0; l < c->Ld && r == TW_OK; ++l) {
+      LayerW& L = c->dec[l];
+      if ((r = retile(L.wqkv, 3 * c->d, c->d)) != TW_OK) break;
+      if ((r = retile(L.wo, c->d, c->d)) != TW_OK) break;
+      if ((r = retile(L.wq_c, c->d, c->d)) != TW_OK) break;
+      if ((r = retile(L.wo_c, c->d, c->d)) != TW_OK) break;
+      if ((r = retile(L.w1, c->ffn, c->d)) != TW_OK) break;
+      if ((r = retile(L.w2, c->d, c->ffn)) != TW_OK) break;
+    }
+    if (r == TW_OK) r = retile(c->logit_w, c->V, c->d);
+    hipError_t he = hipStreamSynchronize(st);
+    hipFree(scratch);
+    if (r != TW_OK) return r;
+    HIPCHK(c, he);
+  }
   c->finalized = true;
   return TW_OK;
 }

@@ -2,11 +2,11 @@
 // skinny GEMM  y[B<=16, N] = f(x[B, K]) . W[N, K]^T  whose cost is streaming W once from HBM
 // (1.6 GB per step for large-v3 in bf16), so these kernels are HBM-bound by construction:
 //
-//  * gemv_kernel: one wavefront owns R output rows for the FULL K (no split-K: deterministic sums,
-//    fused pre-LayerNorm / bias / GELU / residual / KV-cache scatter).  Lanes stride along K with
-//    16-byte loads (1 KiB contiguous per wave instruction); the <=16 activation vectors are staged
-//    once per workgroup in LDS (after the fused LayerNorm) and every weight vector is reused for
-//    all B streams with v_dot2c_f32_bf16 (bf16 mode) or FMAs (strict-f32 mode).
+//  * skinny_mfma_kernel (launch_gemv): the <=16 activation rows are exactly one MFMA operand tile, so one 16-row weight
+//    tile per workgroup is streamed ONCE (fragment-major layout prepared at load time: every wavefront request is 1 KiB
+//    contiguous) and contracted by v_mfma_f32_16x16x32_bf16 (f32 mode: 16x16x4_f32) for all streams at once; K is split
+//    over the wavefronts and summed in a fixed order through LDS (deterministic, no atomics).  Fused: folded
+//    pre-LayerNorm, bias, GELU, residual, KV-cache scatter, fp32 logits.
 //  * dec_self_attn / dec_cross_attn: single-query attention over the KV cache, one wavefront per
 //    (stream, head) [x4 for the 500..1500-key cross attention], lanes = 4 key groups x 16 dim
 //    quads, online softmax in registers, 16-lane shuffle dot products.  Cross attention also emits
@@ -18,6 +18,14 @@
 #include <cstdlib>
 
 namespace {
+
+// Probe builds (tools/dbg/probe_gemv.hip -DTW_PROBE_TS) stamp s_memrealtime at a few points of the projection kernels.
+#ifdef TW_PROBE_TS
+__device__ unsigned long long* g_probe_ts;
+#define TW_TS(k) do { if (threadIdx.x == 0) g_probe_ts[((size_t)cur_pos * 1024 + blockIdx.x) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define TW_TS(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ float row16_sum(float v) { return tw_row16_sum(v); }
 __device__ __forceinline__ float wave_sum(float v) { return tw_wave_sum(v); }
@@ -62,16 +70,6 @@ template <> __device__ __forceinline__ u32x4_t pack16<bf16_t>(const float* in) {
   return __builtin_bit_cast(u32x4_t, f);
 }
 
-constexpr int GEMV_LDS_BUDGET = 80 * 1024;  // activations staged per workgroup (2 workgroups / CU)
-constexpr int GEMV_D = 4;                    // weight vectors in flight per lane and row (register ring)
-constexpr int GEMV_RG = 8;                   // row groups per workgroup for very tall matrices (logits)
-
-template <typename T, int BT> struct GemvChunk {
-  static constexpr int E = ElemTraits<T>::kPer16B;
-  // largest K chunk (in 16-B vectors, multiple of 64) whose BT activation rows fit the LDS budget
-  static constexpr int kVec = (GEMV_LDS_BUDGET / (BT * 16) / 64) * 64;
-};
-
 // Folded pre-LayerNorm.  For y = LN(x) . W^T + bias with LN(x) = (x - mean) * rstd * g + beta:
 //     y[n] = rstd * ( x . W'[n]  -  mean * gW[n] )  +  cb[n],
 //     W'[n,k] = g[k] W[n,k],   gW[n] = sum_k g[k] W[n,k],   cb[n] = sum_k beta[k] W[n,k] + bias[n]
@@ -80,230 +78,9 @@ template <typename T, int BT> struct GemvChunk {
 // (mean, rstd) have to be known when the epilogue runs - they are computed off the critical path while the weight
 // loads are in flight.  No normalised copy of x is ever materialised.
 
-// y[b, n] = epi( x[b, :] . W[n, :] )   one wavefront = R rows x full K, lanes stride K by 16 B  (1..4 streams).
-// Latency structure (the decode step is a chain of ~260 such launches, so this matters as much as bandwidth): the
-// first GEMV_D weight vectors of every row and the epilogue operands are requested BEFORE the activations are staged,
-// the staging loads are issued in batches of 8 per thread, LayerNorm statistics are reduced between the staging
-// barrier and the (already in flight) weight data, and the wave reduction uses DPP/permlane steps only.
-template <typename T, int BT, int R, bool MULTI>
-__global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
-  constexpr int E = ElemTraits<T>::kPer16B;
-  constexpr int D = GEMV_D;
-  constexpr int CV = GemvChunk<T, BT>::kVec;  // vectors per chunk in chunked mode
-  constexpr int IPC = CV / 64;
-  constexpr int MAXV = (1280 / E + 63) / 64;  // LayerNorm rows have K <= 1280
-  constexpr int RG = MULTI ? GEMV_RG : 1;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ float stat[16][2];               // (mean, rstd) per stream
-  u32x4_t* xs = reinterpret_cast<u32x4_t*>(smem);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int K = a.K, N = a.N, B = a.B;
-  const T* x = reinterpret_cast<const T*>(a.x);
-  const T* W = reinterpret_cast<const T*>(a.W);
-  const int nv_row = K / E;
-  const int n_it = (nv_row + 63) / 64;
-  const bool chunked = nv_row > CV;
-  const int xld = chunked ? CV : nv_row;  // LDS row stride in vectors
-  const bool has_ln = a.ln_gw != nullptr;
-
-  int row0 = ((blockIdx.x * RG) * 4 + wave) * R;
-  const T* wrow[R];
-  u32x4_t wq[D][R];
-  auto prime = [&]() {
-#pragma unroll
-    for (int r = 0; r < R; ++r) wrow[r] = W + (long long)min(row0 + r, N - 1) * K;
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-      const int vi = j * 64 + lane;
-#pragma unroll
-      for (int r = 0; r < R; ++r)  // unconditional (clamped): lanes past the row end re-read the last vector, unused
-        wq[j][r] = *reinterpret_cast<const u32x4_t*>(wrow[r] + (long long)min(vi, nv_row - 1) * E);
-    }
-  };
-  // NB on ordering: the vector-memory counter retires loads IN ORDER and a load inside a conditional block gets its own
-  // wait, so every operand is requested unconditionally (clamped addresses, dummy pointers for absent operands) and in
-  // the order it is needed: epilogue scalars, then the activation staging loads, and only then the HBM weight prefetch
-  // (otherwise the LDS staging store would have to wait for the whole weight prefetch as well).
-  const T* bias = reinterpret_cast<const T*>(a.bias);
-  const T* res = reinterpret_cast<const T*>(a.res);
-  const float* gw_p = has_ln ? a.ln_gw : reinterpret_cast<const float*>(W);
-  const float* cb_p = has_ln ? a.ln_cb : reinterpret_cast<const float*>(W);
-  const T* bias_p = bias ? bias : W;
-  const T* res_p = res ? res : W;
-  const DecState* stt_p = a.stt ? a.stt : reinterpret_cast<const DecState*>(W);
-  const int cur_pos = stt_p->pos;  // only meaningful when a.stt != null (KV-cache scatter)
-  auto load_epi = [&](int row0_, float (&e_c)[R], float (&e_gw)[R], float (&e_res)[R]) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int n = min(row0_ + r, N - 1);
-      const float v_gw = gw_p[has_ln ? n : 0];
-      const float v_cb = cb_p[has_ln ? n : 0];
-      const float v_b = (float)bias_p[bias ? n : 0];
-      const float v_r = (float)res_p[res ? (long long)min(lane, B - 1) * a.ldres + n : 0];
-      e_gw[r] = v_gw;
-      e_c[r] = has_ln ? v_cb : (bias ? v_b : 0.f);
-      e_res[r] = res ? v_r : 0.f;
-    }
-  };
-  float e_c0[R], e_gw0[R], e_res0[R];
-  load_epi(row0, e_c0, e_gw0, e_res0);
-  // stage `cv` vectors per activation row starting at vector `cbase`; loads issued 8 per thread at a time
-  constexpr int NB = BT <= 4 ? 4 : 8;  // staging loads per thread and batch (one batch covers K <= 8192/BT... see launcher)
-  auto stage_load = [&](int cbase, int cv, int i0, u32x4_t (&tmp)[NB]) {
-    const int total = BT * cv;
-#pragma unroll
-    for (int u = 0; u < NB; ++u) {
-      const int i = i0 + u * 256;
-      const int b = min(i / cv, BT - 1), vi = i - (i / cv) * cv;
-      const bool on = (i < total) && (i / cv) < B;
-      const T* src = x + (long long)min(b, B - 1) * a.ldx + (long long)(cbase + vi) * E;
-      const u32x4_t v = *reinterpret_cast<const u32x4_t*>(src);  // unconditional (clamped) so the loads batch
-      tmp[u] = on ? v : u32x4_t{0u, 0u, 0u, 0u};
-    }
-  };
-  auto stage_store = [&](int cv, int i0, const u32x4_t (&tmp)[NB]) {
-    const int total = BT * cv;
-#pragma unroll
-    for (int u = 0; u < NB; ++u) {
-      const int i = i0 + u * 256;
-      if (i < total) { const int b = i / cv, vi = i - b * cv; xs[b * xld + vi] = tmp[u]; }
-    }
-  };
-  auto stage = [&](int cbase, int cv) {
-    const int total = BT * cv;
-    for (int i0 = tid; i0 < total; i0 += 256 * NB) {
-      u32x4_t tmp[NB];
-      stage_load(cbase, cv, i0, tmp);
-      stage_store(cv, i0, tmp);
-    }
-  };
-
-  if (!chunked) {
-    u32x4_t first[NB];
-    stage_load(0, nv_row, tid, first);   // first (usually only) staging batch: requested before the weights
-    prime();
-    stage_store(nv_row, tid, first);
-    for (int i0 = tid + 256 * NB; i0 < BT * nv_row; i0 += 256 * NB) {
-      u32x4_t tmp[NB];
-      stage_load(0, nv_row, i0, tmp);
-      stage_store(nv_row, i0, tmp);
-    }
-    __syncthreads();
-    if (has_ln) {  // statistics of the raw rows (two-pass, eps 1e-5, biased variance); wave w owns streams w, w+4, ..
-      for (int b = wave; b < B; b += 4) {
-        float v[MAXV][E];
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-          const int vi = lane + i * 64;
-          if (vi < nv_row) {
-            unpack16<T>(xs[b * xld + vi], v[i]);
-#pragma unroll
-            for (int e = 0; e < E; ++e) s += v[i][e];
-          }
-        }
-        const float mean = wave_sum(s) / (float)K;
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-          const int vi = lane + i * 64;
-          if (vi < nv_row) {
-#pragma unroll
-            for (int e = 0; e < E; ++e) { const float c = v[i][e] - mean; q += c * c; }
-          }
-        }
-        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)K + 1e-5f);
-        if (lane == 0) { stat[b][0] = mean; stat[b][1] = rstd; }
-      }
-    }
-  } else {
-    prime();
-  }
-
-  for (int grp = 0; grp < RG; ++grp) {
-    if (grp > 0) {
-      row0 = ((blockIdx.x * RG + grp) * 4 + wave) * R;
-      prime();
-    }
-    float e_c[R], e_gw[R], e_res[R];
-    if (grp == 0) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) { e_c[r] = e_c0[r]; e_gw[r] = e_gw0[r]; e_res[r] = e_res0[r]; }
-    } else {
-      load_epi(row0, e_c, e_gw, e_res);
-    }
-    float acc[R][BT];
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-      for (int b = 0; b < BT; ++b) acc[r][b] = 0.f;
-
-    for (int it0 = 0; it0 < n_it; it0 += D) {
-#pragma unroll
-      for (int j = 0; j < D; ++j) {
-        const int it = it0 + j;
-        if (it < n_it) {
-          int cbase = 0;
-          if (chunked) {
-            cbase = (it / IPC) * CV;
-            if (it % IPC == 0) {
-              if (it > 0) __syncthreads();
-              stage(cbase, min(CV, nv_row - cbase));
-              __syncthreads();
-            }
-          }
-          const int vi = it * 64 + lane;
-          if (vi < nv_row) {
-#pragma unroll
-            for (int b = 0; b < BT; ++b) {
-              const u32x4_t xv = xs[b * xld + (vi - cbase)];
-#pragma unroll
-              for (int r = 0; r < R; ++r) acc[r][b] = dot16<T>(wq[j][r], xv, acc[r][b]);
-            }
-          }
-          const int vn = (it + D) * 64 + lane;
-#pragma unroll
-          for (int r = 0; r < R; ++r)
-            wq[j][r] = *reinterpret_cast<const u32x4_t*>(wrow[r] + (long long)min(vn, nv_row - 1) * E);
-        }
-      }
-    }
-
-    // ---- reduce across the wavefront; lane b then owns stream b (one predicated store per row) ----
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-      for (int b = 0; b < BT; ++b) acc[r][b] = wave_sum(acc[r][b]);
-    if (has_ln && grp == 0) __syncthreads();  // statistics written by the owning wavefronts are visible
-    float mean = 0.f, rstd = 1.f;
-    if (has_ln && lane < B) { mean = stat[lane][0]; rstd = stat[lane][1]; }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int n = row0 + r;
-      float mine = 0.f;
-#pragma unroll
-      for (int b = 0; b < BT; ++b) mine = (lane == b) ? acc[r][b] : mine;
-      if (n < N && lane < B) {
-        const int b = lane;
-        float v = has_ln ? rstd * (mine - mean * e_gw[r]) + e_c[r] : mine + e_c[r];
-        if (a.gelu) v = gelu_exact(v);
-        v += e_res[r];
-        if (a.y_f32) {
-          a.y_f32[(long long)b * N + n] = v;
-        } else if (a.kcache && n >= a.d_model) {
-          const int seg = n / a.d_model;
-          T* dst = reinterpret_cast<T*>(seg == 1 ? a.kcache : a.vcache);
-          dst[(long long)b * a.cache_bstride + (long long)cur_pos * a.d_model + (n - seg * a.d_model)] = (T)v;
-        } else {
-          reinterpret_cast<T*>(a.y)[(long long)b * a.ldy + n] = (T)v;
-        }
-      }
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
-// Skinny MFMA GEMM for 5..16 concurrent streams:  y[b, n0..n0+15] for one 16-row weight tile per
+// Skinny MFMA GEMM for 1..16 concurrent streams:  y[b, n0..n0+15] for one 16-row weight tile per
 // workgroup, K split over the NW wavefronts.  With 16 streams the activation block is exactly one
 // MFMA tile (v_mfma_f32_16x16x32_bf16: A = 16 weight rows x 32 k, B = 16 streams x 32 k), so each
 // 1-KiB weight fragment costs ONE matrix instruction and ONE 16-B activation fragment instead of
@@ -332,169 +109,225 @@ __device__ __forceinline__ f32x4_t sk_mfma<float>(const u32x4_t& w, const u32x4_
   return acc;
 }
 
+// Epilogue flavours (compile-time: a runtime-uniform branch around a load makes hipcc wait for EVERY outstanding load at
+// the join, which serialises the whole prologue - see the ordering note below).
+enum : int { SK_STORE = 0, SK_RES = 1, SK_GELU = 2, SK_KV = 3, SK_F32 = 4 };
+
+template <typename T>
+__device__ __forceinline__ u32x4_t sk_load_w(const T* p) {  // weights are read exactly once per step: non-temporal
+  return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+}
+
+// (sum, sum of squares) of the 16 bytes of one activation fragment, accumulated per lane
+template <typename T> __device__ __forceinline__ void sk_stats(const u32x4_t& v, float& s, float& ss);
+template <> __device__ __forceinline__ void sk_stats<bf16_t>(const u32x4_t& v, float& s, float& ss) {
+  const bf16x8_t a = __builtin_bit_cast(bf16x8_t, v);
+  const bf16x2_t one = {(bf16_t)1.0f, (bf16_t)1.0f};
+  // named pairs, not a loop over v[i]: see dot16 above
+  const bf16x2_t p0 = __builtin_shufflevector(a, a, 0, 1), p1 = __builtin_shufflevector(a, a, 2, 3);
+  const bf16x2_t p2 = __builtin_shufflevector(a, a, 4, 5), p3 = __builtin_shufflevector(a, a, 6, 7);
+  s = __builtin_amdgcn_fdot2_f32_bf16(p0, one, s, false);
+  ss = __builtin_amdgcn_fdot2_f32_bf16(p0, p0, ss, false);
+  s = __builtin_amdgcn_fdot2_f32_bf16(p1, one, s, false);
+  ss = __builtin_amdgcn_fdot2_f32_bf16(p1, p1, ss, false);
+  s = __builtin_amdgcn_fdot2_f32_bf16(p2, one, s, false);
+  ss = __builtin_amdgcn_fdot2_f32_bf16(p2, p2, ss, false);
+  s = __builtin_amdgcn_fdot2_f32_bf16(p3, one, s, false);
+  ss = __builtin_amdgcn_fdot2_f32_bf16(p3, p3, ss, false);
+}
+template <> __device__ __forceinline__ void sk_stats<float>(const u32x4_t& v, float& s, float& ss) {
+  const f32x4_t a = __builtin_bit_cast(f32x4_t, v);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { s += a[i]; ss = fmaf(a[i], a[i], ss); }
+}
+
 // SK_MAXS = weight/activation fragments a wavefront keeps in flight (5 covers K = 1280 in bf16 with 8 wavefronts)
-template <typename T, int NW, int SK_MAXS>
+// LN      = folded pre-LayerNorm (ln_gw / ln_cb given), EPI = epilogue flavour, MULTI = several 16-row tiles per
+//           workgroup (tall matrices: the tied logits projection), next tile prefetched behind the current reduction.
+// Activations (x, the residual operand, and the outputs of SK_RES / SK_GELU) live in the fragment-major "xt" layout of
+// tw_common.h (tw_xt_index): like the weights, every wavefront request is then 1 KiB contiguous.  The LayerNorm
+// statistics come from the activation fragments the wavefront holds anyway (per-lane sum / sum of squares with
+// v_dot2, folded over the 4 k-groups by two lane swaps, over the wavefronts in the epilogue through LDS): no extra
+// loads and ~60 instead of ~500 VALU instructions on the critical path (at 4 cycles per wave64 VALU op that was 1 us).
+// Ordering rules this kernel follows (measured with tools/dbg/probe_gemv.hip, stamps of s_memrealtime):
+//  * all kernel arguments are pinned in SGPRs by one asm statement: one batch of scalar loads, one wait;
+//  * vmcnt retires loads IN ORDER, so operands are requested in the order they are consumed: the (L2-resident)
+//    activation fragments, then the HBM weight fragments; sched_barriers keep hipcc from reordering the groups or
+//    hoisting arithmetic between them;
+//  * no load sits inside a conditional block (clamped addresses, zero-selected operands instead): at the join of a
+//    runtime-uniform branch around a load hipcc waits for EVERY outstanding load.
+template <typename T, int NW, int SK_MAXS, bool LN, int EPI, bool MULTI>
 __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (SK_MAXS <= 5 ? 4 : 2))) void skinny_mfma_kernel(GemvArgs a) {
   constexpr int E = ElemTraits<T>::kPer16B;
-  constexpr int MAXV = (1280 / E + 63) / 64;
-  constexpr int RPW = (16 + NW - 1) / NW;  // LayerNorm-statistics rows per wavefront
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ float stat[16][2];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int fr = lane & 15, kq = lane >> 4;
-  const int RG = a.rg;
-  const int K = a.K, N = a.N, B = a.B;
+  __shared__ float pstat[NW][16][2];  // per wavefront and stream: (sum, sum of squares) over the wavefront's K slice
   const T* x = reinterpret_cast<const T*>(a.x);
   const T* W = reinterpret_cast<const T*>(a.W);
-  const int nv_row = K / E;          // 16-B vectors per row
-  const int S = nv_row / 4;          // 64-B steps per row
-  const int s_lo = (int)((long long)wave * S / NW), s_hi = (int)((long long)(wave + 1) * S / NW);
-  const bool has_ln = a.ln_gw != nullptr;
-  float* red = reinterpret_cast<float*>(smem);  // [NW][256]
-
-  int n0 = blockIdx.x * RG * 16;
-  const T* wrow = W + (long long)min(n0 + fr, N - 1) * K;
-  const T* xrow = x + (long long)min(fr, B - 1) * a.ldx;  // B operand: 16 streams x 64 B per step, straight from L2
-  constexpr int XS = 5;  // activation fragments requested per sub-batch (L2-resident: short latency)
-  u32x4_t wq[SK_MAXS], xq[XS];
-  auto load_w = [&](int s0) {
-#pragma unroll
-    for (int i = 0; i < SK_MAXS; ++i) {
-      const int st = min(s0 + i, S - 1);  // unconditional (clamped to the row): conditional loads would each get their own wait
-      wq[i] = *reinterpret_cast<const u32x4_t*>(wrow + (long long)(st * 4 + kq) * E);
-    }
-  };
-  auto load_x = [&](int s0) {
-#pragma unroll
-    for (int i = 0; i < XS; ++i) {
-      const int st = min(s0 + i, S - 1);
-      xq[i] = *reinterpret_cast<const u32x4_t*>(xrow + (long long)(st * 4 + kq) * E);
-    }
-  };
-  // NB on ordering: the vector-memory counter retires loads in order, and a load inside a conditional block gets its own
-  // wait.  So every operand is requested unconditionally (clamped addresses, dummy pointers for absent operands), in the
-  // order it is needed: epilogue scalars and the (L2-resident) rows for the LayerNorm statistics FIRST, then the HBM
-  // weight fragments, then the activation fragments - the statistics are reduced while the weights are in flight.
   const T* bias = reinterpret_cast<const T*>(a.bias);
   const T* res = reinterpret_cast<const T*>(a.res);
-  const int ej = tid >> 4, ei = tid & 15;  // epilogue role of threads 0..255: stream ej, tile row ei
-  const float* gw_p = has_ln ? a.ln_gw : reinterpret_cast<const float*>(W);
-  const float* cb_p = has_ln ? a.ln_cb : reinterpret_cast<const float*>(W);
-  const T* bias_p = bias ? bias : W;
-  const T* res_p = res ? res : W;
-  const DecState* stt_p = a.stt ? a.stt : reinterpret_cast<const DecState*>(W);
-  const int cur_pos = stt_p->pos;  // only meaningful when a.stt != null (KV-cache scatter)
-  auto load_epi = [&](int n0_, float& e_c, float& e_gw, float& e_res) {
-    const int n = min(n0_ + ei, N - 1);
-    const float v_gw = gw_p[has_ln ? n : 0];
-    const float v_cb = cb_p[has_ln ? n : 0];
-    const float v_b = (float)bias_p[bias ? n : 0];
-    const float v_r = (float)res_p[res ? (long long)min(ej, B - 1) * a.ldres + n : 0];
-    e_gw = v_gw;
-    e_c = has_ln ? v_cb : (bias ? v_b : 0.f);
-    e_res = res ? v_r : 0.f;
+  const float* gw_p = a.ln_gw;
+  const float* cb_p = a.ln_cb;
+  const int K = a.K, N = a.N, B = a.B, ldy = a.ldy, RG = a.rg, d_model = a.d_model;
+  const long long cache_bstride = a.cache_bstride;
+  T* y = reinterpret_cast<T*>(a.y);
+  float* y_f32 = a.y_f32;
+  T* kcache = reinterpret_cast<T*>(a.kcache);
+  T* vcache = reinterpret_cast<T*>(a.vcache);
+  const DecState* stt = a.stt;
+  asm volatile("" ::"s"(x), "s"(W), "s"(bias), "s"(res), "s"(gw_p), "s"(cb_p), "s"(K), "s"(N), "s"(B), "s"(a.gelu), "s"(ldy),
+               "s"(RG), "s"(d_model), "s"(cache_bstride), "s"(y), "s"(y_f32), "s"(kcache), "s"(vcache), "s"(stt));
+  int cur_pos = 0;
+#ifdef TW_PROBE_TS
+  cur_pos = stt->pos;
+#else
+  if (EPI == SK_KV) cur_pos = stt->pos;
+#endif
+  TW_TS(0);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, kq = lane >> 4;
+  const int S = K / (4 * E);  // 64-B steps per row
+  const int s_lo = (int)((long long)wave * S / NW), s_hi = (int)((long long)(wave + 1) * S / NW);
+  float* red = reinterpret_cast<float*>(smem);  // [NW][256]
+  const int n_tiles = (N + 15) / 16;
+  const int tile0 = blockIdx.x * RG;
+  const int ej = (tid >> 4) & 15, ei = tid & 15;  // epilogue role of threads 0..255: stream ej, tile row ei
+
+  u32x4_t wq[SK_MAXS], xq[SK_MAXS];
+  float e_c = 0.f, e_gw = 0.f, e_res = 0.f;
+  // --- request helpers: all unconditional, addresses clamped into the matrix ---
+  auto load_epi = [&](int tile, float& c, float& g, float& r) {
+    const int n = min(tile * 16 + ei, N - 1);
+    if (LN) {
+      g = gw_p[n];
+      c = cb_p[n];
+    } else {
+      const float v = (float)(bias ? bias : W)[bias ? n : 0];
+      c = bias ? v : 0.f;
+    }
+    if (EPI == SK_RES) r = (float)res[tw_xt_index<T>(ej, n)];
   };
-  float e_c0, e_gw0, e_res0;
-  load_epi(blockIdx.x * RG * 16, e_c0, e_gw0, e_res0);
-  u32x4_t srow[RPW][MAXV];
-  if (has_ln) {
+  auto load_w = [&](int tile, int s0) {  // fragment-major weights: 1 KiB contiguous per wavefront request
+    const T* wt = W + ((long long)min(tile, n_tiles - 1) * S * 64 + lane) * E;
 #pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-      const int b = min(wave + NW * rr, B - 1);
+    for (int i = 0; i < SK_MAXS; ++i) wq[i] = sk_load_w<T>(wt + (long long)min(s0 + i, S - 1) * (64 * E));
+  };
+  auto load_x = [&](int s0) {            // fragment-major activations: lane (stream fr, k-group kq) of step s
+    const T* xt = x + (long long)lane * E;
 #pragma unroll
-      for (int i = 0; i < MAXV; ++i) {
-        const int vi = min(lane + i * 64, nv_row - 1);
-        srow[rr][i] = *reinterpret_cast<const u32x4_t*>(x + (long long)b * a.ldx + vi * E);  // unconditional, clamped
-      }
-    }
-  }
-  load_w(s_lo);
+    for (int i = 0; i < SK_MAXS; ++i) xq[i] = *reinterpret_cast<const u32x4_t*>(xt + (long long)min(s0 + i, S - 1) * (64 * E));
+  };
+
   load_x(s_lo);
+  __builtin_amdgcn_sched_barrier(0);  // request order = consumption order: hipcc must not reorder the groups
+  load_w(tile0, s_lo);
+  load_epi(tile0, e_c, e_gw, e_res);
+  __builtin_amdgcn_sched_barrier(0);  // ... nor hoist arithmetic between the requests
+  TW_TS(1);
 
-  if (has_ln) {  // (mean, rstd) of the raw rows: wavefront w owns streams w, w+NW (both in flight together)
-    float v[RPW][MAXV][E];
-    float sm[RPW], sq[RPW];
-#pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-      sm[rr] = 0.f;
-#pragma unroll
-      for (int i = 0; i < MAXV; ++i) {
-        unpack16<T>(srow[rr][i], v[rr][i]);
-        const bool on = (lane + i * 64) < nv_row;
-#pragma unroll
-        for (int e = 0; e < E; ++e) { v[rr][i][e] = on ? v[rr][i][e] : 0.f; sm[rr] += v[rr][i][e]; }
-      }
-    }
-#pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) sm[rr] = wave_sum(sm[rr]) / (float)K;
-#pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-      sq[rr] = 0.f;
-#pragma unroll
-      for (int i = 0; i < MAXV; ++i) {
-        const bool on = (lane + i * 64) < nv_row;
-#pragma unroll
-        for (int e = 0; e < E; ++e) { const float c = on ? v[rr][i][e] - sm[rr] : 0.f; sq[rr] += c * c; }
-      }
-    }
-#pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-      const float rstd = 1.0f / sqrtf(wave_sum(sq[rr]) / (float)K + 1e-5f);
-      const int b = wave + NW * rr;
-      if (lane == 0 && b < B) { stat[b][0] = sm[rr]; stat[b][1] = rstd; }
-    }
-  }
-
-  for (int grp = 0; grp < RG; ++grp) {
-    float e_c = e_c0, e_gw = e_gw0, e_res = e_res0;
-    if (grp > 0) {
-      n0 = (blockIdx.x * RG + grp) * 16;
-      if (n0 >= N) break;
-      wrow = W + (long long)min(n0 + fr, N - 1) * K;
-      load_epi(n0, e_c, e_gw, e_res);
-      load_w(s_lo);
-      load_x(s_lo);
-    }
-    const bool e_on = tid < 256 && (n0 + ei) < N && ej < B;
+  float mean = 0.f, rstd = 1.f;
+  const int n_grp = MULTI ? RG : 1;
+  for (int grp = 0; grp < n_grp; ++grp) {
+    const int tile = tile0 + grp;
     f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    for (int s0 = s_lo; s0 < s_hi; s0 += SK_MAXS) {
-      if (s0 > s_lo) { load_w(s0); load_x(s0); }
+    float ps = 0.f, pss = 0.f;
+    auto mfma_round = [&](int s0) {
 #pragma unroll
-      for (int h = 0; h < SK_MAXS / XS; ++h) {
-        if (h > 0) load_x(s0 + h * XS);
-#pragma unroll
-        for (int i = 0; i < XS; ++i)
-          if (s0 + h * XS + i < s_hi) acc = sk_mfma<T>(wq[h * XS + i], xq[i], acc);
+      for (int i = 0; i < SK_MAXS; ++i) {
+        const bool on = s0 + i < s_hi;  // wave-uniform: steps past this wavefront's K slice contribute zero
+        const u32x4_t zero = u32x4_t{0u, 0u, 0u, 0u};
+        const u32x4_t xv = on ? xq[i] : zero;
+        if (LN && (!MULTI || grp == 0)) sk_stats<T>(xv, ps, pss);
+        acc = sk_mfma<T>(on ? wq[i] : zero, xv, acc);
       }
+    };
+    mfma_round(s_lo);  // operands already in flight
+    for (int s0 = s_lo + SK_MAXS; s0 < s_hi; s0 += SK_MAXS) {  // K longer than one round of fragments
+      load_x(s0);
+      load_w(tile, s0);
+      mfma_round(s0);
     }
+    // operands of the tile after this one are requested now, behind the reduction and the epilogue of the current one
+    // (MULTI is only launched with a single round of fragments per tile, so the activation fragments stay in registers)
+    float n_c = 0.f, n_gw = 0.f, n_res = 0.f;
+    if (MULTI) {
+      const int nt = min(tile + 1, n_tiles - 1);
+      load_w(nt, s_lo);
+      load_epi(nt, n_c, n_gw, n_res);
+    }
+    TW_TS(2);
     // D[i = weight row (lane>>4)*4 + reg][j = stream lane&15]
-    if (grp > 0) __syncthreads();  // previous group's readers are done with `red`
+    if (MULTI && grp > 0) __syncthreads();  // previous tile's readers are done with `red`
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave * 256 + (kq * 4 + r) * 16 + fr] = acc[r];
+    if (LN && (!MULTI || grp == 0)) {
+      ps = tw_xor32_sum(tw_xor16_sum(ps));
+      pss = tw_xor32_sum(tw_xor16_sum(pss));
+      if (lane < 16) { pstat[wave][fr][0] = ps; pstat[wave][fr][1] = pss; }
+    }
     __syncthreads();
+    TW_TS(3);
     if (tid < 256) {
       const int j = ej, i = ei;  // stream, row: 16 consecutive rows of one stream per 16 threads
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) v += red[w * 256 + i * 16 + j];
-      const int n = n0 + i;
-      if (e_on) {
-        if (has_ln) v = stat[j][1] * (v - stat[j][0] * e_gw) + e_c;
-        else v += e_c;
-        if (a.gelu) v = gelu_exact(v);
-        v += e_res;
-        if (a.y_f32) {
-          a.y_f32[(long long)j * N + n] = v;
-        } else if (a.kcache && n >= a.d_model) {
-          const int seg = n / a.d_model;
-          T* dst = reinterpret_cast<T*>(seg == 1 ? a.kcache : a.vcache);
-          dst[(long long)j * a.cache_bstride + (long long)cur_pos * a.d_model + (n - seg * a.d_model)] = (T)v;
+      const int n = tile * 16 + i;
+      if (LN) {
+        if (!MULTI || grp == 0) {
+          float sx = 0.f, sxx = 0.f;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) { sx += pstat[w][j][0]; sxx += pstat[w][j][1]; }
+          const float inv_k = __builtin_amdgcn_rcpf((float)K);
+          mean = sx * inv_k;
+          rstd = __frsqrt_rn(fmaxf(sxx * inv_k - mean * mean, 0.f) + 1e-5f);
+        }
+        v = rstd * (v - mean * e_gw) + e_c;
+      } else {
+        v += e_c;
+      }
+      if (EPI == SK_GELU) v = gelu_exact(v);
+      if (EPI == SK_RES) v += e_res;
+      if (tile < n_tiles && n < N && j < B) {
+        if (EPI == SK_F32) {
+          y_f32[(long long)j * N + n] = v;
+        } else if (EPI == SK_KV) {
+          const int seg = n / d_model;  // 0: query -> y, 1: key -> cache, 2: value -> cache   (one predicated store)
+          T* dst = seg == 0 ? y + (long long)j * ldy + n
+                            : (seg == 1 ? kcache : vcache) + (long long)j * cache_bstride + (long long)cur_pos * d_model + (n - seg * d_model);
+          *dst = (T)v;
+        } else if (EPI == SK_STORE) {
+          y[(long long)j * ldy + n] = (T)v;  // row-major [B][ldy] (the attention kernels' query operand)
         } else {
-          reinterpret_cast<T*>(a.y)[(long long)j * a.ldy + n] = (T)v;
+          y[tw_xt_index<T>(j, n)] = (T)v;    // feeds the next projection: fragment-major
         }
       }
     }
+    if (MULTI) { e_c = n_c; e_gw = n_gw; e_res = n_res; }
+    TW_TS(4);
   }
+}
+
+// Row-major W[N][K] -> fragment-major layout read by skinny_mfma_kernel: for tile t = n/16 and step s = k/(4E) one
+// 1-KiB block holds the MFMA A operand exactly as the 64 lanes consume it, lane l = kq*16 + fr <- row t*16+fr,
+// 16-B vector s*4+kq.  A wavefront's K slice is then ONE contiguous run (its requests are full cache lines in address
+// order, like a plain streaming copy) instead of 16 row segments of 64 B per request.  Rows >= N are zero.
+template <typename T>
+__global__ __launch_bounds__(256) void tile_weights_kernel(const T* __restrict__ src, T* __restrict__ dst, int N, int K) {
+  constexpr int E = ElemTraits<T>::kPer16B;
+  const int S = K / E / 4;
+  const long long v = (long long)blockIdx.x * 256 + threadIdx.x;  // destination vector index
+  const long long total = (long long)((N + 15) / 16) * S * 64;
+  if (v >= total) return;
+  const int l = (int)(v & 63);
+  const long long ts = v >> 6;
+  const int s = (int)(ts % S);
+  const int t = (int)(ts / S);
+  const int n = t * 16 + (l & 15), kv = s * 4 + (l >> 4);
+  u32x4_t val = u32x4_t{0u, 0u, 0u, 0u};
+  if (n < N) val = *reinterpret_cast<const u32x4_t*>(src + (long long)n * K + (long long)kv * E);
+  *reinterpret_cast<u32x4_t*>(dst + v * E) = val;
 }
 
 // W[n,:] *= g (in place, rounded to T); gw[n] = sum_k g[k] W[n,k]; cb[n] = sum_k beta[k] W[n,k] + bias[n]   (one wave per row)
@@ -547,7 +380,7 @@ __device__ __forceinline__ float wave_max(float v) { return tw_wave_max(v); }
 template <typename T, int NT>
 __device__ __forceinline__ float attend_block(const T* __restrict__ qptr, const T* __restrict__ kbase,
                                               const T* __restrict__ vbase, long long stride, int n_keys, float* sc,
-                                              float* red, T* __restrict__ outp) {
+                                              float* red, T* __restrict__ out_base, int out_j, int out_k0) {
   constexpr int KG = NT / 16;  // key groups
   constexpr int U = 8;         // keys per thread in flight
   constexpr int NW = NT / 64;
@@ -629,7 +462,7 @@ __device__ __forceinline__ float attend_block(const T* __restrict__ qptr, const 
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) v += wo[w * 64 + tid];
-    outp[tid] = (T)(v * inv);
+    out_base[tw_xt_index<T>(out_j, out_k0 + tid)] = (T)(v * inv);  // feeds o-proj: fragment-major (tw_common.h)
   }
   return inv;
 }
@@ -639,8 +472,8 @@ __device__ __forceinline__ float attend_block(const T* __restrict__ qptr, const 
 template <typename T, int NT, int U>
 __device__ __forceinline__ float attend_block_fused(const T* __restrict__ qptr, const T* __restrict__ kbase,
                                                     const T* __restrict__ vbase, long long stride, int n_keys,
-                                                    int max_rows, float* sc, float* red, T* __restrict__ outp,
-                                                    bool want_probs) {
+                                                    int max_rows, float* sc, float* red, T* __restrict__ out_base,
+                                                    int out_j, int out_k0, bool want_probs) {
   // `max_rows` (a launch constant) bounds the addresses so that the K/V requests do not depend on `n_keys`, which
   // for the self-attention cache is itself loaded from device memory (DecState.pos): all 2U+1 loads leave at once.
   constexpr int KG = NT / 16;
@@ -704,7 +537,7 @@ __device__ __forceinline__ float attend_block_fused(const T* __restrict__ qptr, 
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) v += wo[w * 64 + tid];
-    outp[tid] = (T)(v * inv);
+    out_base[tw_xt_index<T>(out_j, out_k0 + tid)] = (T)(v * inv);  // feeds o-proj: fragment-major (tw_common.h)
   }
   return inv;
 }
@@ -721,11 +554,11 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const T* __restrict_
   const int n_keys = stt->pos + 1;
   if (FUSED)  // the host guarantees pos < max_rows <= 256 for this call (single round trip, loads do not wait for `pos`)
     attend_block_fused<T, 256, 16>(q + (long long)b * d + h * 64, kc + (long long)b * cache_bstride + h * 64,
-                                   vc + (long long)b * cache_bstride + h * 64, d, n_keys, max_rows, sc, red,
-                                   out + (long long)b * d + h * 64, false);
+                                   vc + (long long)b * cache_bstride + h * 64, d, n_keys, max_rows, sc, red, out, b, h * 64,
+                                   false);
   else
     attend_block<T, 256>(q + (long long)b * d + h * 64, kc + (long long)b * cache_bstride + h * 64,
-                         vc + (long long)b * cache_bstride + h * 64, d, n_keys, sc, red, out + (long long)b * d + h * 64);
+                         vc + (long long)b * cache_bstride + h * 64, d, n_keys, sc, red, out, b, h * 64);
 }
 
 template <typename T>
@@ -744,10 +577,9 @@ __global__ __launch_bounds__(512) void dec_cross_attn_kernel(const T* __restrict
   float inv;
   if (Tlen <= 32 * 16)
     inv = attend_block_fused<T, 512, 16>(q + (long long)b * d + h * 64, ck + base, cv + base, 64, Tlen, Tlen, sc, red,
-                                         out + (long long)b * d + h * 64, slot >= 0);
+                                         out, b, h * 64, slot >= 0);
   else
-    inv = attend_block<T, 512>(q + (long long)b * d + h * 64, ck + base, cv + base, 64, Tlen, sc, red,
-                               out + (long long)b * d + h * 64);
+    inv = attend_block<T, 512>(q + (long long)b * d + h * 64, ck + base, cv + base, 64, Tlen, sc, red, out, b, h * 64);
   if (slot >= 0) __syncthreads();
   if (slot >= 0) {  // A11 side output: softmax row of an alignment head
     float* row = align + (((long long)b * Ha + slot) * P + stt->pos) * Tlen;
@@ -931,104 +763,70 @@ __global__ void advance_kernel(DecState* stt) { stt->pos += 1; }
 
 }  // namespace
 
-template <typename T, int BT>
-static hipError_t gemv_r(const GemvArgs& a, hipStream_t st) {
-  constexpr int E = ElemTraits<T>::kPer16B;
-  constexpr int CV = GemvChunk<T, BT>::kVec;
-  if (a.K % E != 0 || (a.ln_gw && a.K > 1280) || a.B > BT) return hipErrorInvalidValue;
-  const int nv_row = a.K / E;
-  const bool chunked = nv_row > CV;
-  if (chunked && a.ln_gw) return hipErrorInvalidValue;
-  const size_t lds = (size_t)BT * (chunked ? CV : nv_row) * 16;
-  // rows per wavefront: keep >= ~1000 wavefronts in flight when N allows it; very tall matrices (the tied
-  // logits projection) additionally walk GEMV_RG row groups per workgroup so x is staged/normalised once per 128 rows
-  if (a.N >= 16384) {
-    const int rows_per_block = 4 * 4 * GEMV_RG;
-    dim3 grid((a.N + rows_per_block - 1) / rows_per_block);
-    hipLaunchKernelGGL((gemv_kernel<T, BT, 4, true>), grid, dim3(256), lds, st, a);
-  } else if (a.N >= 3072) {
-    dim3 grid((a.N + 7) / 8);
-    hipLaunchKernelGGL((gemv_kernel<T, BT, 2, false>), grid, dim3(256), lds, st, a);
-  } else {
-    dim3 grid((a.N + 3) / 4);
-    hipLaunchKernelGGL((gemv_kernel<T, BT, 1, false>), grid, dim3(256), lds, st, a);
-  }
-  return hipGetLastError();
-}
-
-template <typename T, int BT>
-static hipError_t gemv_attr() {
-  // up to 80 KiB of staged activations: raise the dynamic-LDS cap once per instantiation
-  const int cap = GEMV_LDS_BUDGET;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<T, BT, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<T, BT, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<T, BT, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-}
-
-hipError_t init_decode_kernels() {
-  hipError_t e;
-  if ((e = gemv_attr<bf16_t, 1>()) != hipSuccess) return e;
-  if ((e = gemv_attr<bf16_t, 4>()) != hipSuccess) return e;
-  if ((e = gemv_attr<bf16_t, 8>()) != hipSuccess) return e;
-  if ((e = gemv_attr<bf16_t, 16>()) != hipSuccess) return e;
-  if ((e = gemv_attr<float, 1>()) != hipSuccess) return e;
-  if ((e = gemv_attr<float, 4>()) != hipSuccess) return e;
-  if ((e = gemv_attr<float, 8>()) != hipSuccess) return e;
-  return gemv_attr<float, 16>();
-}
+hipError_t init_decode_kernels() { return hipSuccess; }  // nothing to configure (kept for the call site in tw_create)
 
 static int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
 
+template <typename T, int NW, int SK_MAXS, bool MULTI>
+static hipError_t skinny_launch_v(const GemvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  const bool ln = a.ln_gw != nullptr;
+#define SK_GO(LNV, EPIV) hipLaunchKernelGGL((skinny_mfma_kernel<T, NW, SK_MAXS, LNV, EPIV, MULTI>), grid, dim3(NW * 64), lds, st, a)
+  if (a.y_f32) {
+    if (!ln || a.res || a.gelu || a.kcache) return hipErrorInvalidValue;
+    SK_GO(true, SK_F32);
+  } else if (a.kcache) {
+    if (!ln || a.res || a.gelu) return hipErrorInvalidValue;
+    SK_GO(true, SK_KV);
+  } else if (a.gelu) {
+    if (!ln || a.res) return hipErrorInvalidValue;
+    SK_GO(true, SK_GELU);
+  } else if (a.res) {
+    if (ln) return hipErrorInvalidValue;
+    SK_GO(false, SK_RES);
+  } else if (ln) {
+    SK_GO(true, SK_STORE);
+  } else {
+    SK_GO(false, SK_STORE);
+  }
+#undef SK_GO
+  return hipGetLastError();
+}
+
 template <typename T, int NW>
 static hipError_t skinny_launch_nw(const GemvArgs& a0, hipStream_t st) {
   constexpr int E = ElemTraits<T>::kPer16B;
   GemvArgs a = a0;
-  if (a.K % (4 * E) != 0 || (a.ln_gw && a.K > 1280) || a.B > 16) return hipErrorInvalidValue;
+  if (a.K % (4 * E) != 0 || a.B > 16) return hipErrorInvalidValue;
   const size_t lds = (size_t)NW * 256 * 4;
   const int tiles = (a.N + 15) / 16;
   // at most `max_blocks` workgroups: tall matrices (the tied logits projection) walk several tiles per workgroup
   static const int max_blocks = env_int("TW_SK_MAX_BLOCKS", 512);
-  a.rg = (tiles + max_blocks - 1) / max_blocks;
-  if (a.rg < 1) a.rg = 1;
-  dim3 grid((tiles + a.rg - 1) / a.rg);
   const int steps_per_wave = (a.K / E / 4 + NW - 1) / NW;
-  if (steps_per_wave <= 5)
-    hipLaunchKernelGGL((skinny_mfma_kernel<T, NW, 5>), grid, dim3(NW * 64), lds, st, a);
-  else
-    hipLaunchKernelGGL((skinny_mfma_kernel<T, NW, 10>), grid, dim3(NW * 64), lds, st, a);
-  return hipGetLastError();
+  a.rg = (tiles + max_blocks - 1) / max_blocks;
+  if (a.rg < 1 || steps_per_wave > 10) a.rg = 1;  // several tiles per workgroup only with one round of fragments per tile
+  dim3 grid((tiles + a.rg - 1) / a.rg);
+  if (a.rg > 1) {
+    if (steps_per_wave <= 5) return skinny_launch_v<T, NW, 5, true>(a, grid, lds, st);
+    return skinny_launch_v<T, NW, 10, true>(a, grid, lds, st);
+  }
+  if (steps_per_wave <= 5) return skinny_launch_v<T, NW, 5, false>(a, grid, lds, st);
+  return skinny_launch_v<T, NW, 10, false>(a, grid, lds, st);
 }
 
 template <typename T>
 static hipError_t skinny_launch(const GemvArgs& a, hipStream_t st) {
-  static const int nw_big = env_int("TW_SK_NW_BIGK", 8);  // wavefronts per tile when K is long (fc2: K = 5120)
-  if (a.K >= 4096 && nw_big == 16) return skinny_launch_nw<T, 16>(a, st);
+  static const int nw_big = env_int("TW_SK_NW_BIGK", 16);  // wavefronts per tile when K is long (fc2: K = 5120)
+  if (a.K >= 4096 && nw_big == 16 && !a.ln_gw && !a.y_f32 && !a.kcache && !a.gelu) return skinny_launch_nw<T, 16>(a, st);
   return skinny_launch_nw<T, 8>(a, st);
-}
-
-static int gemv_mfma_min_b() {  // streams from which the MFMA formulation is used (TW_SKINNY_MIN_B overrides, for A/B runs)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("TW_SKINNY_MIN_B");
-    v = e ? atoi(e) : 5;
-    if (v < 1) v = 1;
-  }
-  return v;
 }
 
 template <typename T>
 static hipError_t gemv_b(const GemvArgs& a, hipStream_t st) {
-  if (a.B >= gemv_mfma_min_b() && a.B <= 16) return skinny_launch<T>(a, st);
-  if (a.B <= 1) return gemv_r<T, 1>(a, st);
-  if (a.B <= 4) return gemv_r<T, 4>(a, st);
-  if (a.B <= 8) return gemv_r<T, 8>(a, st);
-  if (a.B <= 16) return gemv_r<T, 16>(a, st);
-  return hipErrorInvalidValue;
+  if (a.B < 1 || a.B > 16) return hipErrorInvalidValue;
+  return skinny_launch<T>(a, st);
 }
 
 hipError_t launch_gemv(int dtype, const GemvArgs& a, hipStream_t st) {
@@ -1080,6 +878,16 @@ hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st) {
 
 hipError_t launch_advance(DecState* stt, hipStream_t st) {
   hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, stt);
+  return hipGetLastError();
+}
+
+hipError_t launch_tile_weights(int dtype, const void* src, void* dst, int N, int K, hipStream_t st) {
+  const int E = dtype == 1 ? 8 : 4;
+  if (K % (4 * E) != 0) return hipErrorInvalidValue;
+  const long long total = (long long)((N + 15) / 16) * (K / E / 4) * 64;
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (dtype == 1) hipLaunchKernelGGL(tile_weights_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, N, K);
+  else hipLaunchKernelGGL(tile_weights_kernel<float>, grid, dim3(256), 0, st, (const float*)src, (float*)dst, N, K);
   return hipGetLastError();
 }
 

@@ -47,6 +47,16 @@ template <typename T> struct ElemTraits;
 template <> struct ElemTraits<float> { static constexpr int kPer16B = 4; static constexpr int kCode = 0; };
 template <> struct ElemTraits<bf16_t> { static constexpr int kPer16B = 8; static constexpr int kCode = 1; };
 
+// Fragment-major ("xt") layout of the decoder's per-token activations, a [16 streams][K] block stored as the MFMA B
+// operand of the decode projections reads it: 64-B step s = k / (4E), then lane = ((k / E) & 3) * 16 + stream, then the
+// E elements of that lane's 16-B vector.  One wavefront request for step s is 1 KiB contiguous.  Buffers are always 16
+// streams wide (streams >= B are never written and never read back).
+template <typename T>
+__device__ __forceinline__ long long tw_xt_index(int stream, int k) {
+  constexpr int E = ElemTraits<T>::kPer16B;
+  return ((long long)(k / (4 * E)) * 64 + ((k / E) & 3) * 16 + stream) * E + (k % E);
+}
+
 // Affine map from a logical GEMM row m to an element offset:  (m / rpb) * bstride + (m % rpb) * rstride.
 // Lets one GEMM read convolution windows as overlapping rows of a padded token-major buffer and
 // write into padded / per-batch layouts without im2col copies.
@@ -125,15 +135,15 @@ hipError_t launch_embed(int dtype, const int* ids, const DecState* stt, const vo
                         int B, int d, hipStream_t st);
 // y[b, n] = epi( LN?(x[b,:]) . W[n,:] + bias[n] )  for b < B <= 16.
 struct GemvArgs {
-  const void* x; int ldx;        // [B, K] input (T)
+  const void* x; int ldx;        // [16, K] input (T), fragment-major (tw_xt_index); ldx unused
   // folded pre-LayerNorm (see k_decode.hip): W already carries the gain, ln_gw[n] = sum_k g[k] W[n,k],
   // ln_cb[n] = sum_k beta[k] W[n,k] + bias[n]  (float32, null = no LayerNorm); requires K <= 1280
   const float* ln_gw; const float* ln_cb;
-  const void* W; const void* bias;     // [N, K], [N]
+  const void* W; const void* bias;     // [N, K] in the fragment-major layout of launch_tile_weights, [N]
   int N, K, B;
   int gelu;
-  const void* res; int ldres;    // residual [B, N] added after bias/act (may alias-free ping-pong)
-  void* y; int ldy;              // output (T) or
+  const void* res; int ldres;    // residual [16, N] (fragment-major) added after bias/act; output then fragment-major too
+  void* y; int ldy;              // output (T): fragment-major [16, N] with res or gelu, else row-major [B, ldy]; or
   float* y_f32;                  // float32 output [B, N] (logits) when non-null
   // optional KV-cache scatter for the fused self-attention QKV projection: rows [d,2d) -> kcache, [2d,3d) -> vcache
   void* kcache; void* vcache; long long cache_bstride; int d_model; const DecState* stt;
@@ -141,6 +151,8 @@ struct GemvArgs {
 };
 hipError_t launch_gemv(int dtype, const GemvArgs& a, hipStream_t st);
 hipError_t init_decode_kernels();
+// row-major [N][K] -> the fragment-major layout launch_gemv reads (k_decode.hip); dst holds ceil(N/16)*16 rows
+hipError_t launch_tile_weights(int dtype, const void* src, void* dst, int N, int K, hipStream_t st);
 // weight preparation for the folded pre-LayerNorm: W <- Wsrc * g (may alias), gw, cb as above
 hipError_t launch_fold_ln(int dtype, void* W, const void* Wsrc, const void* g, const void* beta, const void* bias, float* gw,
                           float* cb, int N, int K, hipStream_t st);  // once per process: dynamic-LDS caps of the gemv instantiations

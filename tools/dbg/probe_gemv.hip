@@ -2,6 +2,7 @@
 // launches from a hipGraph (like one decode step does), printing microseconds per launch per shape.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DTW_TIMING] tools/dbg/probe_gemv.hip -o tools/dbg/probe_gemv
 #include "../../thewhisper_amd/csrc/k_decode.hip"
+#include <algorithm>
 #include <cstdio>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
@@ -14,7 +15,13 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&bias, 52000 * 2)); CK(hipMalloc(&g, 1280 * 2)); CK(hipMalloc(&b, 1280 * 2)); CK(hipMalloc(&logits, 16 * 52000 * 4)); CK(hipMalloc(&gw, 52000 * 4)); CK(hipMalloc(&cb, 52000 * 4)); CK(hipMemset(gw, 0, 52000 * 4)); CK(hipMemset(cb, 0, 52000 * 4));
   CK(hipMemset(x, 0, 16 * 5120 * 2)); CK(hipMemset(res, 0, 16 * 5120 * 2)); CK(hipMemset(bias, 0, 52000 * 2));
   CK(hipMemset(g, 0, 2560)); CK(hipMemset(b, 0, 2560));
-  DecState* stt; CK(hipMalloc(&stt, sizeof(DecState))); CK(hipMemset(stt, 0, sizeof(DecState)));
+  const int NL = 128;
+  DecState* stt; CK(hipMalloc(&stt, NL * sizeof(DecState)));
+  { std::vector<DecState> h(NL); for (int i = 0; i < NL; ++i) { h[i] = DecState{}; h[i].pos = i; } CK(hipMemcpy(stt, h.data(), NL * sizeof(DecState), hipMemcpyHostToDevice)); }
+#ifdef TW_PROBE_TS
+  unsigned long long* ts; const size_t ts_n = (size_t)NL * 1024 * 8; CK(hipMalloc(&ts, ts_n * 8));
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_ts), &ts, sizeof(ts)));
+#endif
   CK(init_decode_kernels());
   hipStream_t st; CK(hipStreamCreate(&st));
   struct Shape { const char* name; int N, K; bool ln, resid, gelu; };
@@ -25,7 +32,6 @@ int main(int argc, char** argv) {
       {"fc1     5120x1280 LN G ", 5120, 1280, true, false, true},
       {"fc2     1280x5120      ", 1280, 5120, false, true, false},
   };
-  const int NL = 128;
   for (int B : {1, 4, 16}) {
     for (const Shape& s : shapes) {
       const size_t wbytes = (size_t)s.N * s.K * 2;
@@ -37,12 +43,15 @@ int main(int argc, char** argv) {
         a.N = s.N; a.K = s.K; a.B = B; a.gelu = s.gelu; a.y = (i & 1) ? x : y; a.ldy = s.N;
         if (s.ln) { a.ln_gw = gw; a.ln_cb = cb; }
         if (s.resid) { a.res = res; a.ldres = s.N; }
-        a.stt = stt;
+        a.stt = stt + i;
         CK(launch_gemv(1, a, st));
       }
       CK(hipStreamEndCapture(st, &gr));
       CK(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
       CK(hipGraphLaunch(ge, st)); CK(hipStreamSynchronize(st));
+#ifdef TW_PROBE_TS
+      CK(hipMemset(ts, 0, ts_n * 8));
+#endif
       hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
       CK(hipEventRecord(e0, st));
       const int R = 10;
@@ -51,6 +60,30 @@ int main(int argc, char** argv) {
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       const double us = ms * 1e3 / (R * NL);
       printf("B=%2d %s: %6.2f us/launch  (%.2f TB/s of weights)\n", B, s.name, us, wbytes / us * 1e-6);
+#ifdef TW_PROBE_TS
+      {
+        std::vector<unsigned long long> h(ts_n);
+        CK(hipMemcpy(h.data(), ts, ts_n * 8, hipMemcpyDeviceToHost));
+        double span = 0, skew = 0, gap = 0, stage[8] = {0}; int nstage = 0, nblk = 0; unsigned long long prev_end = 0;
+        for (int i = 0; i < NL; ++i) {
+          unsigned long long s0 = ~0ull, s1 = 0, e1 = 0; double l[8] = {0}; int nb = 0;
+          for (int bk = 0; bk < 1024; ++bk) {
+            const unsigned long long* q = &h[((size_t)i * 1024 + bk) * 8];
+            if (!q[0]) continue;
+            ++nb; s0 = std::min(s0, q[0]); s1 = std::max(s1, q[0]);
+            for (int k = 1; k < 8; ++k) if (q[k]) { l[k] += (double)(q[k] - q[0]); e1 = std::max(e1, q[k]); nstage = std::max(nstage, k); }
+          }
+          nblk = nb;
+          span += (double)(e1 - s0); skew += (double)(s1 - s0);
+          for (int k = 1; k < 8; ++k) stage[k] += l[k] / nb;
+          if (i > 0) gap += (double)((long long)(s0 - prev_end));
+          prev_end = e1;
+        }
+        printf("      blocks %d | span %.2f us, dispatch skew %.2f, gap %.2f | mean stamp offsets:", nblk, span / NL * 0.01, skew / NL * 0.01, gap / (NL - 1) * 0.01);
+        for (int k = 1; k <= nstage; ++k) printf(" t%d=%.2f", k, stage[k] / NL * 0.01);
+        printf("\n");
+      }
+#endif
       hipGraphExecDestroy(ge); hipGraphDestroy(gr);
     }
   }
