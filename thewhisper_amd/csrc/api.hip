@@ -309,10 +309,13 @@ int tw_create(const tw_config* cfg, tw_ctx** out) {
   CALLOC(c->enc_out, B * T * d * e, false);
   // ---- decoder state ----
   const size_t Ld = c->Ld;
-  CALLOC(c->self_k, Ld * B * P * d * e, true);
-  CALLOC(c->self_v, Ld * B * P * d * e, true);
-  CALLOC(c->cross_k, Ld * B * T * d * e, false);
-  CALLOC(c->cross_v, Ld * B * T * d * e, false);
+  // decoder K / V^T caches: fragment-major per (stream, head), key count padded to 64 (tw_kf_index / tw_vtf_index);
+  // the padding is never written and must stay zero (V^T padding meets probability 0 in the P.V product)
+  const size_t Pp = (P + 63) / 64 * 64;
+  CALLOC(c->self_k, Ld * B * Pp * d * e, true);
+  CALLOC(c->self_v, Ld * B * Pp * d * e, true);
+  CALLOC(c->cross_k, Ld * B * Tp * d * e, true);
+  CALLOC(c->cross_v, Ld * B * Tp * d * e, true);
   // per-token decoder activations that feed a projection are fragment-major and always 16 streams wide (tw_xt_index)
   CALLOC(c->dx0, 16 * d * e, true); CALLOC(c->dx1, 16 * d * e, true); CALLOC(c->dq, B * d * e, true);
   CALLOC(c->datt, 16 * d * e, true); CALLOC(c->dh, 16 * F * e, true);
@@ -598,7 +601,7 @@ int tw_cross_kv(tw_ctx* c, int32_t B, void* stream) {
   if (B < 1 || B > c->encoded_B) return fail(c, TW_ESTATE, "tw_cross_kv: B=%d but %d clips encoded", B, c->encoded_B);
   hipStream_t st = pick_stream(c, stream);
   const int d = c->d, T = c->T;
-  const size_t per_layer = (size_t)c->Bmax * T * d;
+  const size_t per_layer = (size_t)c->Bmax * c->Tp * d;
   tic(c, 2, st);
   for (int l = 0; l < c->Ld; ++l) {
     const LayerW& L = c->dec[l];
@@ -627,8 +630,9 @@ int decode_core(tw_ctx* c, int B, hipStream_t st) {
   HIPCHK(c, launch_embed(dt, c->cur_ids, c->stt, c->tok_emb, c->dec_pos, c->dx0, B, d, st));
   void* xin = c->dx0;
   void* xmid = c->dx1;
-  const size_t self_layer = (size_t)c->Bmax * P * d;
-  const size_t cross_layer = (size_t)c->Bmax * T * d;
+  const int Pp = (P + 63) / 64 * 64;
+  const size_t self_layer = (size_t)c->Bmax * Pp * d;
+  const size_t cross_layer = (size_t)c->Bmax * c->Tp * d;
   for (int l = 0; l < c->Ld; ++l) {
     const LayerW& L = c->dec[l];
     void* sk = at(c->self_k, self_layer * l, e);
@@ -636,11 +640,10 @@ int decode_core(tw_ctx* c, int B, hipStream_t st) {
     {  // LN + fused QKV; k,v rows go straight into the cache at position pos
       GemvArgs a{};
       a.x = xin; a.ldx = d; a.ln_gw = L.qkv_gw; a.ln_cb = L.qkv_cb; a.W = L.wqkv; a.N = 3 * d; a.K = d; a.B = B;
-      a.y = c->dq; a.ldy = d; a.kcache = sk; a.vcache = sv; a.cache_bstride = (long long)P * d; a.d_model = d; a.stt = c->stt;
+      a.y = c->dq; a.ldy = d; a.kcache = sk; a.vcache = sv; a.cache_bstride = (long long)Pp * d; a.d_model = d; a.stt = c->stt;
       HIPCHK(c, launch_gemv(dt, a, st));
     }
-    HIPCHK(c, launch_dec_self_attn(dt, c->dq, sk, sv, (long long)P * d, c->datt, B, H, c->dec_key_bound > 0 ? c->dec_key_bound : P,
-                                   c->stt, st));
+    HIPCHK(c, launch_dec_self_attn(dt, c->dq, sk, sv, Pp, c->datt, B, H, c->dec_key_bound > 0 ? c->dec_key_bound : P, c->stt, st));
     {
       GemvArgs a{};
       a.x = c->datt; a.ldx = d; a.W = L.wo; a.bias = L.bo; a.N = d; a.K = d; a.B = B; a.res = xin; a.ldres = d;
@@ -654,7 +657,7 @@ int decode_core(tw_ctx* c, int B, hipStream_t st) {
       HIPCHK(c, launch_gemv(dt, a, st));
     }
     HIPCHK(c, launch_dec_cross_attn(dt, c->dq, at(c->cross_k, cross_layer * l, e), at(c->cross_v, cross_layer * l, e),
-                                    c->datt, B, H, T, c->Ha > 0 ? c->align_slot + (size_t)l * H : nullptr, c->align, c->Ha,
+                                    c->datt, B, H, T, c->Tp, c->Ha > 0 ? c->align_slot + (size_t)l * H : nullptr, c->align, c->Ha,
                                     P, c->stt, st));
     {
       GemvArgs a{};
@@ -769,7 +772,7 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
   // ---- optional graph capture of one full step ----
   char keybuf[256];
   snprintf(keybuf, sizeof keybuf, "%d|%d|%d|%d|%d|%d|%d|%d|%d|%d", B, o->eos_id, o->pad_id, o->min_new_tokens, o->timestamps,
-           o->no_timestamps_id, o->max_initial_timestamp_index, o->n_begin_suppress, o->n_suppress, max_len <= 256 ? 1 : 0);
+           o->no_timestamps_id, o->max_initial_timestamp_index, o->n_begin_suppress, o->n_suppress, (max_len + 63) / 64);
   const bool use_graph = c->cfg.use_graph != 0;
   if (use_graph && (c->step_graph == nullptr || c->step_graph_key != keybuf)) {
     if (c->step_graph) { (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }

@@ -293,9 +293,11 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (SK_MAXS <= 5 ? 4 : 2))) v
         if (EPI == SK_F32) {
           y_f32[(long long)j * N + n] = v;
         } else if (EPI == SK_KV) {
-          const int seg = n / d_model;  // 0: query -> y, 1: key -> cache, 2: value -> cache   (one predicated store)
+          const int seg = n / d_model;  // 0: query -> y, 1: key -> K cache, 2: value -> V^T cache   (one predicated store)
+          const int nn = n - seg * d_model, hh = nn >> 6, cc = nn & 63;
+          const long long hb = (long long)j * cache_bstride + (long long)hh * (cache_bstride / (d_model >> 6));  // (stream, head)
           T* dst = seg == 0 ? y + (long long)j * ldy + n
-                            : (seg == 1 ? kcache : vcache) + (long long)j * cache_bstride + (long long)cur_pos * d_model + (n - seg * d_model);
+                            : (seg == 1 ? kcache + hb + tw_kf_index<T>(cur_pos, cc) : vcache + hb + tw_vtf_index<T>(cur_pos, cc));
           *dst = (T)v;
         } else if (EPI == SK_STORE) {
           y[(long long)j * ldy + n] = (T)v;  // row-major [B][ldy] (the attention kernels' query operand)
@@ -356,177 +358,117 @@ __global__ __launch_bounds__(256) void fold_ln_kernel(T* __restrict__ W, const T
 
 // ---------------------------------------------------------------------------------------------
 // single-query attention (decoder self-attention over the growing cache, cross-attention over the
-// cached encoder K/V).  One workgroup per (stream, head); thread = (key group kg, dim quad dq):
-// 16 lanes cover one 128-B (bf16) K or V row, NT/16 rows per wave instruction, U rows per thread in
-// flight.  Two passes with all loads of a pass issued back to back (the kernel is latency-, not
-// bandwidth-bound: ~130 KB per head): scores -> LDS, block max / sum, then P.V.
+// cached encoder K/V).  One workgroup per (stream, head), NW wavefronts, each owning 64 consecutive
+// keys per chunk of NW*64 keys.  Both products run on the matrix cores although there is only one
+// query: K is the A operand (16 keys x 64 dims per tile) against the query broadcast over the 16 B
+// columns, V^T is the A operand (16 dims x 4E keys) against the probabilities.  15/16 of the MFMA
+// columns are redundant, which is free - the kernel moves 128 KiB per head (cross attention, 10 s)
+// and is bound by how fast one CU can take that in, and the VALU formulation (a dot product, a
+// 16-lane reduction and an exp per key and 8-byte loads) cost more issue time than the loads.
+// K and V^T are stored fragment-major (tw_kf_index / tw_vtf_index in tw_common.h), written in that
+// layout by the producers (cross-K/V GEMM epilogue, QKV projection epilogue): every request of a
+// wavefront is 1 KiB contiguous and a wavefront's 64 keys are one 8-KiB run of each operand.
+// Softmax in fp32 (scores -> LDS, block max, exp, sum); probabilities are rounded to the storage
+// type for the P.V product as the reference does (HF casts attn_weights to the value dtype).
 // ---------------------------------------------------------------------------------------------
-template <typename T> __device__ __forceinline__ void load4(const T* p, float* o);
-template <> __device__ __forceinline__ void load4<float>(const float* p, float* o) {
-  const f32x4_t v = *reinterpret_cast<const f32x4_t*>(p);
-  o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
-}
-template <> __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float* o) {
-  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
-  const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(p);
-  o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
-}
-
-__device__ __forceinline__ float group16_sum(float v) { return row16_sum(v); }
 __device__ __forceinline__ float wave_max(float v) { return tw_wave_max(v); }
 
-// Shared by both attention kernels.  NT threads; sc: LDS float[n_keys]; red: LDS float[NT/64 * 64 + 16].
-// Returns (in every thread) 1/L; the normalised context vector is written by the first 64 threads.
-template <typename T, int NT>
-__device__ __forceinline__ float attend_block(const T* __restrict__ qptr, const T* __restrict__ kbase,
-                                              const T* __restrict__ vbase, long long stride, int n_keys, float* sc,
-                                              float* red, T* __restrict__ out_base, int out_j, int out_k0) {
-  constexpr int KG = NT / 16;  // key groups
-  constexpr int U = 8;         // keys per thread in flight
-  constexpr int NW = NT / 64;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kg = tid >> 4, dq = tid & 15;
-  float qv[4];
-  load4<T>(qptr + dq * 4, qv);
-  // ---- pass 1: scores ----
-  for (int c = 0; c < n_keys; c += KG * U) {
-    float kv[U][4];
+// SINGLE: n_bound <= NW*64, so every K and V^T fragment of the head is requested before anything is waited for
+// (one memory round trip per head); otherwise two passes over chunks of NW*64 keys.
+// n_keys = valid keys (rest masked), n_bound = keys addressable (multiple of 64, <= rows allocated per head).
+// sc: LDS float[n_bound] (unnormalised probabilities on return); red: LDS float[2*NW + NW*64].
+// Returns 1/L in every thread; threads 0..63 write the context vector (fragment-major activation layout).
+template <typename T, int NW, bool SINGLE>
+__device__ __forceinline__ float attn_mfma_block(const T* __restrict__ q, const T* __restrict__ kf, const T* __restrict__ vtf,
+                                                 int n_keys, int n_bound, float* sc, float* red, T* __restrict__ out_base,
+                                                 int out_j, int out_k0) {
+  constexpr int E = ElemTraits<T>::kPer16B;
+  constexpr int DS = 64 / (4 * E);  // dim steps per key tile (QK^T) = key steps per 64 keys (P.V)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, kq = lane >> 4;
+  const int n_chunks = SINGLE ? 1 : (n_bound + NW * 64 - 1) / (NW * 64);
+  const int last64 = n_bound / 64 - 1;  // last addressable 64-key group
+  u32x4_t qf[DS], kfr[4 * DS], vfr[4 * DS];
+  auto load_k = [&](int g64) {  // 64 keys = 4 tiles x DS steps = 4*DS KiB contiguous
+    const T* p = kf + ((long long)min(g64, last64) * (4 * DS) * 64 + lane) * E;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      int t = c + u * KG + kg;
-      if (t >= n_keys) t = n_keys - 1;
-      load4<T>(kbase + (long long)t * stride + dq * 4, kv[u]);
-    }
+    for (int i = 0; i < 4 * DS; ++i) kfr[i] = *reinterpret_cast<const u32x4_t*>(p + (long long)i * 64 * E);
+  };
+  auto load_v = [&](int g64) {  // 64 keys = DS key steps x 4 dim tiles
+    const T* p = vtf + ((long long)min(g64, last64) * (4 * DS) * 64 + lane) * E;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      float s = qv[0] * kv[u][0] + qv[1] * kv[u][1] + qv[2] * kv[u][2] + qv[3] * kv[u][3];
-      s = group16_sum(s);
-      const int t = c + u * KG + kg;
-      if (dq == 0 && t < n_keys) sc[t] = s;
-    }
-  }
-  __syncthreads();
-  // ---- block max, exp, block sum ----
-  float m = -1.0e30f;
-  for (int t = tid; t < n_keys; t += NT) m = fmaxf(m, sc[t]);
-  m = wave_max(m);
-  if (lane == 0) red[wave] = m;
-  __syncthreads();
-  float M = red[0];
+    for (int i = 0; i < 4 * DS; ++i) vfr[i] = *reinterpret_cast<const u32x4_t*>(p + (long long)i * 64 * E);
+  };
 #pragma unroll
-  for (int w = 1; w < NW; ++w) M = fmaxf(M, red[w]);
-  __syncthreads();
-  float ls = 0.f;
-  for (int t = tid; t < n_keys; t += NT) {
-    const float p = expf(sc[t] - M);
-    sc[t] = p;
-    ls += p;
-  }
-  ls = wave_sum(ls);
-  if (lane == 0) red[wave] = ls;
-  __syncthreads();
-  float L = 0.f;
-#pragma unroll
-  for (int w = 0; w < NW; ++w) L += red[w];
-  const float inv = 1.0f / L;
-  __syncthreads();
-  // ---- pass 2: context = sum_t p[t] * V[t] ----
-  float o[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int c = 0; c < n_keys; c += KG * U) {
-    float vv[U][4];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      int t = c + u * KG + kg;
-      if (t >= n_keys) t = n_keys - 1;
-      load4<T>(vbase + (long long)t * stride + dq * 4, vv[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int t = c + u * KG + kg;
-      const float p = (t < n_keys) ? sc[t] : 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = fmaf(p, vv[u][i], o[i]);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {  // fold the 4 key groups of this wavefront
-    o[i] = tw_xor32_sum(tw_xor16_sum(o[i]));
-  }
-  float* wo = red + 16;  // [NW][64]
-  if (lane < 16) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) wo[wave * 64 + lane * 4 + i] = o[i];
-  }
-  __syncthreads();
-  if (tid < 64) {
-    float v = 0.f;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) v += wo[w * 64 + tid];
-    out_base[tw_xt_index<T>(out_j, out_k0 + tid)] = (T)(v * inv);  // feeds o-proj: fragment-major (tw_common.h)
-  }
-  return inv;
-}
+  for (int ds = 0; ds < DS; ++ds) qf[ds] = *reinterpret_cast<const u32x4_t*>(q + ds * 4 * E + kq * E);
+  load_k(wave);
+  if (SINGLE) load_v(wave);
+  __builtin_amdgcn_sched_barrier(0);
 
-// Single-round-trip variant for n_keys <= (NT/16)*U: every thread requests its U K rows AND U V rows back to
-// back (one memory latency for the whole head), scores and probabilities stay in registers, two barriers.
-template <typename T, int NT, int U>
-__device__ __forceinline__ float attend_block_fused(const T* __restrict__ qptr, const T* __restrict__ kbase,
-                                                    const T* __restrict__ vbase, long long stride, int n_keys,
-                                                    int max_rows, float* sc, float* red, T* __restrict__ out_base,
-                                                    int out_j, int out_k0, bool want_probs) {
-  // `max_rows` (a launch constant) bounds the addresses so that the K/V requests do not depend on `n_keys`, which
-  // for the self-attention cache is itself loaded from device memory (DecState.pos): all 2U+1 loads leave at once.
-  constexpr int KG = NT / 16;
-  constexpr int NW = NT / 64;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int kg = tid >> 4, dq = tid & 15;
-  typedef __attribute__((ext_vector_type(4))) float f4;
-  float kv[U][4], vv[U][4];
-#pragma unroll
-  for (int u = 0; u < U; ++u) load4<T>(kbase + (long long)min(u * KG + kg, max_rows - 1) * stride + dq * 4, kv[u]);
-#pragma unroll
-  for (int u = 0; u < U; ++u) load4<T>(vbase + (long long)min(u * KG + kg, max_rows - 1) * stride + dq * 4, vv[u]);
-  float qv[4];
-  load4<T>(qptr + dq * 4, qv);
-  float sv[U];
+  // ---- scores: D[i = key (lane>>4)*4 + r][j] identical in every column j; column 0 lanes publish them ----
   float m = -1.0e30f;
+  for (int c = 0; c < n_chunks; ++c) {
+    const int g64 = c * NW + wave;
+    if (c > 0) load_k(g64);
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    float s = qv[0] * kv[u][0] + qv[1] * kv[u][1] + qv[2] * kv[u][2] + qv[3] * kv[u][3];
-    s = group16_sum(s);
-    const bool valid = (u * KG + kg) < n_keys;
-    sv[u] = valid ? s : -1.0e30f;
-    m = fmaxf(m, sv[u]);
+    for (int a = 0; a < 4; ++a) {
+      f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ds = 0; ds < DS; ++ds) acc = sk_mfma<T>(kfr[a * DS + ds], qf[ds], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = g64 * 64 + a * 16 + kq * 4 + r;
+        const float sv = (t < n_keys) ? acc[r] : -1.0e30f;
+        m = fmaxf(m, sv);
+        if (fr == 0 && t < n_bound) sc[t] = sv;
+      }
+    }
   }
-  m = tw_xor32_max(tw_xor16_max(m));  // rows of the wavefront hold different key groups
+  m = tw_xor32_max(tw_xor16_max(m));
   if (lane == 0) red[wave] = m;
   __syncthreads();
   float M = red[0];
 #pragma unroll
   for (int w = 1; w < NW; ++w) M = fmaxf(M, red[w]);
-  float o[4] = {0.f, 0.f, 0.f, 0.f};
+
+  // ---- probabilities of this wavefront's own keys (written back to LDS for the B operand and the alignment rows) and P.V
+  f32x4_t o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   float ls = 0.f;
+  for (int c = 0; c < n_chunks; ++c) {
+    const int g64 = c * NW + wave;
+    if (!SINGLE) load_v(g64);
+    const int t0 = g64 * 64 + lane;  // one key per lane
+    float pr = 0.f;
+    if (t0 < n_bound) {
+      pr = (t0 < n_keys) ? expf(sc[t0] - M) : 0.f;
+      sc[t0] = pr;
+    }
+    ls += pr;
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int t = u * KG + kg;
-    const float p = (t < n_keys) ? expf(sv[u] - M) : 0.f;
-    ls += p;
-    if (want_probs && dq == 0 && t < n_keys) sc[t] = p;
+    for (int ks = 0; ks < DS; ++ks) {
+      float pv[E];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = fmaf(p, vv[u][i], o[i]);
+      for (int e = 0; e < E; ++e) {
+        const int t = g64 * 64 + ks * 4 * E + kq * E + e;
+        pv[e] = (t < n_bound) ? sc[t] : 0.f;  // same wavefront wrote these: LDS operations of a wavefront stay in order
+      }
+      const u32x4_t pf = pack16<T>(pv);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt] = sk_mfma<T>(vfr[ks * 4 + dt], pf, o[dt]);
+    }
   }
-  // all 16 lanes of a key group carry the same p: fold the 4 groups of the wavefront, one partial per wave
-  ls = tw_xor32_sum(tw_xor16_sum(ls));
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    o[i] = tw_xor32_sum(tw_xor16_sum(o[i]));
-  }
-  float* wl = red + 8;    // [NW]
-  float* wo = red + 16;   // [NW][64]
+  ls = tw_wave_sum(ls);
+  float* wl = red + NW;       // [NW]
+  float* wo = red + 2 * NW;   // [NW][64]
   if (lane == 0) wl[wave] = ls;
-  if (lane < 16) {
+  if (fr == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wo[wave * 64 + lane * 4 + i] = o[i];
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wo[wave * 64 + dt * 16 + kq * 4 + r] = o[dt][r];
   }
   __syncthreads();
   float L = 0.f;
@@ -542,46 +484,39 @@ __device__ __forceinline__ float attend_block_fused(const T* __restrict__ qptr, 
   return inv;
 }
 
-template <typename T, bool FUSED>
+// q [B, H*64] row-major; kc / vc per (stream, head): `rows` (multiple of 64) keys of K fragment-major / V^T fragment-major
+template <typename T, bool SINGLE>
 __global__ __launch_bounds__(256) void dec_self_attn_kernel(const T* __restrict__ q, const T* __restrict__ kc,
-                                                             const T* __restrict__ vc, long long cache_bstride,
-                                                             T* __restrict__ out, int H, int max_rows,
-                                                             const DecState* __restrict__ stt) {
+                                                             const T* __restrict__ vc, int rows, T* __restrict__ out, int H,
+                                                             int key_bound, const DecState* __restrict__ stt) {
   __shared__ float sc[512];
-  __shared__ float red[16 + 4 * 64];
+  __shared__ float red[2 * 4 + 4 * 64];
+  asm volatile("" ::"s"(q), "s"(kc), "s"(vc), "s"(rows), "s"(out), "s"(H), "s"(key_bound), "s"(stt));
   const int h = blockIdx.x, b = blockIdx.y;
-  const int d = H * 64;
   const int n_keys = stt->pos + 1;
-  if (FUSED)  // the host guarantees pos < max_rows <= 256 for this call (single round trip, loads do not wait for `pos`)
-    attend_block_fused<T, 256, 16>(q + (long long)b * d + h * 64, kc + (long long)b * cache_bstride + h * 64,
-                                   vc + (long long)b * cache_bstride + h * 64, d, n_keys, max_rows, sc, red, out, b, h * 64,
-                                   false);
-  else
-    attend_block<T, 256>(q + (long long)b * d + h * 64, kc + (long long)b * cache_bstride + h * 64,
-                         vc + (long long)b * cache_bstride + h * 64, d, n_keys, sc, red, out, b, h * 64);
+  const long long base = ((long long)b * H + h) * rows * 64;
+  // the host guarantees pos < key_bound (a multiple of 64, <= rows): the requests do not wait for `pos`
+  attn_mfma_block<T, 4, SINGLE>(q + ((long long)b * H + h) * 64, kc + base, vc + base, n_keys, key_bound, sc, red, out, b, h * 64);
 }
 
-template <typename T>
+template <typename T, bool SINGLE>
 __global__ __launch_bounds__(512) void dec_cross_attn_kernel(const T* __restrict__ q, const T* __restrict__ ck,
                                                               const T* __restrict__ cv, T* __restrict__ out, int H,
-                                                              int Tlen, const int* __restrict__ align_slot,
+                                                              int Tlen, int Tp, const int* __restrict__ align_slot,
                                                               float* __restrict__ align, int Ha, int P,
                                                               const DecState* __restrict__ stt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* sc = reinterpret_cast<float*>(smem);  // [Tlen] scores -> unnormalised probabilities
-  __shared__ float red[16 + 8 * 64];
+  float* sc = reinterpret_cast<float*>(smem);  // [Tp] scores -> unnormalised probabilities
+  __shared__ float red[2 * 8 + 8 * 64];
+  asm volatile("" ::"s"(q), "s"(ck), "s"(cv), "s"(out), "s"(H), "s"(Tlen), "s"(Tp), "s"(align_slot), "s"(align), "s"(Ha), "s"(P),
+               "s"(stt));
   const int h = blockIdx.x, b = blockIdx.y;
-  const int d = H * 64;
-  const long long base = ((long long)b * H + h) * Tlen * 64;
+  const long long base = ((long long)b * H + h) * Tp * 64;
+  const float inv = attn_mfma_block<T, 8, SINGLE>(q + ((long long)b * H + h) * 64, ck + base, cv + base, Tlen, Tp, sc, red, out,
+                                                  b, h * 64);
   const int slot = align_slot ? align_slot[h] : -1;
-  float inv;
-  if (Tlen <= 32 * 16)
-    inv = attend_block_fused<T, 512, 16>(q + (long long)b * d + h * 64, ck + base, cv + base, 64, Tlen, Tlen, sc, red,
-                                         out, b, h * 64, slot >= 0);
-  else
-    inv = attend_block<T, 512>(q + (long long)b * d + h * 64, ck + base, cv + base, 64, Tlen, sc, red, out, b, h * 64);
-  if (slot >= 0) __syncthreads();
   if (slot >= 0) {  // A11 side output: softmax row of an alignment head
+    __syncthreads();
     float* row = align + (((long long)b * Ha + slot) * P + stt->pos) * Tlen;
     for (int t = threadIdx.x; t < Tlen; t += 512) row[t] = sc[t] * inv;
   }
@@ -833,38 +768,31 @@ hipError_t launch_gemv(int dtype, const GemvArgs& a, hipStream_t st) {
   return dtype == 1 ? gemv_b<bf16_t>(a, st) : gemv_b<float>(a, st);
 }
 
-hipError_t launch_dec_self_attn(int dtype, const void* q, const void* kc, const void* vc, long long cache_bstride,
-                                void* out, int B, int H, int key_bound, const DecState* stt, hipStream_t st) {
-  // key_bound: an upper bound of pos+1 for this call known on the host (prompt + max new tokens), also <= cache rows
-  const bool fused = key_bound <= 256;
-  if (dtype == 1) {
-    if (fused)
-      hipLaunchKernelGGL((dec_self_attn_kernel<bf16_t, true>), dim3(H, B), dim3(256), 0, st, (const bf16_t*)q,
-                         (const bf16_t*)kc, (const bf16_t*)vc, cache_bstride, (bf16_t*)out, H, key_bound, stt);
-    else
-      hipLaunchKernelGGL((dec_self_attn_kernel<bf16_t, false>), dim3(H, B), dim3(256), 0, st, (const bf16_t*)q,
-                         (const bf16_t*)kc, (const bf16_t*)vc, cache_bstride, (bf16_t*)out, H, key_bound, stt);
-  } else {
-    if (fused)
-      hipLaunchKernelGGL((dec_self_attn_kernel<float, true>), dim3(H, B), dim3(256), 0, st, (const float*)q,
-                         (const float*)kc, (const float*)vc, cache_bstride, (float*)out, H, key_bound, stt);
-    else
-      hipLaunchKernelGGL((dec_self_attn_kernel<float, false>), dim3(H, B), dim3(256), 0, st, (const float*)q,
-                         (const float*)kc, (const float*)vc, cache_bstride, (float*)out, H, key_bound, stt);
-  }
+hipError_t launch_dec_self_attn(int dtype, const void* q, const void* kc, const void* vc, int rows, void* out, int B, int H,
+                                int key_bound, const DecState* stt, hipStream_t st) {
+  // key_bound: an upper bound of pos+1 for this call known on the host (prompt + max new tokens)
+  int kb = (key_bound + 63) / 64 * 64;
+  if (rows % 64 != 0 || rows > 512 || kb > rows) return hipErrorInvalidValue;
+  const bool single = kb <= 256;
+#define SA_GO(TT, SV) hipLaunchKernelGGL((dec_self_attn_kernel<TT, SV>), dim3(H, B), dim3(256), 0, st, (const TT*)q, (const TT*)kc, \
+                                         (const TT*)vc, rows, (TT*)out, H, kb, stt)
+  if (dtype == 1) { if (single) SA_GO(bf16_t, true); else SA_GO(bf16_t, false); }
+  else { if (single) SA_GO(float, true); else SA_GO(float, false); }
+#undef SA_GO
   return hipGetLastError();
 }
 
 hipError_t launch_dec_cross_attn(int dtype, const void* q, const void* ck, const void* cv, void* out, int B, int H,
-                                 int T, const int* align_slot_for_head, float* align, int Ha, int P,
+                                 int T, int Tp, const int* align_slot_for_head, float* align, int Ha, int P,
                                  const DecState* stt, hipStream_t st) {
-  const size_t lds = (size_t)T * sizeof(float);
-  if (dtype == 1)
-    hipLaunchKernelGGL(dec_cross_attn_kernel<bf16_t>, dim3(H, B), dim3(512), lds, st, (const bf16_t*)q,
-                       (const bf16_t*)ck, (const bf16_t*)cv, (bf16_t*)out, H, T, align_slot_for_head, align, Ha, P, stt);
-  else
-    hipLaunchKernelGGL(dec_cross_attn_kernel<float>, dim3(H, B), dim3(512), lds, st, (const float*)q, (const float*)ck,
-                       (const float*)cv, (float*)out, H, T, align_slot_for_head, align, Ha, P, stt);
+  if (Tp % 64 != 0 || Tp < T) return hipErrorInvalidValue;
+  const size_t lds = (size_t)Tp * sizeof(float);
+  const bool single = Tp <= 512;
+#define CA_GO(TT, SV) hipLaunchKernelGGL((dec_cross_attn_kernel<TT, SV>), dim3(H, B), dim3(512), lds, st, (const TT*)q, (const TT*)ck, \
+                                         (const TT*)cv, (TT*)out, H, T, Tp, align_slot_for_head, align, Ha, P, stt)
+  if (dtype == 1) { if (single) CA_GO(bf16_t, true); else CA_GO(bf16_t, false); }
+  else { if (single) CA_GO(float, true); else CA_GO(float, false); }
+#undef CA_GO
   return hipGetLastError();
 }
 

@@ -217,6 +217,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A, RowM
           T* o = reinterpret_cast<T*>(ep.out3) + ((long long)(bidx * ep.H + h) * 64 + dd) * ep.Tp + t;
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[(long long)r * ep.Tp] = ov.elem(r);
+        } else if (ep.mode == EPI_KV_CROSS) {
+          // decoder cross-attention operands, fragment-major per (stream, head) with Tp keys (tw_common.h)
+          const long long hb = (long long)(bidx * ep.H + h) * ep.Tp * 64;
+          if (seg == 0) {
+            ov.store(reinterpret_cast<T*>(ep.out) + hb + tw_kf_index<T>(t, dd));  // 4 dims of one key: one 16-B vector
+          } else {
+            T* o = reinterpret_cast<T*>(ep.out2) + hb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[tw_vtf_index<T>(t, dd + r)] = ov.elem(r);
+          }
         } else {
           T* base = reinterpret_cast<T*>(seg == 0 ? ep.out : ep.out2);
           ov.store(base + ((long long)(bidx * ep.H + h) * ep.T + t) * 64 + dd);

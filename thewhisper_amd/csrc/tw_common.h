@@ -57,6 +57,21 @@ __device__ __forceinline__ long long tw_xt_index(int stream, int k) {
   return ((long long)(k / (4 * E)) * 64 + ((k / E) & 3) * 16 + stream) * E + (k % E);
 }
 
+// Decoder K / V caches, per (stream, head), fragment-major for the single-query MFMA attention (k_decode.hip):
+//  K  : key tile t/16, dim step c/(4E): lane = ((c/E)&3)*16 + t%16 holds dims of one 16-B vector      (A operand of Q.K^T)
+//  V^T: key step t/(4E), dim tile c/16: lane = ((t/E)&3)*16 + c%16 holds E consecutive KEYS of dim c  (A operand of P.V)
+// 64 keys of either operand are one contiguous run of 64*64 elements.
+template <typename T>
+__device__ __forceinline__ long long tw_kf_index(int t, int c) {
+  constexpr int E = ElemTraits<T>::kPer16B;
+  return ((long long)((t >> 4) * (64 / (4 * E)) + c / (4 * E)) * 64 + ((c / E) & 3) * 16 + (t & 15)) * E + (c % E);
+}
+template <typename T>
+__device__ __forceinline__ long long tw_vtf_index(int t, int c) {
+  constexpr int E = ElemTraits<T>::kPer16B;
+  return ((long long)((t / (4 * E)) * 4 + (c >> 4)) * 64 + ((t / E) & 3) * 16 + (c & 15)) * E + (t % E);
+}
+
 // Affine map from a logical GEMM row m to an element offset:  (m / rpb) * bstride + (m % rpb) * rstride.
 // Lets one GEMM read convolution windows as overlapping rows of a padded token-major buffer and
 // write into padded / per-batch layouts without im2col copies.
@@ -146,6 +161,7 @@ struct GemvArgs {
   void* y; int ldy;              // output (T): fragment-major [16, N] with res or gelu, else row-major [B, ldy]; or
   float* y_f32;                  // float32 output [B, N] (logits) when non-null
   // optional KV-cache scatter for the fused self-attention QKV projection: rows [d,2d) -> kcache, [2d,3d) -> vcache
+  // (fragment-major per (stream, head): tw_kf_index / tw_vtf_index; cache_bstride = elements per stream = H * rows * 64)
   void* kcache; void* vcache; long long cache_bstride; int d_model; const DecState* stt;
   int rg;  // skinny path: 16-row tiles walked per workgroup (set by the launcher)
 };
@@ -156,14 +172,15 @@ hipError_t launch_tile_weights(int dtype, const void* src, void* dst, int N, int
 // weight preparation for the folded pre-LayerNorm: W <- Wsrc * g (may alias), gw, cb as above
 hipError_t launch_fold_ln(int dtype, void* W, const void* Wsrc, const void* g, const void* beta, const void* bias, float* gw,
                           float* cb, int N, int K, hipStream_t st);  // once per process: dynamic-LDS caps of the gemv instantiations
-// self attention over the growing cache: q [B,d]; kc/vc [B][P][d] (batch stride cache_bstride); out [B,d]
-// key_bound: host-known upper bound of pos+1 for this call (<= cache rows); <= 256 selects the single-round-trip kernel
-hipError_t launch_dec_self_attn(int dtype, const void* q, const void* kc, const void* vc, long long cache_bstride,
-                                void* out, int B, int H, int key_bound, const DecState* stt, hipStream_t st);
-// cross attention over cached encoder K/V: ck/cv [B,H,T,64]; out [B,d]; align rows: for head h with
-// align_slot[h] >= 0 write softmax row to align[((b*Ha + slot)*P + pos)*T + t]
+// self attention over the growing cache: q [B,d] row-major; kc/vc per (stream, head) `rows` (multiple of 64) keys, fragment-major
+// (tw_kf_index / tw_vtf_index); out [16,d] fragment-major (tw_xt_index).
+// key_bound: host-known upper bound of pos+1 for this call; <= 256 selects the single-round-trip kernel
+hipError_t launch_dec_self_attn(int dtype, const void* q, const void* kc, const void* vc, int rows, void* out, int B, int H,
+                                int key_bound, const DecState* stt, hipStream_t st);
+// cross attention over cached encoder K/V: ck/cv per (stream, head) Tp keys fragment-major; out fragment-major; align rows:
+// for head h with align_slot[h] >= 0 write the softmax row to align[((b*Ha + slot)*P + pos)*T + t]
 hipError_t launch_dec_cross_attn(int dtype, const void* q, const void* ck, const void* cv, void* out, int B, int H,
-                                 int T, const int* align_slot_for_head, float* align, int Ha, int P,
+                                 int T, int Tp, const int* align_slot_for_head, float* align, int Ha, int P,
                                  const DecState* stt, hipStream_t st);
 
 struct SamplerArgs {   // A10 + argmax + bookkeeping
