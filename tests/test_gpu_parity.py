@@ -96,6 +96,7 @@ DEC_CASES = [
     ("micro", 100, 3, "f32", 2, 2e-5), ("micro", 500, 1, "f32", 2, 2e-5), ("micro", 100, 8, "f32", 2, 2e-5),
     ("micro", 100, 16, "bf16", 2, 3e-2), ("large-v3", 500, 1, "f32", 1, 2e-5), ("large-v3", 500, 2, "bf16", 1, 3e-2),
     ("large-v3", 500, 16, "bf16", 1, 3e-2), ("tiny.en", 1500, 5, "f32", 4, 5e-5), ("micro", 100, 2, "f32", 0, 2e-5),
+    ("micro", 750, 2, "f32", 2, 2e-5), ("micro", 750, 3, "bf16", 2, 3e-2),   # 15 s chunks: two key chunks, second one partial
 ]
 
 
@@ -143,7 +144,7 @@ def test_logits_golden_reference_topk():
 
 # ---------------------------------------------------------------- A9-A11
 GREEDY_CASES = [("micro", 100, 1, 24, False, 0), ("micro", 100, 3, 24, True, 0), ("micro", 500, 2, 40, True, 40),
-                ("micro80", 100, 2, 24, False, 0), ("micro", 100, 16, 20, True, 0)]
+                ("micro80", 100, 2, 24, False, 0), ("micro", 100, 16, 20, True, 0), ("micro", 750, 2, 24, True, 0)]
 
 
 @pytest.mark.parametrize("preset,T,B,max_new,graph,min_new", GREEDY_CASES)
@@ -170,6 +171,35 @@ def test_greedy_ids_alignment_and_timestamps(preset, T, B, max_new, graph, min_n
         nf[1] = -(T // 2) - 1                                              # negative bound: HF slices from the end (seek loop)
     ts = eng.token_timestamps(B, 3, L, nf)
     assert np.abs(ts - wo.token_timestamps(ref["cross"], 3, nf)).max() <= 0.0201
+    eng.close()
+
+
+@pytest.mark.parametrize("timestamps", [False, True])
+def test_suppress_lists_match_oracle(timestamps):
+    """SuppressTokens / SuppressTokensAtBegin (HF:generation/logits_process.py:1816-1906): a suppress list that contains the
+    tokens an unconstrained run picks, so the mask has to change the result, plus ids at the bitmap word edges."""
+    dims = wo.PRESETS["micro"]
+    w = wo.make_weights(dims, 0)
+    eng = make_engine(dims, w, T=100, max_batch=2, dtype="f32", use_graph=True)
+    pcm = clips(100 * 320, 2)
+    mel = wo.log_mel(pcm, dims.n_mels)
+    om = wo.OracleWhisper(dims, w, T=100)
+    enc = om.encode(mel)
+    prompt = np.tile(np.array(PROMPT, dtype=np.int32), (2, 1))
+    free = wo.greedy_generate(om, enc, prompt, wo.GreedyOptions(max_new_tokens=12, timestamps=timestamps))
+    picked = sorted({int(t) for t in free["sequences"][:, prompt.shape[1]:].ravel() if t < 50257})
+    sup = tuple(picked[: max(1, len(picked) // 2)] + [0, 31, 32, 63, 64, 50256, 1234])
+    begin = (220, 50257) + tuple(picked[-1:])
+    opt = wo.GreedyOptions(max_new_tokens=12, timestamps=timestamps, suppress=sup, begin_suppress=begin)
+    ref = wo.greedy_generate(om, enc, prompt, opt)
+    assert not np.array_equal(ref["sequences"], free["sequences"])
+    eng.encode(torch.from_numpy(mel).cuda())
+    eng.cross_kv(2)
+    for _ in range(2):  # second call replays the captured step graph with the same bitmap buffer
+        out = eng.generate_greedy(prompt, max_new_tokens=12, timestamps=timestamps, suppress=sup, begin_suppress=begin)
+        assert np.array_equal(out["sequences"], ref["sequences"])
+    out = eng.generate_greedy(prompt, max_new_tokens=12, timestamps=timestamps)  # list removed again: bitmap is rebuilt per call
+    assert np.array_equal(out["sequences"], free["sequences"])
     eng.close()
 
 

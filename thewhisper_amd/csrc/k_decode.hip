@@ -214,7 +214,11 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (SK_MAXS <= 5 ? 4 : 2))) v
     for (int i = 0; i < SK_MAXS; ++i) wq[i] = sk_load_w<T>(wt + (long long)min(s0 + i, S - 1) * (64 * E));
   };
   auto load_x = [&](int s0) {            // fragment-major activations: lane (stream fr, k-group kq) of step s
+#ifdef TW_PROBE_XBCAST   // probe only: every lane reads the same 16 B (what would the kernel cost without activation traffic?)
+    const T* xt = x;
+#else
     const T* xt = x + (long long)lane * E;
+#endif
 #pragma unroll
     for (int i = 0; i < SK_MAXS; ++i) xq[i] = *reinterpret_cast<const u32x4_t*>(xt + (long long)min(s0 + i, S - 1) * (64 * E));
   };
@@ -542,32 +546,53 @@ __device__ __forceinline__ MaxIdx wave_best(MaxIdx x) {
   return x;
 }
 
+// static part of the mask (SuppressTokensLogitsProcessor list, HF:generation/logits_process.py:1869-1906) as a bitmap
+__global__ void suppress_bitmap_kernel(const int* __restrict__ list, int n, unsigned* __restrict__ bits, int V) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const int v = list[i];
+    if (v >= 0 && v < V) atomicOr(&bits[v >> 5], 1u << (v & 31));
+  }
+}
+
+// One workgroup per stream.  The 207-KB logits row is requested ONCE, before anything else (the requests depend on kernel
+// arguments only, not on the decoding state) and kept in registers for both passes; the early-outs (prompt phase, finished
+// stream) are decided at the end instead of branching around the loads.
 __global__ __launch_bounds__(1024) void sampler_kernel(SamplerArgs a) {
   __shared__ MaxIdx red_text[16], red_ts[16];
   __shared__ float red_sum[16];
-  __shared__ int s_choice;
+  __shared__ unsigned sbits[2048];
+  constexpr int MAXIT = 26;  // 26 * 1024 * 2 = 53248 >= vocab
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int V = a.V;
+  const float* lg = a.logits + (long long)b * V;
+  const int nwords = (V + 31) >> 5;
+  const bool vec_ok = (V <= MAXIT * 2048) && ((V & 1) == 0) && V >= 2;
+  float s0[MAXIT], s1[MAXIT];
+  const int v_last = max(V - 2, 0) & ~1;  // last even index with a full pair in the row
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {  // unconditional (clamped) requests, selected afterwards; unused when !vec_ok
+    const int v = (it * 1024 + tid) * 2;
+    const float2 x2 = *reinterpret_cast<const float2*>(lg + min(v, v_last));
+    s0[it] = x2.x;
+    s1[it] = x2.y;
+  }
+  const unsigned w0 = a.suppress_bits[min(tid, nwords - 1)], w1 = a.suppress_bits[min(tid + 1024, nwords - 1)];
+  __builtin_amdgcn_sched_barrier(0);
   const int pos = a.stt->pos;
   const int n_prompt = a.stt->n_prompt;
   const int cur_len = pos + 1;
   int* seq = a.seq + (long long)b * a.seq_ld;
-  if (cur_len < n_prompt) {  // still consuming the forced prompt
-    if (tid == 0) a.cur_ids[b] = seq[cur_len];
-    return;
-  }
-  if (a.finished[b]) {  // HF: finished rows keep receiving pad_token_id
-    if (tid == 0) { seq[cur_len] = a.pad; a.cur_ids[b] = a.pad; }
-    return;
-  }
-  const int V = a.V;
+  const bool in_prompt = cur_len < n_prompt;   // still consuming the forced prompt
+  const bool fin = a.finished[b] != 0;          // HF: finished rows keep receiving pad_token_id
   const bool first = (cur_len == n_prompt);
   const int n_new = cur_len - n_prompt;
   const int ts_begin = a.timestamps ? a.no_ts_id + 1 : V;
   // ---- mask description (uniform scalars) ----
   bool last_ts = false, penult_ts = true;
   int lastts_tok = -1;
-  if (a.timestamps) {
+  if (a.timestamps && !in_prompt) {
     last_ts = (n_new >= 1) && (seq[cur_len - 1] >= ts_begin);
     penult_ts = (n_new < 2) || (seq[cur_len - 2] >= ts_begin);
     lastts_tok = a.last_ts[b];
@@ -587,37 +612,12 @@ __global__ __launch_bounds__(1024) void sampler_kernel(SamplerArgs a) {
     if (a.max_initial_ts >= 0) e_lo = ts_begin + a.max_initial_ts + 1;
   }
   const bool mask_eos = n_new < a.min_new;
-  const float* lg = a.logits + (long long)b * V;
-  auto score = [&](int v) -> float {
-    bool masked = false;
-    if (mask_eos && v == a.eos) masked = true;
-    if (a.timestamps && v == a.no_ts_id) masked = true;
-    if (v >= b_lo && v < b_hi) masked = true;
-    if (v >= c_lo && v < c_hi) masked = true;
-    if (v < d_hi) masked = true;
-    if (v >= e_lo) masked = true;
-    if (first)
-      for (int i = 0; i < a.n_begin_suppress; ++i) masked |= (v == a.begin_suppress[i]);
-    for (int i = 0; i < a.n_suppress; ++i) masked |= (v == a.suppress[i]);
-    return masked ? -INFINITY : lg[v];
-  };
-  // ---- the row is read ONCE into registers (2 consecutive floats per thread and iteration, all loads in
-  //      flight together: the row is 207 KB, the kernel is latency-bound), then both passes run on registers ----
-  constexpr int MAXIT = 26;  // 26 * 1024 * 2 = 53248 >= vocab
-  const bool vec_ok = (V <= MAXIT * 2048) && ((V & 1) == 0);
-  float s0[MAXIT], s1[MAXIT];
-  if (vec_ok) {
-#pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
-      const int v = (it * 1024 + tid) * 2;
-      float2 x2 = make_float2(-INFINITY, -INFINITY);
-      if (v < V) x2 = *reinterpret_cast<const float2*>(lg + v);
-      s0[it] = x2.x;
-      s1[it] = x2.y;
-    }
-  }
+  sbits[tid] = w0;
+  sbits[tid + 1024] = w1;
+  __syncthreads();
   auto masked_at = [&](int v) -> bool {
-    bool masked = false;
+    const unsigned wbits = vec_ok ? sbits[v >> 5] : a.suppress_bits[v >> 5];
+    bool masked = ((wbits >> (v & 31)) & 1u) != 0;
     if (mask_eos && v == a.eos) masked = true;
     if (a.timestamps && v == a.no_ts_id) masked = true;
     if (v >= b_lo && v < b_hi) masked = true;
@@ -626,7 +626,6 @@ __global__ __launch_bounds__(1024) void sampler_kernel(SamplerArgs a) {
     if (v >= e_lo) masked = true;
     if (first)
       for (int i = 0; i < a.n_begin_suppress; ++i) masked |= (v == a.begin_suppress[i]);
-    for (int i = 0; i < a.n_suppress; ++i) masked |= (v == a.suppress[i]);
     return masked;
   };
   // ---- pass 1: best text token, best timestamp token ----
@@ -635,9 +634,11 @@ __global__ __launch_bounds__(1024) void sampler_kernel(SamplerArgs a) {
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
       const int v = (it * 1024 + tid) * 2;
-      if (v < V) {
-        if (masked_at(v)) s0[it] = -INFINITY;
-        if (masked_at(v + 1)) s1[it] = -INFINITY;
+      const bool in = v < V;
+      const int vc = in ? v : 0;
+      s0[it] = (in && !masked_at(vc)) ? s0[it] : -INFINITY;
+      s1[it] = (in && !masked_at(vc + 1)) ? s1[it] : -INFINITY;
+      if (in) {
         MaxIdx c0{s0[it], v}, c1{s1[it], v + 1};
         if (v < ts_begin) bt = better(bt, c0); else bs = better(bs, c0);
         if (v + 1 < ts_begin) bt = better(bt, c1); else bs = better(bs, c1);
@@ -645,8 +646,7 @@ __global__ __launch_bounds__(1024) void sampler_kernel(SamplerArgs a) {
     }
   } else {
     for (int v = tid; v < V; v += 1024) {
-      const float sc_ = score(v);
-      MaxIdx c{sc_, v};
+      MaxIdx c{masked_at(v) ? -INFINITY : lg[v], v};
       if (v < ts_begin) bt = better(bt, c); else bs = better(bs, c);
     }
   }
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(1024) void sampler_kernel(SamplerArgs a) {
         }
       }
     } else {
-      for (int v = ts_begin + tid; v < V; v += 1024) sum += expf(score(v) - bs.v);
+      for (int v = ts_begin + tid; v < V; v += 1024) sum += masked_at(v) ? 0.f : expf(lg[v] - bs.v);
     }
     sum = wave_sum(sum);
     if (lane == 0) red_sum[wave] = sum;
@@ -682,15 +682,21 @@ __global__ __launch_bounds__(1024) void sampler_kernel(SamplerArgs a) {
     force_ts = lse_ts > bt.v;
   }
   if (tid == 0) {
-    int choice;
-    if (force_ts) choice = bs.i;
-    else choice = (bs.v > bt.v) ? bs.i : bt.i;
-    if (choice == 0x7fffffff) choice = 0;  // everything masked: torch.argmax of all -inf is 0
-    seq[cur_len] = choice;
-    a.cur_ids[b] = choice;
-    if (a.timestamps && choice >= ts_begin) a.last_ts[b] = choice;
-    if (choice == a.eos) a.finished[b] = 1;
-    s_choice = choice;
+    if (in_prompt) {
+      a.cur_ids[b] = seq[cur_len];
+    } else if (fin) {
+      seq[cur_len] = a.pad;
+      a.cur_ids[b] = a.pad;
+    } else {
+      int choice;
+      if (force_ts) choice = bs.i;
+      else choice = (bs.v > bt.v) ? bs.i : bt.i;
+      if (choice == 0x7fffffff) choice = 0;  // everything masked: torch.argmax of all -inf is 0
+      seq[cur_len] = choice;
+      a.cur_ids[b] = choice;
+      if (a.timestamps && choice >= ts_begin) a.last_ts[b] = choice;
+      if (choice == a.eos) a.finished[b] = 1;
+    }
   }
 }
 
@@ -801,6 +807,13 @@ hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, a.stt);
+  return hipGetLastError();
+}
+
+hipError_t launch_suppress_bitmap(const int* list, int n, unsigned* bits, int V, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(bits, 0, (size_t)((V + 31) / 32) * 4, st);
+  if (e != hipSuccess || n <= 0) return e;
+  hipLaunchKernelGGL(suppress_bitmap_kernel, dim3((n + 255) / 256), dim3(256), 0, st, list, n, bits, V);
   return hipGetLastError();
 }
 

@@ -192,9 +192,10 @@ struct SamplerArgs {   // A10 + argmax + bookkeeping
   DecState* stt;
   int eos, pad, min_new, timestamps, no_ts_id, max_initial_ts;  // max_initial_ts < 0: unset
   const int* begin_suppress; int n_begin_suppress;
-  const int* suppress; int n_suppress;
+  const unsigned* suppress_bits;  // static suppress list as a V-bit map (launch_suppress_bitmap)
 };
 hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st);   // sampler + pos advance
+hipError_t launch_suppress_bitmap(const int* list, int n, unsigned* bits, int V, hipStream_t st);  // zero + set bits
 hipError_t launch_advance(DecState* stt, hipStream_t st);            // pos += 1 only (teacher-forced stepping)
 
 // A11: alignment rows -> token timestamps
