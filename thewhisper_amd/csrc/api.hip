@@ -70,6 +70,7 @@ struct tw_ctx {
   int *seq = nullptr, *cur_ids = nullptr, *finished = nullptr, *last_ts = nullptr;
   DecState* stt = nullptr;
   int* begin_suppress_dev = nullptr; int* suppress_dev = nullptr;
+  SamplerPartial* sampler_partials = nullptr;
   unsigned* suppress_bits = nullptr;  // [(V+31)/32] static suppress list as a bitmap, rebuilt per generate call
   int* h_pinned = nullptr;  // pinned host scratch: finished ring [8][Bmax] + misc
   hipEvent_t ring_ev[8]{};
@@ -337,6 +338,7 @@ int tw_create(const tw_config* cfg, tw_ctx** out) {
   CALLOC(c->last_ts, B * 4, true); CALLOC(c->stt, sizeof(DecState), true);
   CALLOC(c->begin_suppress_dev, 64 * 4, true); CALLOC(c->suppress_dev, 1024 * 4, true);
   CALLOC(c->suppress_bits, ((V + 31) / 32 + 2048) * 4, true);
+  CALLOC(c->sampler_partials, 16 * 8 * sizeof(SamplerPartial), true);
   // ---- dtw workspace ----
   CALLOC(c->zbuf, B * Ha * P * T * 4, false);
   CALLOC(c->mat, B * P * T * 4, false);
@@ -770,7 +772,7 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
   sa.eos = o->eos_id; sa.pad = o->pad_id; sa.min_new = o->min_new_tokens; sa.timestamps = o->timestamps;
   sa.no_ts_id = o->no_timestamps_id; sa.max_initial_ts = o->max_initial_timestamp_index;
   sa.begin_suppress = c->begin_suppress_dev; sa.n_begin_suppress = o->n_begin_suppress;
-  sa.suppress_bits = c->suppress_bits;
+  sa.suppress_bits = c->suppress_bits; sa.partials = c->sampler_partials;
 
   // ---- optional graph capture of one full step ----
   char keybuf[256];

@@ -555,99 +555,114 @@ __global__ void suppress_bitmap_kernel(const int* __restrict__ list, int n, unsi
   }
 }
 
-// One workgroup per stream.  The 207-KB logits row is requested ONCE, before anything else (the requests depend on kernel
-// arguments only, not on the decoding state) and kept in registers for both passes; the early-outs (prompt phase, finished
-// stream) are decided at the end instead of branching around the loads.
-__global__ __launch_bounds__(1024) void sampler_kernel(SamplerArgs a) {
-  __shared__ MaxIdx red_text[16], red_ts[16];
-  __shared__ float red_sum[16];
-  __shared__ unsigned sbits[2048];
-  constexpr int MAXIT = 26;  // 26 * 1024 * 2 = 53248 >= vocab
-  const int b = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// Sampling = Whisper's logits processors + first-index argmax (HF:generation/logits_process.py:1816-2047,
+// HF:generation/utils.py:2925), in two launches:
+//  * sampler_part_kernel: SAMPLER_NS workgroups per stream, each owning a slice of the vocabulary (one CU cannot evaluate
+//    the mask and the comparisons for 51866 logits in less than ~20 us - the work is VALU-, not memory-bound).  The slice
+//    is requested before anything else (addresses depend on kernel arguments only) and kept in registers for both
+//    passes.  Output per slice: best text token, best timestamp token, sum of exp(x - slice max) over timestamp tokens.
+//  * sampler_finish_kernel: ONE workgroup, wavefront b merges the slices of stream b (log-sum-exp merge), applies the
+//    "timestamp mass beats every text token" rule, appends the token, and thread 0 advances the position afterwards.
+constexpr int SAMPLER_NS = 8;
+constexpr int SAMPLER_IT = 13;  // float2 requests per thread: 13 * 256 * 2 * 8 = 53248 >= vocab
+
+struct SamplerMask {  // dynamic part of the mask: uniform scalars derived from the decoding state
+  int b_lo, b_hi, c_lo, c_hi, d_hi, e_lo, ts_begin;
+  bool mask_eos, first, in_prompt, fin;
+};
+
+__device__ __forceinline__ SamplerMask sampler_mask(const SamplerArgs& a, int b) {
+  SamplerMask k;
   const int V = a.V;
-  const float* lg = a.logits + (long long)b * V;
-  const int nwords = (V + 31) >> 5;
-  const bool vec_ok = (V <= MAXIT * 2048) && ((V & 1) == 0) && V >= 2;
-  float s0[MAXIT], s1[MAXIT];
-  const int v_last = max(V - 2, 0) & ~1;  // last even index with a full pair in the row
-#pragma unroll
-  for (int it = 0; it < MAXIT; ++it) {  // unconditional (clamped) requests, selected afterwards; unused when !vec_ok
-    const int v = (it * 1024 + tid) * 2;
-    const float2 x2 = *reinterpret_cast<const float2*>(lg + min(v, v_last));
-    s0[it] = x2.x;
-    s1[it] = x2.y;
-  }
-  const unsigned w0 = a.suppress_bits[min(tid, nwords - 1)], w1 = a.suppress_bits[min(tid + 1024, nwords - 1)];
-  __builtin_amdgcn_sched_barrier(0);
   const int pos = a.stt->pos;
   const int n_prompt = a.stt->n_prompt;
   const int cur_len = pos + 1;
-  int* seq = a.seq + (long long)b * a.seq_ld;
-  const bool in_prompt = cur_len < n_prompt;   // still consuming the forced prompt
-  const bool fin = a.finished[b] != 0;          // HF: finished rows keep receiving pad_token_id
-  const bool first = (cur_len == n_prompt);
+  const int* seq = a.seq + (long long)b * a.seq_ld;
+  k.in_prompt = cur_len < n_prompt;     // still consuming the forced prompt
+  k.fin = a.finished[b] != 0;           // HF: finished rows keep receiving pad_token_id
+  k.first = (cur_len == n_prompt);
   const int n_new = cur_len - n_prompt;
-  const int ts_begin = a.timestamps ? a.no_ts_id + 1 : V;
-  // ---- mask description (uniform scalars) ----
+  k.ts_begin = a.timestamps ? a.no_ts_id + 1 : V;
   bool last_ts = false, penult_ts = true;
   int lastts_tok = -1;
-  if (a.timestamps && !in_prompt) {
-    last_ts = (n_new >= 1) && (seq[cur_len - 1] >= ts_begin);
-    penult_ts = (n_new < 2) || (seq[cur_len - 2] >= ts_begin);
+  if (a.timestamps && !k.in_prompt) {
+    last_ts = (n_new >= 1) && (seq[cur_len - 1] >= k.ts_begin);
+    penult_ts = (n_new < 2) || (seq[cur_len - 2] >= k.ts_begin);
     lastts_tok = a.last_ts[b];
   }
-  int b_lo = 0, b_hi = 0;  // range masked by the pairing rule
+  k.b_lo = 0; k.b_hi = 0;  // range masked by the pairing rule
   if (last_ts) {
-    if (penult_ts) { b_lo = ts_begin; b_hi = V; } else { b_lo = 0; b_hi = a.eos; }
+    if (penult_ts) { k.b_lo = k.ts_begin; k.b_hi = V; } else { k.b_lo = 0; k.b_hi = a.eos; }
   }
-  int c_lo = 0, c_hi = 0;  // non-decreasing timestamps
+  k.c_lo = 0; k.c_hi = 0;  // non-decreasing timestamps
   if (a.timestamps && lastts_tok >= 0) {
-    c_lo = ts_begin;
-    c_hi = (last_ts && !penult_ts) ? lastts_tok : lastts_tok + 1;
+    k.c_lo = k.ts_begin;
+    k.c_hi = (last_ts && !penult_ts) ? lastts_tok : lastts_tok + 1;
   }
-  int d_hi = 0, e_lo = V;  // first sampled token must be a timestamp <= max_initial
-  if (a.timestamps && first) {
-    d_hi = ts_begin;
-    if (a.max_initial_ts >= 0) e_lo = ts_begin + a.max_initial_ts + 1;
+  k.d_hi = 0; k.e_lo = V;  // first sampled token must be a timestamp <= max_initial
+  if (a.timestamps && k.first) {
+    k.d_hi = k.ts_begin;
+    if (a.max_initial_ts >= 0) k.e_lo = k.ts_begin + a.max_initial_ts + 1;
   }
-  const bool mask_eos = n_new < a.min_new;
-  sbits[tid] = w0;
-  sbits[tid + 1024] = w1;
-  __syncthreads();
-  auto masked_at = [&](int v) -> bool {
-    const unsigned wbits = vec_ok ? sbits[v >> 5] : a.suppress_bits[v >> 5];
-    bool masked = ((wbits >> (v & 31)) & 1u) != 0;
-    if (mask_eos && v == a.eos) masked = true;
+  k.mask_eos = n_new < a.min_new;
+  return k;
+}
+
+__global__ __launch_bounds__(256) void sampler_part_kernel(SamplerArgs a) {
+  __shared__ MaxIdx red_text[4], red_ts[4];
+  __shared__ float red_sum[4];
+  const int part = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int V = a.V;
+  const float* lg = a.logits + (long long)b * V;
+  const int chunk = ((V + 2 * SAMPLER_NS - 1) / (2 * SAMPLER_NS)) * 2;  // even slice length
+  const int v0 = part * chunk, v1 = min(v0 + chunk, V);
+  const bool vec_ok = (chunk <= SAMPLER_IT * 512) && ((V & 1) == 0) && V >= 2;
+  const int v_last = max(V - 2, 0) & ~1;
+  float s0[SAMPLER_IT], s1[SAMPLER_IT];
+  unsigned wb[SAMPLER_IT];
+#pragma unroll
+  for (int it = 0; it < SAMPLER_IT; ++it) {  // unconditional (clamped) requests; the pair (v, v+1) shares one bitmap word
+    const int v = min(v0 + (it * 256 + tid) * 2, v_last);
+    const float2 x2 = *reinterpret_cast<const float2*>(lg + v);
+    s0[it] = x2.x;
+    s1[it] = x2.y;
+    wb[it] = a.suppress_bits[v >> 5];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const SamplerMask k = sampler_mask(a, b);
+  auto masked_at = [&](int v, unsigned word) -> bool {
+    bool masked = ((word >> (v & 31)) & 1u) != 0;
+    if (k.mask_eos && v == a.eos) masked = true;
     if (a.timestamps && v == a.no_ts_id) masked = true;
-    if (v >= b_lo && v < b_hi) masked = true;
-    if (v >= c_lo && v < c_hi) masked = true;
-    if (v < d_hi) masked = true;
-    if (v >= e_lo) masked = true;
-    if (first)
+    if (v >= k.b_lo && v < k.b_hi) masked = true;
+    if (v >= k.c_lo && v < k.c_hi) masked = true;
+    if (v < k.d_hi) masked = true;
+    if (v >= k.e_lo) masked = true;
+    if (k.first)
       for (int i = 0; i < a.n_begin_suppress; ++i) masked |= (v == a.begin_suppress[i]);
     return masked;
   };
-  // ---- pass 1: best text token, best timestamp token ----
+  // ---- pass 1: best text token, best timestamp token of the slice ----
   MaxIdx bt{-INFINITY, 0x7fffffff}, bs{-INFINITY, 0x7fffffff};
   if (vec_ok) {
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
-      const int v = (it * 1024 + tid) * 2;
-      const bool in = v < V;
+    for (int it = 0; it < SAMPLER_IT; ++it) {
+      const int v = v0 + (it * 256 + tid) * 2;
+      const bool in = v < v1;
       const int vc = in ? v : 0;
-      s0[it] = (in && !masked_at(vc)) ? s0[it] : -INFINITY;
-      s1[it] = (in && !masked_at(vc + 1)) ? s1[it] : -INFINITY;
+      s0[it] = (in && !masked_at(vc, wb[it])) ? s0[it] : -INFINITY;
+      s1[it] = (in && !masked_at(vc + 1, wb[it])) ? s1[it] : -INFINITY;
       if (in) {
         MaxIdx c0{s0[it], v}, c1{s1[it], v + 1};
-        if (v < ts_begin) bt = better(bt, c0); else bs = better(bs, c0);
-        if (v + 1 < ts_begin) bt = better(bt, c1); else bs = better(bs, c1);
+        if (v < k.ts_begin) bt = better(bt, c0); else bs = better(bs, c0);
+        if (v + 1 < k.ts_begin) bt = better(bt, c1); else bs = better(bs, c1);
       }
     }
   } else {
-    for (int v = tid; v < V; v += 1024) {
-      MaxIdx c{masked_at(v) ? -INFINITY : lg[v], v};
-      if (v < ts_begin) bt = better(bt, c); else bs = better(bs, c);
+    for (int v = v0 + tid; v < v1; v += 256) {
+      MaxIdx c{masked_at(v, a.suppress_bits[v >> 5]) ? -INFINITY : lg[v], v};
+      if (v < k.ts_begin) bt = better(bt, c); else bs = better(bs, c);
     }
   }
   bt = wave_best(bt);
@@ -656,48 +671,72 @@ __global__ __launch_bounds__(1024) void sampler_kernel(SamplerArgs a) {
   __syncthreads();
   bt = red_text[0];
   bs = red_ts[0];
-  for (int w = 1; w < 16; ++w) { bt = better(bt, red_text[w]); bs = better(bs, red_ts[w]); }
-  // ---- pass 2: logsumexp over timestamp tokens ----
-  bool force_ts = false;
+  for (int w = 1; w < 4; ++w) { bt = better(bt, red_text[w]); bs = better(bs, red_ts[w]); }
+  // ---- pass 2: sum of exp(x - slice max) over the slice's timestamp tokens ----
+  float sum = 0.f;
   if (a.timestamps && bs.v > -INFINITY) {
-    float sum = 0.f;
     if (vec_ok) {
 #pragma unroll
-      for (int it = 0; it < MAXIT; ++it) {
-        const int v = (it * 1024 + tid) * 2;
-        if (v < V) {
-          if (v >= ts_begin) sum += expf(s0[it] - bs.v);
-          if (v + 1 >= ts_begin) sum += expf(s1[it] - bs.v);
+      for (int it = 0; it < SAMPLER_IT; ++it) {
+        const int v = v0 + (it * 256 + tid) * 2;
+        if (v < v1) {
+          if (v >= k.ts_begin) sum += expf(s0[it] - bs.v);
+          if (v + 1 >= k.ts_begin) sum += expf(s1[it] - bs.v);
         }
       }
     } else {
-      for (int v = ts_begin + tid; v < V; v += 1024) sum += masked_at(v) ? 0.f : expf(lg[v] - bs.v);
+      for (int v = max(v0, k.ts_begin) + tid; v < v1; v += 256)
+        sum += masked_at(v, a.suppress_bits[v >> 5]) ? 0.f : expf(lg[v] - bs.v);
     }
-    sum = wave_sum(sum);
-    if (lane == 0) red_sum[wave] = sum;
-    __syncthreads();
-    float tot = 0.f;
-    for (int w = 0; w < 16; ++w) tot += red_sum[w];
-    const float lse_ts = bs.v + logf(tot);
-    force_ts = lse_ts > bt.v;
   }
+  sum = wave_sum(sum);
+  if (lane == 0) red_sum[wave] = sum;
+  __syncthreads();
   if (tid == 0) {
-    if (in_prompt) {
-      a.cur_ids[b] = seq[cur_len];
-    } else if (fin) {
-      seq[cur_len] = a.pad;
-      a.cur_ids[b] = a.pad;
-    } else {
-      int choice;
-      if (force_ts) choice = bs.i;
-      else choice = (bs.v > bt.v) ? bs.i : bt.i;
-      if (choice == 0x7fffffff) choice = 0;  // everything masked: torch.argmax of all -inf is 0
-      seq[cur_len] = choice;
-      a.cur_ids[b] = choice;
-      if (a.timestamps && choice >= ts_begin) a.last_ts[b] = choice;
-      if (choice == a.eos) a.finished[b] = 1;
+    SamplerPartial o;
+    o.bt_v = bt.v; o.bt_i = bt.i; o.bs_v = bs.v; o.bs_i = bs.i;
+    o.sum = red_sum[0] + red_sum[1] + red_sum[2] + red_sum[3];
+    a.partials[b * SAMPLER_NS + part] = o;
+  }
+}
+
+// wavefront b <- stream b; thread 0 advances the position once every wavefront has used it
+__global__ __launch_bounds__(1024) void sampler_finish_kernel(SamplerArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, b = tid >> 6;
+  if (b < a.B) {
+    const SamplerMask k = sampler_mask(a, b);
+    SamplerPartial p = a.partials[b * SAMPLER_NS + min(lane, SAMPLER_NS - 1)];
+    const bool on = lane < SAMPLER_NS;
+    MaxIdx bt{on ? p.bt_v : -INFINITY, on ? p.bt_i : 0x7fffffff}, bs{on ? p.bs_v : -INFINITY, on ? p.bs_i : 0x7fffffff};
+    const float my_m = bs.v;
+    bt = wave_best(bt);
+    bs = wave_best(bs);
+    float part_sum = (on && my_m > -INFINITY) ? p.sum * expf(my_m - bs.v) : 0.f;  // log-sum-exp merge of the slices
+    const float tot = wave_sum(part_sum);
+    bool force_ts = false;
+    if (a.timestamps && bs.v > -INFINITY) force_ts = (bs.v + logf(tot)) > bt.v;
+    if (lane == 0) {
+      const int cur_len = a.stt->pos + 1;
+      int* seq = a.seq + (long long)b * a.seq_ld;
+      if (k.in_prompt) {
+        a.cur_ids[b] = seq[cur_len];
+      } else if (k.fin) {
+        seq[cur_len] = a.pad;
+        a.cur_ids[b] = a.pad;
+      } else {
+        int choice;
+        if (force_ts) choice = bs.i;
+        else choice = (bs.v > bt.v) ? bs.i : bt.i;
+        if (choice == 0x7fffffff) choice = 0;  // everything masked: torch.argmax of all -inf is 0
+        seq[cur_len] = choice;
+        a.cur_ids[b] = choice;
+        if (a.timestamps && choice >= k.ts_begin) a.last_ts[b] = choice;
+        if (choice == a.eos) a.finished[b] = 1;
+      }
     }
   }
+  __syncthreads();
+  if (tid == 0) a.stt->pos += 1;
 }
 
 __global__ void advance_kernel(DecState* stt) { stt->pos += 1; }
@@ -803,10 +842,11 @@ hipError_t launch_dec_cross_attn(int dtype, const void* q, const void* ck, const
 }
 
 hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(sampler_kernel, dim3(a.B), dim3(1024), 0, st, a);
+  if (a.B < 1 || a.B > 16 || !a.partials || !a.suppress_bits) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(sampler_part_kernel, dim3(SAMPLER_NS, a.B), dim3(256), 0, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, a.stt);
+  hipLaunchKernelGGL(sampler_finish_kernel, dim3(1), dim3(1024), 0, st, a);  // also advances the position
   return hipGetLastError();
 }
 

@@ -183,6 +183,7 @@ hipError_t launch_dec_cross_attn(int dtype, const void* q, const void* ck, const
                                  int T, int Tp, const int* align_slot_for_head, float* align, int Ha, int P,
                                  const DecState* stt, hipStream_t st);
 
+struct SamplerPartial { float bt_v; int bt_i; float bs_v; int bs_i; float sum; int pad_[3]; };  // per vocabulary slice
 struct SamplerArgs {   // A10 + argmax + bookkeeping
   const float* logits; int V; int B;
   int* seq; int seq_ld;          // [B, seq_ld] token history (prompt included)
@@ -193,6 +194,7 @@ struct SamplerArgs {   // A10 + argmax + bookkeeping
   int eos, pad, min_new, timestamps, no_ts_id, max_initial_ts;  // max_initial_ts < 0: unset
   const int* begin_suppress; int n_begin_suppress;
   const unsigned* suppress_bits;  // static suppress list as a V-bit map (launch_suppress_bitmap)
+  SamplerPartial* partials;       // [B][8] workspace between the two sampler launches
 };
 hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st);   // sampler + pos advance
 hipError_t launch_suppress_bitmap(const int* list, int n, unsigned* bits, int V, hipStream_t st);  // zero + set bits
