@@ -196,7 +196,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=8)
-    ap.add_argument("--latency-iters", type=int, default=10)
+    ap.add_argument("--latency-iters", type=int, default=100, help="single-stream chunk calls timed for the p50 (after 10 warm-ups; SURVEY.md section 8d)")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -263,7 +263,8 @@ def main():
     # single-stream chunk latency (config 3 shape): same engine, B = 1
     lat = []
     if rank == 0 and args.latency_iters > 0:
-        step(1)
+        for _ in range(min(10, args.latency_iters)):   # warm-ups
+            step(1)
         for _ in range(args.latency_iters):
             torch.cuda.synchronize()
             a = time.perf_counter()
@@ -311,6 +312,7 @@ def main():
         if lat:
             lat.sort()
             result["p50_chunk_latency_ms"] = round(lat[len(lat) // 2], 2)
+            result["p90_chunk_latency_ms"] = round(lat[min(len(lat) - 1, (len(lat) * 9) // 10)], 2)
             result["chunk_latency_note"] = f"1 stream, {args.chunk_s} s chunk, {args.new_tokens} tokens + DTW, {len(lat)} calls"
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -33,7 +33,9 @@ extern "C" {
 #define TW_VERSION_STRING "thewhisper-gfx950 0.1.0"
 
 /* element types of caller buffers and of the context's compute mode */
-enum { TW_F32 = 0, TW_BF16 = 1, TW_F16 = 2 };
+enum { TW_F32 = 0, TW_BF16 = 1, TW_F16 = 2,
+       TW_BF16_MXFP8 = 3 /* context dtype only: bf16 activations / encoder, decoder projection weights as MXFP8 (OCP e4m3 +
+                            one power-of-two scale per 32 values) on v_mfma_scale_f32_16x16x128_f8f6f4; BASELINE config 5 */ };
 
 /* error codes */
 enum {
@@ -65,7 +67,7 @@ typedef struct tw_config {
                                     (R:thestage_speechkit/nvidia/asr_pipeline.py:15-27). */
   int32_t target_positions;      /* decoder positions, 448 */
   int32_t max_batch;             /* concurrent streams per call */
-  int32_t dtype;                 /* TW_BF16 (production) or TW_F32 (strict-parity mode) */
+  int32_t dtype;                 /* TW_BF16 (production), TW_F32 (strict-parity mode) or TW_BF16_MXFP8 (fp8 decoder weights) */
   int32_t n_align_heads;         /* alignment heads for word timestamps (generation_config.alignment_heads) */
   int32_t align_heads[2 * TW_MAX_ALIGN_HEADS]; /* (layer, head) pairs */
   int32_t device;                /* HIP device ordinal */

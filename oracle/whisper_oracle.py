@@ -322,6 +322,22 @@ class OracleWhisper:
     def _ln(self, x, name):
         return layer_norm(x, self.w[name + ".weight"], self.w[name + ".bias"])
 
+    # decoder projections go through these two hooks so that OracleWhisperMXFP8 can restate the quantised arithmetic
+    def _dec_proj(self, x, ln_name, lin_name, bias=True):
+        """pre-LayerNorm followed by a linear layer (HF:models/whisper/modeling_whisper.py:441-470)."""
+        memo = getattr(self, "_ln_memo", None)
+        if memo is None or memo[0] is not x or memo[1] != ln_name:  # q/k/v share one normalised input
+            memo = (x, ln_name, self._ln(x, ln_name))
+            self._ln_memo = memo
+        return self._lin(memo[2], lin_name, bias)
+
+    def _dec_lin(self, x, lin_name):
+        return self._lin(x, lin_name)
+
+    def _dec_logits(self, x):
+        d = "model.decoder"
+        return self._ln(x, d + ".layer_norm") @ self.w[d + ".embed_tokens.weight"].T  # tied proj_out (HF :965, :1080)
+
     def _heads(self, x):  # [B, n, d] -> [B, H, n, hd]
         b, n, _ = x.shape
         return x.reshape(b, n, self.dims.heads, self.dims.head_dim).transpose(0, 2, 1, 3)
@@ -405,33 +421,181 @@ class OracleWhisper:
             cross = [None] * len(want_cross)
         for i in range(self.dims.dec_layers):
             p = f"{d}.layers.{i}"
-            h_ = self._ln(x, p + ".self_attn_layer_norm")
-            q = self._heads(self._lin(h_, p + ".self_attn.q_proj") * scale)
-            k = self._heads(self._lin(h_, p + ".self_attn.k_proj", bias=False))
-            v = self._heads(self._lin(h_, p + ".self_attn.v_proj"))
+            ln = p + ".self_attn_layer_norm"
+            q = self._heads(self._dec_proj(x, ln, p + ".self_attn.q_proj") * scale)
+            k = self._heads(self._dec_proj(x, ln, p + ".self_attn.k_proj", bias=False))
+            v = self._heads(self._dec_proj(x, ln, p + ".self_attn.v_proj"))
             cache.self_k[i] = np.concatenate([cache.self_k[i], k], axis=2)
             cache.self_v[i] = np.concatenate([cache.self_v[i], v], axis=2)
             s = q @ cache.self_k[i].transpose(0, 1, 3, 2) + causal[None, None]
             a = softmax(s) @ cache.self_v[i]
-            x = x + self._lin(self._merge(a), p + ".self_attn.out_proj")
-            h_ = self._ln(x, p + ".encoder_attn_layer_norm")
-            q = self._heads(self._lin(h_, p + ".encoder_attn.q_proj") * scale)
+            x = x + self._dec_lin(self._merge(a), p + ".self_attn.out_proj")
+            q = self._heads(self._dec_proj(x, p + ".encoder_attn_layer_norm", p + ".encoder_attn.q_proj") * scale)
             pr = softmax(q @ cache.cross_k[i].transpose(0, 1, 3, 2))
             if i in want:
                 for j, hh in want[i]:
                     cross[j] = pr[:, hh]  # [B, n, T]
             a = pr @ cache.cross_v[i]
-            x = x + self._lin(self._merge(a), p + ".encoder_attn.out_proj")
-            h_ = self._ln(x, p + ".final_layer_norm")
-            h_ = gelu(self._lin(h_, p + ".fc1"))
-            x = (x + self._lin(h_, p + ".fc2")).astype(self.dtype)
+            x = x + self._dec_lin(self._merge(a), p + ".encoder_attn.out_proj")
+            h_ = gelu(self._dec_proj(x, p + ".final_layer_norm", p + ".fc1"))
+            x = (x + self._dec_lin(h_, p + ".fc2")).astype(self.dtype)
         cache.length = past + n
-        x = self._ln(x, d + ".layer_norm")
-        logits = x @ self.w[d + ".embed_tokens.weight"].T  # tied proj_out (HF :965, :1080)
+        logits = self._dec_logits(x)
         cross_out = None
         if cross is not None:
             cross_out = np.stack(cross, axis=1)  # [B, Ha, n, T]
         return logits, cross_out
+
+
+# --------------------------------------------------------------------------------------
+# BASELINE config 5: MXFP8 decoder projections (restates thewhisper_amd/csrc/k_decode.hip: sk_quant_mx8,
+# quant_mx8_kernel, skinny_mfma_kernel<W8>; there is no reference implementation of this mode - the
+# reference's fp8 engines are closed TensorRT plans, R:thestage_speechkit/nvidia/asr_pipeline.py:48-56)
+# --------------------------------------------------------------------------------------
+
+
+def bf16_round(x: np.ndarray) -> np.ndarray:
+    """float32 -> nearest bfloat16 (ties to even) -> float32."""
+    u = np.asarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def e4m3_rne(v: np.ndarray) -> np.ndarray:
+    """Round to the OCP e4m3 grid, ties to even; valid for |v| < 256 (callers scale into that range)."""
+    v = np.asarray(v, dtype=np.float64)
+    a = np.abs(v)
+    e = np.floor(np.log2(np.maximum(a, 2.0**-6)))  # binade (values below the smallest normal share the subnormal spacing)
+    step = 2.0 ** (e - 3)
+    return np.sign(v) * np.rint(a / step) * step
+
+
+def mx8_quant_dequant(x: np.ndarray) -> np.ndarray:
+    """Quantise-dequantise the last axis (K, multiple of 128) in the blocks of 32 that the gfx950 scaled MFMA scales
+    together under the engine's operand layout: within each 128-wide step, k = (2h + mm) * 32 + (2u + kk) * 8 + e with
+    mm, kk in {0, 1}, e < 8 form block (h, u) (thewhisper_amd/csrc/k_decode.hip: sk_quant_mx8).  Scale = 2^(E - 7 - 127)
+    with E the biased exponent of the block maximum (one exponent above the OCP MX convention: the hardware convert does
+    not saturate), elements RNE to e4m3."""
+    x = np.asarray(x, dtype=np.float32)
+    K = x.shape[-1]
+    assert K % 128 == 0
+    lead = x.shape[:-1]
+    v = x.reshape(*lead, K // 128, 2, 2, 2, 2, 8)  # [.., s, h, mm, u, kk, e]
+    amax = np.abs(v).max(axis=(-4, -2, -1), keepdims=True)  # over (mm, kk, e) for each (s, h, u)
+    Eb = np.floor(np.log2(np.maximum(amax, 2.0**-126))).astype(np.int64) + 127
+    sb = np.maximum(Eb - 7, 1)
+    X = np.ldexp(1.0, sb - 127)
+    q = e4m3_rne(v.astype(np.float64) / X)
+    return (q * X).astype(np.float32).reshape(x.shape)
+
+
+class OracleWhisperMXFP8(OracleWhisper):
+    """bf16 activations, decoder projection weights in MXFP8 with the pre-LayerNorm folded into the weights, as the
+    TW_BF16_MXFP8 engine computes:  y = rstd * (Q(x) . Q(W')^T - mean * gW) + cb,  W' = bf16(g * W)."""
+
+    def __init__(self, dims, weights, T=None):
+        super().__init__(dims, weights, T=T, dtype=np.float32)
+        self._fold_cache: Dict[Tuple[str, str], Tuple[np.ndarray, np.ndarray, np.ndarray]] = {}
+        self._wq_cache: Dict[str, np.ndarray] = {}
+
+    def _folded(self, ln_name, w_name, b_name):
+        key = (ln_name, w_name)
+        if key not in self._fold_cache:
+            g = bf16_round(self.w[ln_name + ".weight"])
+            beta = bf16_round(self.w[ln_name + ".bias"])
+            W = bf16_round(self.w[w_name])
+            Wf = bf16_round(W * g[None, :])
+            gw = (W.astype(np.float64) @ g.astype(np.float64)).astype(np.float32)
+            cb = W.astype(np.float64) @ beta.astype(np.float64)
+            if b_name is not None:
+                cb = cb + bf16_round(self.w[b_name]).astype(np.float64)
+            self._fold_cache[key] = (mx8_quant_dequant(Wf), gw, cb.astype(np.float32))
+        return self._fold_cache[key]
+
+    def _folded_apply(self, x, ln_name, w_name, b_name):
+        xb = bf16_round(x)
+        Wq, gw, cb = self._folded(ln_name, w_name, b_name)
+        mean = xb.mean(axis=-1, keepdims=True)
+        var = np.maximum((xb.astype(np.float64) ** 2).mean(axis=-1, keepdims=True) - mean.astype(np.float64) ** 2, 0.0)
+        rstd = (1.0 / np.sqrt(var + 1e-5)).astype(np.float32)
+        acc = mx8_quant_dequant(xb) @ Wq.T
+        return rstd * (acc - mean * gw) + cb
+
+    def _dec_proj(self, x, ln_name, lin_name, bias=True):
+        return self._folded_apply(x, ln_name, lin_name + ".weight", lin_name + ".bias" if bias else None)
+
+    def _dec_lin(self, x, lin_name):
+        if lin_name not in self._wq_cache:
+            self._wq_cache[lin_name] = mx8_quant_dequant(bf16_round(self.w[lin_name + ".weight"]))
+        return mx8_quant_dequant(bf16_round(x)) @ self._wq_cache[lin_name].T + bf16_round(self.w[lin_name + ".bias"])
+
+    def _dec_logits(self, x):
+        d = "model.decoder"
+        return self._folded_apply(x, d + ".layer_norm", d + ".embed_tokens.weight", None)
+
+    def new_cache(self, enc):
+        """Cross K/V as the engine's bf16 GEMM produces them: bf16 encoder states x bf16 weights, fp32 accumulation, bf16 store."""
+        r = bf16_round
+        e = r(enc)
+        ck, cv = [], []
+        for i in range(self.dims.dec_layers):
+            p = f"model.decoder.layers.{i}.encoder_attn"
+            ck.append(self._heads(r(e @ r(self.w[p + ".k_proj.weight"]).T)))
+            cv.append(self._heads(r(e @ r(self.w[p + ".v_proj.weight"]).T + r(self.w[p + ".v_proj.bias"]))))
+        b = enc.shape[0]
+        empty = lambda: np.zeros((b, self.dims.heads, 0, self.dims.head_dim), dtype=np.float32)  # noqa: E731
+        L = self.dims.dec_layers
+        return DecoderCache([empty() for _ in range(L)], [empty() for _ in range(L)], ck, cv, 0)
+
+    @staticmethod
+    def _attend(q, K, V, mask=None):
+        """softmax(q K^T) V the way the decode attention kernels evaluate it: fp32 scores, unnormalised probabilities
+        rounded to bf16 for the P.V product, fp32 sum of the unrounded probabilities as the normaliser."""
+        sc = q @ K.transpose(0, 1, 3, 2)
+        if mask is not None:
+            sc = sc + mask
+        p = np.exp(sc - sc.max(axis=-1, keepdims=True))
+        return (bf16_round(p) @ V) / p.sum(axis=-1, keepdims=True), p / p.sum(axis=-1, keepdims=True)
+
+    def decode(self, ids, cache, want_cross=None):
+        """Same dataflow as OracleWhisper.decode with the engine's storage roundings made explicit: every tensor the
+        TW_BF16_MXFP8 engine keeps in HBM (residual stream, q/k/v, attention outputs, FFN hidden) is rounded to bf16 where
+        the engine rounds it, so that the fp8 quantiser sees the same inputs (a value that bf16 rounding moves across an
+        e4m3 rounding boundary would otherwise change by a whole fp8 step)."""
+        ids = np.asarray(ids)
+        b, n = ids.shape
+        past = cache.length
+        d = "model.decoder"
+        r = bf16_round
+        x = r(r(self.w[d + ".embed_tokens.weight"])[ids] + r(self.w[d + ".embed_positions.weight"])[past : past + n][None])
+        scale = np.float32(self.dims.head_dim**-0.5)
+        causal = np.triu(np.full((n, past + n), -np.inf, dtype=np.float32), k=past + 1)
+        cross = [None] * len(want_cross) if want_cross is not None else None
+        want = {}
+        if want_cross is not None:
+            for j, (l, h) in enumerate(want_cross):
+                want.setdefault(int(l), []).append((j, int(h)))
+        for i in range(self.dims.dec_layers):
+            p = f"{d}.layers.{i}"
+            ln = p + ".self_attn_layer_norm"
+            q = self._heads(r(self._dec_proj(x, ln, p + ".self_attn.q_proj") * scale))
+            k = self._heads(r(self._dec_proj(x, ln, p + ".self_attn.k_proj", bias=False)))
+            v = self._heads(r(self._dec_proj(x, ln, p + ".self_attn.v_proj")))
+            cache.self_k[i] = np.concatenate([cache.self_k[i], k], axis=2)
+            cache.self_v[i] = np.concatenate([cache.self_v[i], v], axis=2)
+            a, _ = self._attend(q, cache.self_k[i], cache.self_v[i], causal[None, None])
+            x = r(x + self._dec_lin(r(self._merge(a)), p + ".self_attn.out_proj"))
+            q = self._heads(r(self._dec_proj(x, p + ".encoder_attn_layer_norm", p + ".encoder_attn.q_proj") * scale))
+            a, pr = self._attend(q, r(cache.cross_k[i]), r(cache.cross_v[i]))
+            if i in want:
+                for j, hh in want[i]:
+                    cross[j] = pr[:, hh]
+            x = r(x + self._dec_lin(r(self._merge(a)), p + ".encoder_attn.out_proj"))
+            h_ = r(gelu(self._dec_proj(x, p + ".final_layer_norm", p + ".fc1")))
+            x = r(x + self._dec_lin(h_, p + ".fc2"))
+        cache.length = past + n
+        logits = self._dec_logits(x)
+        return logits, (np.stack(cross, axis=1) if cross is not None else None)
 
 
 # --------------------------------------------------------------------------------------

@@ -125,6 +125,65 @@ def test_decoder_teacher_forced(preset, T, B, dtype, layers, tol):
     eng.close()
 
 
+FP8_CASES = [("micro", 100, 3, 0), ("micro", 100, 3, 1), ("micro", 100, 16, 2), ("large-v3", 500, 2, 1), ("tiny.en", 1500, 1, 2)]
+
+
+@pytest.mark.parametrize("preset,T,B,layers", FP8_CASES)
+def test_decoder_mxfp8_teacher_forced(preset, T, B, layers):
+    """BASELINE config 5: decoder projection weights in MXFP8 on v_mfma_scale_f32_16x16x128_f8f6f4.  Checked against the
+    numpy restatement of the same quantised arithmetic and against the unquantised f32 oracle (fp8 noise budget).
+    Quantisation is chaotic: a 1-ulp bf16 difference upstream (fp32 summation order in the cross-K/V GEMM or a softmax)
+    moves a value across an e4m3 rounding boundary and changes it by 6 %, so only the first token through at most one
+    decoder layer reproduces the restatement to rounding error; deeper/later comparisons share the quantised weights but
+    decorrelate in the activations and are held to the fp8 noise level instead."""
+    dims = dims_variant(preset, enc_layers=1, dec_layers=layers)
+    w = wo.make_weights(dims, 2)
+    eng = make_engine(dims, w, T=T, max_batch=B, dtype="fp8")
+    mel = wo.log_mel(clips(T * 320, B), dims.n_mels)
+    om = wo.OracleWhisper(dims, w, T=T)
+    oq = wo.OracleWhisperMXFP8(dims, w, T=T)
+    # the decoder is compared on the ENGINE's encoder states (bf16): see the docstring
+    enc = eng.encode(torch.from_numpy(mel).cuda(), return_hidden=True).cpu().numpy()
+    eng.cross_kv(B)
+    eng.decoder_reset(B)
+    ids = np.concatenate([np.tile(np.array(PROMPT), (B, 1)), np.random.default_rng(3).integers(0, 50000, size=(B, 3))], axis=1)
+    cache, cache_q = om.new_cache(enc), oq.new_cache(enc)
+    for s in range(ids.shape[1]):
+        ref = om.decode(ids[:, s : s + 1], cache)[0][:, 0]
+        refq = oq.decode(ids[:, s : s + 1], cache_q)[0][:, 0]
+        got = eng.decode_step(ids[:, s].tolist()).cpu().numpy()
+        if preset == "micro" and layers <= 1 and s == 0:
+            assert rel_l2(got, refq) < 2e-3, rel_l2(got, refq)     # bit-level agreement of layouts, scales, roundings
+        assert rel_l2(got, refq) < 6e-2, (s, rel_l2(got, refq))
+        assert rel_l2(got, ref) < 1e-1, (s, rel_l2(got, ref))       # fp8 (W8A8) quantisation noise vs exact arithmetic
+        assert rel_l2(refq, ref) > 1e-2                             # ... which the restatement does model
+        srt = np.sort(ref, axis=-1)
+        clear = (srt[:, -1] - srt[:, -2]) > 1.0
+        assert np.array_equal(got.argmax(-1)[clear], ref.argmax(-1)[clear])
+    eng.close()
+
+
+def test_mxfp8_greedy_generation_runs_and_is_deterministic():
+    """The fp8 context runs the whole path (graph replay, sampler, alignment, DTW); ids are deterministic across calls and
+    batch positions (there is no reference for fp8 token ids: with random weights they legitimately differ from bf16)."""
+    dims = wo.PRESETS["micro"]
+    w = wo.make_weights(dims, 0)
+    heads = [(dims.dec_layers - 1, 0), (dims.dec_layers - 1, 1)]
+    eng = make_engine(dims, w, T=750, max_batch=4, dtype="fp8", heads=heads, use_graph=True)
+    pcm = np.tile(clips(750 * 320, 1), (4, 1))
+    eng.encode(eng.logmel(torch.from_numpy(pcm).cuda()))
+    eng.cross_kv(4)
+    prompt = np.tile(np.array(PROMPT, dtype=np.int32), (4, 1))
+    a = eng.generate_greedy(prompt, max_new_tokens=20, min_new_tokens=20, timestamps=True, want_alignment=True)
+    b = eng.generate_greedy(prompt, max_new_tokens=20, min_new_tokens=20, timestamps=True, want_alignment=True)
+    assert np.array_equal(a["sequences"], b["sequences"])
+    assert all(np.array_equal(a["sequences"][0], a["sequences"][i]) for i in range(1, 4))   # same clip in every stream
+    L = int(a["length"])
+    ts = eng.token_timestamps(4, 3, L, [1500] * 4)
+    assert np.all(np.diff(ts[:, 3:L], axis=1) >= 0) and ts.max() <= 15.0 + 1e-6
+    eng.close()
+
+
 def test_logits_golden_reference_topk():
     z = np.load(os.path.join(GOLD, "micro_c10.npz"))
     meta = json.load(open(os.path.join(GOLD, "pipeline_golden.json")))["micro_c10"]

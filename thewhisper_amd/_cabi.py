@@ -13,6 +13,7 @@ from typing import Optional
 from . import build as _build
 
 TW_F32, TW_BF16, TW_F16 = 0, 1, 2
+TW_BF16_MXFP8 = 3  # context dtype only: bf16 activations, MXFP8 decoder projection weights
 TW_MAX_ALIGN_HEADS = 32
 
 

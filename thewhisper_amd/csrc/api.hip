@@ -18,6 +18,8 @@ thread_local std::string g_create_error;
 struct LayerW {
   void *ln1_g = nullptr, *ln1_b = nullptr;  // self_attn_layer_norm
   void *wqkv = nullptr, *bqkv = nullptr;    // [3d, d], [3d] (q rows pre-scaled by 1/8, k bias = 0)
+  // MXFP8 contexts: block scales of the six decoder projections (inside the weight buffers, behind the fp8 fragments)
+  unsigned char *s_qkv = nullptr, *s_o = nullptr, *s_qc = nullptr, *s_oc = nullptr, *s_1 = nullptr, *s_2 = nullptr;
   void *wo = nullptr, *bo = nullptr;
   void *lnx_g = nullptr, *lnx_b = nullptr;  // encoder_attn_layer_norm (decoder)
   void *wq_c = nullptr, *bq_c = nullptr;    // cross q (pre-scaled)
@@ -34,6 +36,8 @@ struct LayerW {
 struct tw_ctx {
   tw_config cfg{};
   int dtype = 1;
+  bool w8 = false;   // decoder projection weights in MXFP8 (TW_BF16_MXFP8 contexts)
+  unsigned char* logit_ws = nullptr;  // block scales of logit_w
   size_t esz = 2;
   int d = 0, H = 0, ffn = 0, V = 0, T = 0, Tp = 0, P = 0, C = 0, Bmax = 0, Le = 0, Ld = 0, n_mels = 0, Ha = 0;
   std::string err;
@@ -204,7 +208,10 @@ int tw_create(const tw_config* cfg, tw_ctx** out) {
   *out = nullptr;
   if (cfg->heads <= 0 || cfg->d_model != cfg->heads * 64)
     return fail(nullptr, TW_EINVAL, "head_dim must be 64 (d_model=%d heads=%d)", cfg->d_model, cfg->heads);
-  if (cfg->dtype != TW_BF16 && cfg->dtype != TW_F32) return fail(nullptr, TW_EINVAL, "dtype must be TW_BF16 or TW_F32");
+  if (cfg->dtype != TW_BF16 && cfg->dtype != TW_F32 && cfg->dtype != TW_BF16_MXFP8)
+    return fail(nullptr, TW_EINVAL, "dtype must be TW_BF16, TW_F32 or TW_BF16_MXFP8");
+  if (cfg->dtype == TW_BF16_MXFP8 && (cfg->d_model % 128 || cfg->ffn % 128))
+    return fail(nullptr, TW_EINVAL, "TW_BF16_MXFP8 needs d_model and ffn to be multiples of 128");
   if (cfg->d_model % 64 || cfg->ffn % 64 || cfg->d_model > 1280)
     return fail(nullptr, TW_EINVAL, "d_model/ffn must be multiples of 64 and d_model <= 1280");
   if (cfg->max_batch < 1 || cfg->max_batch > 16) return fail(nullptr, TW_EINVAL, "max_batch must be in [1,16]");
@@ -220,8 +227,9 @@ int tw_create(const tw_config* cfg, tw_ctx** out) {
 
   tw_ctx* c = new tw_ctx();
   c->cfg = *cfg;
-  c->dtype = cfg->dtype;
-  c->esz = cfg->dtype == TW_BF16 ? 2 : 4;
+  c->w8 = cfg->dtype == TW_BF16_MXFP8;
+  c->dtype = c->w8 ? (int)TW_BF16 : cfg->dtype;
+  c->esz = c->dtype == TW_BF16 ? 2 : 4;
   c->d = cfg->d_model; c->H = cfg->heads; c->ffn = cfg->ffn; c->V = cfg->vocab;
   c->T = cfg->source_positions; c->Tp = (c->T + 63) / 64 * 64; c->P = cfg->target_positions;
   c->n_mels = cfg->n_mels; c->C = (cfg->n_mels + 63) / 64 * 64;
@@ -485,22 +493,31 @@ int tw_finalize_weights(tw_ctx* c, void* stream) {
     if ((size_t)c->ffn * c->d > mx) mx = (size_t)c->ffn * c->d;
     void* scratch = nullptr;
     HIPCHK(c, hipMalloc(&scratch, mx * e));
-    auto retile = [&](void* w, int N, int K) -> int {
-      HIPCHK(c, launch_tile_weights(c->dtype, w, scratch, N, K, st));
-      HIPCHK(c, hipMemcpyAsync(w, scratch, (size_t)((N + 15) / 16 * 16) * K * e, hipMemcpyDeviceToDevice, st));
+    auto retile = [&](void* w, int N, int K, unsigned char** scales) -> int {
+      const size_t Np = (size_t)(N + 15) / 16 * 16;
+      if (c->w8) {  // MXFP8 fragments + block scales replace the bf16 rows in the same buffer (half the bytes + 1/32)
+        unsigned char* sc = reinterpret_cast<unsigned char*>(scratch);
+        HIPCHK(c, launch_quant_mx8(w, sc, sc + Np * K, N, K, st));
+        HIPCHK(c, hipMemcpyAsync(w, scratch, Np * K + Np * K / 32, hipMemcpyDeviceToDevice, st));
+        *scales = reinterpret_cast<unsigned char*>(w) + Np * K;
+      } else {
+        HIPCHK(c, launch_tile_weights(c->dtype, w, scratch, N, K, st));
+        HIPCHK(c, hipMemcpyAsync(w, scratch, Np * K * e, hipMemcpyDeviceToDevice, st));
+        *scales = nullptr;
+      }
       return TW_OK;
     };
     int r = TW_OK;
     for (int l = 0; l < c->Ld && r == TW_OK; ++l) {
       LayerW& L = c->dec[l];
-      if ((r = retile(L.wqkv, 3 * c->d, c->d)) != TW_OK) break;
-      if ((r = retile(L.wo, c->d, c->d)) != TW_OK) break;
-      if ((r = retile(L.wq_c, c->d, c->d)) != TW_OK) break;
-      if ((r = retile(L.wo_c, c->d, c->d)) != TW_OK) break;
-      if ((r = retile(L.w1, c->ffn, c->d)) != TW_OK) break;
-      if ((r = retile(L.w2, c->d, c->ffn)) != TW_OK) break;
+      if ((r = retile(L.wqkv, 3 * c->d, c->d, &L.s_qkv)) != TW_OK) break;
+      if ((r = retile(L.wo, c->d, c->d, &L.s_o)) != TW_OK) break;
+      if ((r = retile(L.wq_c, c->d, c->d, &L.s_qc)) != TW_OK) break;
+      if ((r = retile(L.wo_c, c->d, c->d, &L.s_oc)) != TW_OK) break;
+      if ((r = retile(L.w1, c->ffn, c->d, &L.s_1)) != TW_OK) break;
+      if ((r = retile(L.w2, c->d, c->ffn, &L.s_2)) != TW_OK) break;
     }
-    if (r == TW_OK) r = retile(c->logit_w, c->V, c->d);
+    if (r == TW_OK) r = retile(c->logit_w, c->V, c->d, &c->logit_ws);
     hipError_t he = hipStreamSynchronize(st);
     hipFree(scratch);
     if (r != TW_OK) return r;
@@ -643,20 +660,20 @@ int decode_core(tw_ctx* c, int B, hipStream_t st) {
     void* sv = at(c->self_v, self_layer * l, e);
     {  // LN + fused QKV; k,v rows go straight into the cache at position pos
       GemvArgs a{};
-      a.x = xin; a.ldx = d; a.ln_gw = L.qkv_gw; a.ln_cb = L.qkv_cb; a.W = L.wqkv; a.N = 3 * d; a.K = d; a.B = B;
+      a.x = xin; a.ldx = d; a.ln_gw = L.qkv_gw; a.ln_cb = L.qkv_cb; a.W = L.wqkv; a.wscale = L.s_qkv; a.N = 3 * d; a.K = d; a.B = B;
       a.y = c->dq; a.ldy = d; a.kcache = sk; a.vcache = sv; a.cache_bstride = (long long)Pp * d; a.d_model = d; a.stt = c->stt;
       HIPCHK(c, launch_gemv(dt, a, st));
     }
     HIPCHK(c, launch_dec_self_attn(dt, c->dq, sk, sv, Pp, c->datt, B, H, c->dec_key_bound > 0 ? c->dec_key_bound : P, c->stt, st));
     {
       GemvArgs a{};
-      a.x = c->datt; a.ldx = d; a.W = L.wo; a.bias = L.bo; a.N = d; a.K = d; a.B = B; a.res = xin; a.ldres = d;
+      a.x = c->datt; a.ldx = d; a.W = L.wo; a.wscale = L.s_o; a.bias = L.bo; a.N = d; a.K = d; a.B = B; a.res = xin; a.ldres = d;
       a.y = xmid; a.ldy = d;
       HIPCHK(c, launch_gemv(dt, a, st));
     }
     {
       GemvArgs a{};
-      a.x = xmid; a.ldx = d; a.ln_gw = L.qc_gw; a.ln_cb = L.qc_cb; a.W = L.wq_c; a.N = d; a.K = d; a.B = B;
+      a.x = xmid; a.ldx = d; a.ln_gw = L.qc_gw; a.ln_cb = L.qc_cb; a.W = L.wq_c; a.wscale = L.s_qc; a.N = d; a.K = d; a.B = B;
       a.y = c->dq; a.ldy = d;
       HIPCHK(c, launch_gemv(dt, a, st));
     }
@@ -665,19 +682,19 @@ int decode_core(tw_ctx* c, int B, hipStream_t st) {
                                     P, c->stt, st));
     {
       GemvArgs a{};
-      a.x = c->datt; a.ldx = d; a.W = L.wo_c; a.bias = L.bo_c; a.N = d; a.K = d; a.B = B; a.res = xmid; a.ldres = d;
+      a.x = c->datt; a.ldx = d; a.W = L.wo_c; a.wscale = L.s_oc; a.bias = L.bo_c; a.N = d; a.K = d; a.B = B; a.res = xmid; a.ldres = d;
       a.y = xin; a.ldy = d;
       HIPCHK(c, launch_gemv(dt, a, st));
     }
     {
       GemvArgs a{};
-      a.x = xin; a.ldx = d; a.ln_gw = L.fc1_gw; a.ln_cb = L.fc1_cb; a.W = L.w1; a.N = F; a.K = d; a.B = B;
+      a.x = xin; a.ldx = d; a.ln_gw = L.fc1_gw; a.ln_cb = L.fc1_cb; a.W = L.w1; a.wscale = L.s_1; a.N = F; a.K = d; a.B = B;
       a.gelu = 1; a.y = c->dh; a.ldy = F;
       HIPCHK(c, launch_gemv(dt, a, st));
     }
     {
       GemvArgs a{};
-      a.x = c->dh; a.ldx = F; a.W = L.w2; a.bias = L.b2; a.N = d; a.K = F; a.B = B; a.res = xin; a.ldres = d;
+      a.x = c->dh; a.ldx = F; a.W = L.w2; a.wscale = L.s_2; a.bias = L.b2; a.N = d; a.K = F; a.B = B; a.res = xin; a.ldres = d;
       a.y = xmid; a.ldy = d;
       HIPCHK(c, launch_gemv(dt, a, st));
     }
@@ -685,7 +702,7 @@ int decode_core(tw_ctx* c, int B, hipStream_t st) {
   }
   {
     GemvArgs a{};
-    a.x = xin; a.ldx = d; a.ln_gw = c->logit_gw; a.ln_cb = c->logit_cb; a.W = c->logit_w; a.N = c->V; a.K = d; a.B = B;
+    a.x = xin; a.ldx = d; a.ln_gw = c->logit_gw; a.ln_cb = c->logit_cb; a.W = c->logit_w; a.wscale = c->logit_ws; a.N = c->V; a.K = d; a.B = B;
     a.y_f32 = c->logits;
     HIPCHK(c, launch_gemv(dt, a, st));
   }

@@ -118,6 +118,67 @@ __device__ __forceinline__ u32x4_t sk_load_w(const T* p) {  // weights are read 
   return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
 }
 
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+
+// value of lane ^ 16 / lane ^ 32 (bit pattern; after the swap {a, b} = {own, partner} whichever half the lane is in)
+__device__ __forceinline__ unsigned sk_from_xor16(unsigned v) {
+  float a = __builtin_bit_cast(float, v), b = a;
+  tw_swap16(a, b);
+  return __builtin_bit_cast(unsigned, a) ^ __builtin_bit_cast(unsigned, b) ^ v;
+}
+__device__ __forceinline__ unsigned sk_from_xor32(unsigned v) {
+  float a = __builtin_bit_cast(float, v), b = a;
+  tw_swap32(a, b);
+  return __builtin_bit_cast(unsigned, a) ^ __builtin_bit_cast(unsigned, b) ^ v;
+}
+
+// MXFP8 quantisation of one 128-k operand step held by a wavefront: lane (kq = lane>>4, idx = lane&15) holds 32 bf16
+// values, 4 fragments of 8; byte 8m + e of its 32-B operand <- fragment m, element e.
+// Block structure = what v_mfma_scale_f32_16x16x128_f8f6f4 scales together (measured with tools/dbg/mx_probe2.hip: the
+// instruction's true k of operand byte q in lane group kq is (q/16)*64 + kq*16 + q%16, and the scale of the 32-k block t
+// is byte 0 of the scale register in lane t*16 + idx): block (u, h) = 16-byte half h of the two lane groups kq = 2u, 2u+1,
+// its scale lives in lane group h*2 + u.  Hence: per-half maxima, one exchange with lane^16, convert, and one exchange
+// with lane^32 to put each scale byte where the hardware reads it.
+// Scale byte sb = max(E - 7, 1), E = biased exponent of the block's largest magnitude; elements = RNE_e4m3(v / 2^(sb-127))
+// (|.| < 256, never overflows).  One exponent more conservative than the OCP MX convention (E - 8 with saturation)
+// because the gfx950 converts return NaN instead of saturating above 464.  Must be called by all 64 lanes.
+__device__ __forceinline__ v8i_t sk_quant_mx8(const u32x4_t (&xv)[4], int& scale_operand) {
+  u16x2_t mx[2] = {{0, 0}, {0, 0}};
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mx[m >> 1] = __builtin_elementwise_max(mx[m >> 1], __builtin_bit_cast(u16x2_t, xv[m][q] & 0x7fff7fffu));
+  const unsigned own = max((unsigned)mx[0][0], (unsigned)mx[0][1]) | (max((unsigned)mx[1][0], (unsigned)mx[1][1]) << 16);
+  const unsigned oth = sk_from_xor16(own);
+  const int sb0 = max((int)(max(own & 0xffffu, oth & 0xffffu) >> 7) - 7, 1);
+  const int sb1 = max((int)(max(own >> 16, oth >> 16) >> 7) - 7, 1);
+  const float X0 = __builtin_bit_cast(float, (unsigned)sb0 << 23), X1 = __builtin_bit_cast(float, (unsigned)sb1 << 23);  // 2^(sb-127)
+  v8i_t out;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    // named pairs of the whole vector, not bit_cast<bf16x2>(xv[m][q]): hipcc (ROCm 7.2) folds the latter to element 0 (dot16)
+    const bf16x8_t a = __builtin_bit_cast(bf16x8_t, xv[m]);
+    const float X = m < 2 ? X0 : X1;
+    s16x2_t lo = {0, 0}, hi = {0, 0};
+    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(lo, __builtin_shufflevector(a, a, 0, 1), X, false);
+    lo = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(lo, __builtin_shufflevector(a, a, 2, 3), X, true);
+    hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(hi, __builtin_shufflevector(a, a, 4, 5), X, false);
+    hi = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(hi, __builtin_shufflevector(a, a, 6, 7), X, true);
+    out[2 * m] = __builtin_bit_cast(int, lo);
+    out[2 * m + 1] = __builtin_bit_cast(int, hi);
+  }
+  // scale of block t belongs in lane group t: t = 0 <- (u 0, h 0), 1 <- (u 1, h 0), 2 <- (u 0, h 1), 3 <- (u 1, h 1); this
+  // lane knows (u = kq/2, h = 0 and 1), the lane group kq^2 knows the other u
+  const unsigned mine = (unsigned)sb0 | ((unsigned)sb1 << 8);
+  const unsigned far = sk_from_xor32(mine);
+  const int kq = (threadIdx.x >> 4) & 3;
+  const unsigned pick = (kq == 0) ? (mine & 0xffu) : (kq == 3) ? (mine >> 8) : (kq == 1) ? (far & 0xffu) : (far >> 8);
+  scale_operand = (int)(pick & 0xffu);
+  return out;
+}
+
 // (sum, sum of squares) of the 16 bytes of one activation fragment, accumulated per lane
 template <typename T> __device__ __forceinline__ void sk_stats(const u32x4_t& v, float& s, float& ss);
 template <> __device__ __forceinline__ void sk_stats<bf16_t>(const u32x4_t& v, float& s, float& ss) {
@@ -156,13 +217,23 @@ template <> __device__ __forceinline__ void sk_stats<float>(const u32x4_t& v, fl
 //    hoisting arithmetic between them;
 //  * no load sits inside a conditional block (clamped addresses, zero-selected operands instead): at the join of a
 //    runtime-uniform branch around a load hipcc waits for EVERY outstanding load.
-template <typename T, int NW, int SK_MAXS, bool LN, int EPI, bool MULTI>
-__global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (SK_MAXS <= 5 ? 4 : 2))) void skinny_mfma_kernel(GemvArgs a) {
+//
+// W8 = MXFP8 weights (TW_BF16_MXFP8 contexts): the weight operand is OCP e4m3 with one power-of-two scale per 32 values
+// (quant_mx8_kernel below), the bf16 activation fragments are quantised the same way in registers (a lane's 32 values of
+// one 128-wide k step are exactly one scale block, so no cross-lane reduction is needed), and the product runs on
+// v_mfma_scale_f32_16x16x128_f8f6f4, which applies both block scales in hardware.  One step is then 128 k: 2 KiB of
+// weights + 64 scale bytes per tile, half the bytes of the bf16 kernel.
+template <typename T, int NW, int SK_MAXS, bool LN, int EPI, bool MULTI, bool W8>
+__global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (W8 ? (SK_MAXS <= 2 ? 4 : 2) : (SK_MAXS <= 5 ? 4 : 2)))) void skinny_mfma_kernel(GemvArgs a) {
+  static_assert(!W8 || sizeof(T) == 2, "MXFP8 weights go with bf16 activations");
   constexpr int E = ElemTraits<T>::kPer16B;
+  constexpr int XPS = W8 ? 4 : 1;  // 32-wide activation fragments per MFMA step
+  constexpr int WPS = W8 ? 2 : 1;  // 16-B weight requests per MFMA step
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ float pstat[NW][16][2];  // per wavefront and stream: (sum, sum of squares) over the wavefront's K slice
   const T* x = reinterpret_cast<const T*>(a.x);
   const T* W = reinterpret_cast<const T*>(a.W);
+  const unsigned char* wscale = a.wscale;
   const T* bias = reinterpret_cast<const T*>(a.bias);
   const T* res = reinterpret_cast<const T*>(a.res);
   const float* gw_p = a.ln_gw;
@@ -175,7 +246,7 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (SK_MAXS <= 5 ? 4 : 2))) v
   T* vcache = reinterpret_cast<T*>(a.vcache);
   const DecState* stt = a.stt;
   asm volatile("" ::"s"(x), "s"(W), "s"(bias), "s"(res), "s"(gw_p), "s"(cb_p), "s"(K), "s"(N), "s"(B), "s"(a.gelu), "s"(ldy),
-               "s"(RG), "s"(d_model), "s"(cache_bstride), "s"(y), "s"(y_f32), "s"(kcache), "s"(vcache), "s"(stt));
+               "s"(RG), "s"(d_model), "s"(cache_bstride), "s"(y), "s"(y_f32), "s"(kcache), "s"(vcache), "s"(stt), "s"(wscale));
   int cur_pos = 0;
 #ifdef TW_PROBE_TS
   cur_pos = stt->pos;
@@ -187,14 +258,15 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (SK_MAXS <= 5 ? 4 : 2))) v
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, kq = lane >> 4;
-  const int S = K / (4 * E);  // 64-B steps per row
+  const int S = K / (4 * E * XPS);  // MFMA steps per row (32 k each; 128 k with MXFP8 weights)
   const int s_lo = (int)((long long)wave * S / NW), s_hi = (int)((long long)(wave + 1) * S / NW);
   float* red = reinterpret_cast<float*>(smem);  // [NW][256]
   const int n_tiles = (N + 15) / 16;
   const int tile0 = blockIdx.x * RG;
   const int ej = (tid >> 4) & 15, ei = tid & 15;  // epilogue role of threads 0..255: stream ej, tile row ei
 
-  u32x4_t wq[SK_MAXS], xq[SK_MAXS];
+  u32x4_t wq[SK_MAXS * WPS], xq[SK_MAXS * XPS];
+  int wsc[SK_MAXS];  // MXFP8: scale byte of this lane's 32-value weight block
   float e_c = 0.f, e_gw = 0.f, e_res = 0.f;
   // --- request helpers: all unconditional, addresses clamped into the matrix ---
   auto load_epi = [&](int tile, float& c, float& g, float& r) {
@@ -209,18 +281,30 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (SK_MAXS <= 5 ? 4 : 2))) v
     if (EPI == SK_RES) r = (float)res[tw_xt_index<T>(ej, n)];
   };
   auto load_w = [&](int tile, int s0) {  // fragment-major weights: 1 KiB contiguous per wavefront request
-    const T* wt = W + ((long long)min(tile, n_tiles - 1) * S * 64 + lane) * E;
+    const int tl = min(tile, n_tiles - 1);
+    if (W8) {
+      const unsigned char* wt = reinterpret_cast<const unsigned char*>(W) + ((long long)tl * S * 128 + lane) * 16;
+      const unsigned char* ws = wscale + (long long)tl * S * 64 + lane;
 #pragma unroll
-    for (int i = 0; i < SK_MAXS; ++i) wq[i] = sk_load_w<T>(wt + (long long)min(s0 + i, S - 1) * (64 * E));
+      for (int i = 0; i < SK_MAXS; ++i) {
+        const long long st = min(s0 + i, S - 1);
+        wq[2 * i] = sk_load_w<unsigned char>(wt + st * 2048);
+        wq[2 * i + 1] = sk_load_w<unsigned char>(wt + st * 2048 + 1024);
+        wsc[i] = ws[st * 64];
+      }
+    } else {
+      const T* wt = W + ((long long)tl * S * 64 + lane) * E;
+#pragma unroll
+      for (int i = 0; i < SK_MAXS; ++i) wq[i] = sk_load_w<T>(wt + (long long)min(s0 + i, S - 1) * (64 * E));
+    }
   };
-  auto load_x = [&](int s0) {            // fragment-major activations: lane (stream fr, k-group kq) of step s
-#ifdef TW_PROBE_XBCAST   // probe only: every lane reads the same 16 B (what would the kernel cost without activation traffic?)
-    const T* xt = x;
-#else
+  auto load_x = [&](int s0) {            // fragment-major activations: lane (stream fr, k-group kq) of each 32-k step
     const T* xt = x + (long long)lane * E;
-#endif
 #pragma unroll
-    for (int i = 0; i < SK_MAXS; ++i) xq[i] = *reinterpret_cast<const u32x4_t*>(xt + (long long)min(s0 + i, S - 1) * (64 * E));
+    for (int i = 0; i < SK_MAXS; ++i)
+#pragma unroll
+      for (int m = 0; m < XPS; ++m)
+        xq[i * XPS + m] = *reinterpret_cast<const u32x4_t*>(xt + ((long long)min(s0 + i, S - 1) * XPS + m) * (64 * E));
   };
 
   load_x(s_lo);
@@ -241,9 +325,23 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (SK_MAXS <= 5 ? 4 : 2))) v
       for (int i = 0; i < SK_MAXS; ++i) {
         const bool on = s0 + i < s_hi;  // wave-uniform: steps past this wavefront's K slice contribute zero
         const u32x4_t zero = u32x4_t{0u, 0u, 0u, 0u};
-        const u32x4_t xv = on ? xq[i] : zero;
-        if (LN && (!MULTI || grp == 0)) sk_stats<T>(xv, ps, pss);
-        acc = sk_mfma<T>(on ? wq[i] : zero, xv, acc);
+        if (W8) {
+          u32x4_t xv[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            xv[m] = on ? xq[i * 4 + m] : zero;
+            if (LN && (!MULTI || grp == 0)) sk_stats<T>(xv[m], ps, pss);
+          }
+          int xs;
+          const v8i_t xb = sk_quant_mx8(xv, xs);
+          const u32x4_t w0 = on ? wq[2 * i] : zero, w1 = on ? wq[2 * i + 1] : zero;
+          const v8i_t wb = {(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
+          acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wb, xb, acc, 0, 0, 0, wsc[i], 0, xs);
+        } else {
+          const u32x4_t xv = on ? xq[i] : zero;
+          if (LN && (!MULTI || grp == 0)) sk_stats<T>(xv, ps, pss);
+          acc = sk_mfma<T>(on ? wq[i] : zero, xv, acc);
+        }
       }
     };
     mfma_round(s_lo);  // operands already in flight
@@ -334,6 +432,36 @@ __global__ __launch_bounds__(256) void tile_weights_kernel(const T* __restrict__
   u32x4_t val = u32x4_t{0u, 0u, 0u, 0u};
   if (n < N) val = *reinterpret_cast<const u32x4_t*>(src + (long long)n * K + (long long)kv * E);
   *reinterpret_cast<u32x4_t*>(dst + v * E) = val;
+}
+
+// Row-major bf16 W[N][K] -> MXFP8 operand of skinny_mfma_kernel<.., W8 = true>: per 16-row tile and 128-k step, 2 KiB of
+// e4m3 as [half][lane][16 B] (lane = kq*16 + row%16; its 32 bytes, fragment m / element e at byte 8m + e, are
+// W[row][(4s + m)*32 + kq*8 + e]: the same k set the activation lane (stream, kq) holds) followed, in a separate array, by
+// one scale byte per lane (already placed in the lane the MFMA reads it from).  Quantisation = sk_quant_mx8, i.e. identical
+// to what the projection kernel does to the activations.
+__global__ __launch_bounds__(256) void quant_mx8_kernel(const bf16_t* __restrict__ src, unsigned char* __restrict__ dst,
+                                                        unsigned char* __restrict__ scales, int N, int K) {
+  const int S = K / 128;
+  const long long v = (long long)blockIdx.x * 256 + threadIdx.x;  // (tile, step, lane)
+  const long long total = (long long)((N + 15) / 16) * S * 64;
+  if (v >= total) return;
+  const int l = (int)(v & 63);
+  const long long ts = v >> 6;
+  const int s = (int)(ts % S);
+  const long long t = ts / S;
+  const int n = (int)t * 16 + (l & 15), kq = l >> 4;
+  u32x4_t xv[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    xv[m] = u32x4_t{0u, 0u, 0u, 0u};
+    if (n < N) xv[m] = *reinterpret_cast<const u32x4_t*>(src + (long long)n * K + (4 * s + m) * 32 + kq * 8);
+  }
+  int sb;  // (whole wavefronts reach this point: `total` is a multiple of 64)
+  const v8i_t q = sk_quant_mx8(xv, sb);
+  unsigned char* blk = dst + ts * 2048;
+  *reinterpret_cast<u32x4_t*>(blk + l * 16) = u32x4_t{(unsigned)q[0], (unsigned)q[1], (unsigned)q[2], (unsigned)q[3]};
+  *reinterpret_cast<u32x4_t*>(blk + 1024 + l * 16) = u32x4_t{(unsigned)q[4], (unsigned)q[5], (unsigned)q[6], (unsigned)q[7]};
+  scales[ts * 64 + l] = (unsigned char)sb;
 }
 
 // W[n,:] *= g (in place, rounded to T); gw[n] = sum_k g[k] W[n,k]; cb[n] = sum_k beta[k] W[n,k] + bias[n]   (one wave per row)
@@ -750,11 +878,15 @@ static int env_int(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-template <typename T, int NW, int SK_MAXS, bool MULTI>
+template <typename T, int NW, int SK_MAXS, bool MULTI, bool W8>
 static hipError_t skinny_launch_v(const GemvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
   const bool ln = a.ln_gw != nullptr;
-#define SK_GO(LNV, EPIV) hipLaunchKernelGGL((skinny_mfma_kernel<T, NW, SK_MAXS, LNV, EPIV, MULTI>), grid, dim3(NW * 64), lds, st, a)
-  if (a.y_f32) {
+#define SK_GO(LNV, EPIV) hipLaunchKernelGGL((skinny_mfma_kernel<T, NW, SK_MAXS, LNV, EPIV, MULTI, W8>), grid, dim3(NW * 64), lds, st, a)
+  if constexpr (NW >= 16) {  // 16 wavefronts per tile only for the long-K residual projections (fc2)
+    if (ln || a.y_f32 || a.kcache || a.gelu) return hipErrorInvalidValue;
+    if (a.res) SK_GO(false, SK_RES);
+    else SK_GO(false, SK_STORE);
+  } else if (a.y_f32) {
     if (!ln || a.res || a.gelu || a.kcache) return hipErrorInvalidValue;
     SK_GO(true, SK_F32);
   } else if (a.kcache) {
@@ -789,18 +921,42 @@ static hipError_t skinny_launch_nw(const GemvArgs& a0, hipStream_t st) {
   if (a.rg < 1 || steps_per_wave > 10) a.rg = 1;  // several tiles per workgroup only with one round of fragments per tile
   dim3 grid((tiles + a.rg - 1) / a.rg);
   if (a.rg > 1) {
-    if (steps_per_wave <= 5) return skinny_launch_v<T, NW, 5, true>(a, grid, lds, st);
-    return skinny_launch_v<T, NW, 10, true>(a, grid, lds, st);
+    if (steps_per_wave <= 5) return skinny_launch_v<T, NW, 5, true, false>(a, grid, lds, st);
+    return skinny_launch_v<T, NW, 10, true, false>(a, grid, lds, st);
   }
-  if (steps_per_wave <= 5) return skinny_launch_v<T, NW, 5, false>(a, grid, lds, st);
-  return skinny_launch_v<T, NW, 10, false>(a, grid, lds, st);
+  if (steps_per_wave <= 5) return skinny_launch_v<T, NW, 5, false, false>(a, grid, lds, st);
+  return skinny_launch_v<T, NW, 10, false, false>(a, grid, lds, st);
+}
+
+// MXFP8 weights: 128-k steps; 2 steps per wavefront cover K = 1280 with 8 wavefronts, 3 cover K = 5120 with 16
+template <int NW>
+static hipError_t skinny_launch_w8(const GemvArgs& a0, hipStream_t st) {
+  GemvArgs a = a0;
+  if (a.K % 128 != 0 || a.B > 16) return hipErrorInvalidValue;
+  const size_t lds = (size_t)NW * 256 * 4;
+  const int tiles = (a.N + 15) / 16;
+  static const int max_blocks = env_int("TW_SK_MAX_BLOCKS", 512);
+  const int steps_per_wave = (a.K / 128 + NW - 1) / NW;
+  a.rg = (tiles + max_blocks - 1) / max_blocks;
+  if (a.rg < 1 || steps_per_wave > 3) a.rg = 1;
+  dim3 grid((tiles + a.rg - 1) / a.rg);
+  if (a.rg > 1) {
+    if (steps_per_wave <= 2) return skinny_launch_v<bf16_t, NW, 2, true, true>(a, grid, lds, st);
+    return skinny_launch_v<bf16_t, NW, 3, true, true>(a, grid, lds, st);
+  }
+  if (steps_per_wave <= 2) return skinny_launch_v<bf16_t, NW, 2, false, true>(a, grid, lds, st);
+  return skinny_launch_v<bf16_t, NW, 3, false, true>(a, grid, lds, st);
 }
 
 template <typename T>
 static hipError_t skinny_launch(const GemvArgs& a, hipStream_t st) {
   static const int nw_big = env_int("TW_SK_NW_BIGK", 16);  // wavefronts per tile when K is long (fc2: K = 5120)
-  if (a.K >= 4096 && nw_big == 16 && !a.ln_gw && !a.y_f32 && !a.kcache && !a.gelu) return skinny_launch_nw<T, 16>(a, st);
-  return skinny_launch_nw<T, 8>(a, st);
+  const bool big = a.K >= 4096 && nw_big == 16 && !a.ln_gw && !a.y_f32 && !a.kcache && !a.gelu;
+  if (a.wscale) {
+    if (sizeof(T) != 2) return hipErrorInvalidValue;
+    return big ? skinny_launch_w8<16>(a, st) : skinny_launch_w8<8>(a, st);
+  }
+  return big ? skinny_launch_nw<T, 16>(a, st) : skinny_launch_nw<T, 8>(a, st);
 }
 
 template <typename T>
@@ -869,6 +1025,14 @@ hipError_t launch_tile_weights(int dtype, const void* src, void* dst, int N, int
   dim3 grid((unsigned)((total + 255) / 256));
   if (dtype == 1) hipLaunchKernelGGL(tile_weights_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, N, K);
   else hipLaunchKernelGGL(tile_weights_kernel<float>, grid, dim3(256), 0, st, (const float*)src, (float*)dst, N, K);
+  return hipGetLastError();
+}
+
+hipError_t launch_quant_mx8(const void* src_bf16, void* dst_fp8, void* dst_scales, int N, int K, hipStream_t st) {
+  if (K % 128 != 0) return hipErrorInvalidValue;
+  const long long total = (long long)((N + 15) / 16) * (K / 128) * 64;
+  hipLaunchKernelGGL(quant_mx8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const bf16_t*)src_bf16,
+                     (unsigned char*)dst_fp8, (unsigned char*)dst_scales, N, K);
   return hipGetLastError();
 }
 

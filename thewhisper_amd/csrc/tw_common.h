@@ -155,6 +155,7 @@ struct GemvArgs {
   // ln_cb[n] = sum_k beta[k] W[n,k] + bias[n]  (float32, null = no LayerNorm); requires K <= 1280
   const float* ln_gw; const float* ln_cb;
   const void* W; const void* bias;     // [N, K] in the fragment-major layout of launch_tile_weights, [N]
+  const unsigned char* wscale;         // non-null: W is MXFP8 (launch_quant_mx8), these are its block scales; bf16 activations
   int N, K, B;
   int gelu;
   const void* res; int ldres;    // residual [16, N] (fragment-major) added after bias/act; output then fragment-major too
@@ -169,6 +170,8 @@ hipError_t launch_gemv(int dtype, const GemvArgs& a, hipStream_t st);
 hipError_t init_decode_kernels();
 // row-major [N][K] -> the fragment-major layout launch_gemv reads (k_decode.hip); dst holds ceil(N/16)*16 rows
 hipError_t launch_tile_weights(int dtype, const void* src, void* dst, int N, int K, hipStream_t st);
+// row-major bf16 [N][K] -> MXFP8 fragments (ceil(N/16)*16*K bytes) + block scales (ceil(N/16)*16*K/32 bytes); K % 128 == 0
+hipError_t launch_quant_mx8(const void* src_bf16, void* dst_fp8, void* dst_scales, int N, int K, hipStream_t st);
 // weight preparation for the folded pre-LayerNorm: W <- Wsrc * g (may alias), gw, cb as above
 hipError_t launch_fold_ln(int dtype, void* W, const void* Wsrc, const void* g, const void* beta, const void* bias, float* gw,
                           float* cb, int N, int K, hipStream_t st);  // once per process: dynamic-LDS caps of the gemv instantiations

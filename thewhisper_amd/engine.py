@@ -44,8 +44,9 @@ class WhisperEngine:
         self.max_batch = int(max_batch)
         self.device = torch.device("cuda", device)
         self.dtype_name = dtype
-        self.tw_dtype = {"bf16": _cabi.TW_BF16, "f32": _cabi.TW_F32}[dtype]
-        self.torch_dtype = {"bf16": torch.bfloat16, "f32": torch.float32}[dtype]
+        # "fp8" = bf16 activations and encoder, decoder projection weights quantised to MXFP8 at load (BASELINE config 5)
+        self.tw_dtype = {"bf16": _cabi.TW_BF16, "f32": _cabi.TW_F32, "fp8": _cabi.TW_BF16_MXFP8}[dtype]
+        self.torch_dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "fp8": torch.bfloat16}[dtype]
         self.alignment_heads = [tuple(map(int, x)) for x in (alignment_heads or [])]
         cfg = _cabi.tw_config()
         cfg.d_model = dims["d_model"]
