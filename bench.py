@@ -97,11 +97,12 @@ def alignment_heads(dims):
     return out
 
 
-def algorithmic_decode_bytes(dims, B, T, n_prompt, steps, esz=2):
+def algorithmic_decode_bytes(dims, B, T, n_prompt, steps, esz=2, wsz=None):
     """bytes/step = W + B*163840*(T + t) (large-v3 numbers generalised):
     W = esz*(Ld*14*d^2 + V*d); per stream and step the cross K/V (2*Ld*T*d*esz) and the self K/V read so far."""
     d, Ld, V = dims["d_model"], dims["dec_layers"], dims["vocab"]
-    W = esz * (Ld * (4 * d * d + 4 * d * d + 2 * d * dims["ffn"]) + V * d)
+    wsz = esz if wsz is None else wsz  # bytes per projection weight (MXFP8: 1 + 1/32 for the block scales)
+    W = wsz * (Ld * (4 * d * d + 4 * d * d + 2 * d * dims["ffn"]) + V * d)
     total = 0
     for s in range(steps):
         t = s + 1
@@ -192,7 +193,8 @@ def main():
     ap.add_argument("--chunk-s", type=int, default=10)
     ap.add_argument("--streams", type=int, default=16, help="concurrent streams per GPU")
     ap.add_argument("--new-tokens", type=int, default=128)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"],
+                    help="fp8 = bf16 activations/encoder + MXFP8 decoder projection weights (BASELINE config 5)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=8)
@@ -273,9 +275,11 @@ def main():
             lat.append((time.perf_counter() - a) * 1e3)
 
     if rank == 0:
-        esz = 2 if args.dtype == "bf16" else 4
+        esz = 4 if args.dtype == "f32" else 2
+        wsz = 1.0 + 1.0 / 32 if args.dtype == "fp8" else None
         steps_per_call = dec_steps // max(1, args.steps)
-        alg_bytes, W = algorithmic_decode_bytes(dims, B, T, n_prompt, steps_per_call, esz)
+        alg_bytes, W = algorithmic_decode_bytes(dims, B, T, n_prompt, steps_per_call, esz, wsz)
+        alg_bytes, W = int(alg_bytes), int(W)
         greedy_ms = stage["greedy_ms"] / args.steps
         achieved = alg_bytes / (greedy_ms * 1e-3) / 1e9 if greedy_ms > 0 else 0.0
         result = {
@@ -290,7 +294,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": args.dtype,
+            "dtype": "bf16 activations, MXFP8 (e4m3 + block scales) decoder weights" if args.dtype == "fp8" else args.dtype,
             "data": "synthetic 16 kHz gaussian audio (sigma 0.1), random-init weights of the named architecture",
             "config": {
                 "workload": f"whisper-{args.model}, {args.chunk_s} s chunks, {B} concurrent streams per GPU (configs[3] per-GPU share), "

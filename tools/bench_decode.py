@@ -12,10 +12,11 @@ ap.add_argument("--layers", type=int, default=8)
 ap.add_argument("--batches", default="1,4,16")
 ap.add_argument("--tokens", type=int, default=64)
 ap.add_argument("--T", type=int, default=500)
+ap.add_argument("--dtype", default="bf16")
 args = ap.parse_args()
 dims = dict(bench.DIMS["large-v3"], enc_layers=1, dec_layers=args.layers)
 dev = torch.device("cuda", 0)
-eng = WhisperEngine(dims, args.T, max_batch=16, dtype="bf16", alignment_heads=bench.alignment_heads(dims), use_graph=True)
+eng = WhisperEngine(dims, args.T, max_batch=16, dtype=args.dtype, alignment_heads=bench.alignment_heads(dims), use_graph=True)
 eng.load_state_dict(bench.random_state_dict(dims, dev, 0))
 pcm = torch.randn((16, args.T * 320), device=dev) * 0.1
 for B in [int(x) for x in args.batches.split(",")]:
