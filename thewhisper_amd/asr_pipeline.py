@@ -39,10 +39,14 @@ class ASRPipeline(AutomaticSpeechRecognitionPipeline):
     ):
         revision = kwargs.pop("revision", "main")
         engine_factory: Optional[Callable] = kwargs.pop("engine_factory", None)  # test seam only
+        decoder_weights: Optional[str] = kwargs.pop("decoder_weights", None)     # MI355X-only option: "fp8" = MXFP8 decoder weights
         if model_size not in (None, "S", "M", "L", "XL"):
             raise ValueError(f"Invalid model_size: {model_size}")
-        # model_size selects a TheStage engine flavour on NVIDIA (S = quantised, XL = fp16).  On MI355X every
-        # size currently maps to the bf16 kernels (fp8 weights: SURVEY.md section 8, config 5 - next round).
+        # model_size selects a TheStage engine flavour on NVIDIA (S = quantised, XL = fp16).  On MI355X every size maps to the
+        # bf16 kernels (results identical to the reference arithmetic within the bf16 tolerance); the quantised flavour is an
+        # explicit opt-in, ``decoder_weights="fp8"`` (BASELINE config 5: MXFP8 decoder projection weights).
+        if decoder_weights not in (None, "bf16", "fp8"):
+            raise ValueError(f"Invalid decoder_weights: {decoder_weights}")
 
         if type(model) is str:
             model_name = model
@@ -80,6 +84,6 @@ class ASRPipeline(AutomaticSpeechRecognitionPipeline):
         batch_size = int(kwargs.get("batch_size") or 1)
         engine = self.model.build_engine(
             chunk_length_s=chunk_length_s, max_batch=max(1, min(16, batch_size)), dtype=torch_dtype,
-            engine_factory=engine_factory,
+            engine_factory=engine_factory, decoder_weights=decoder_weights,
         )
         self.feature_extractor.attach_engine(engine)

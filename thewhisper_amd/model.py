@@ -173,7 +173,8 @@ class AMDWhisperForConditionalGeneration(WhisperForConditionalGeneration, _Engin
 
     # -- engine lifetime ---------------------------------------------------------------------------
     def build_engine(self, chunk_length_s: int = 30, max_batch: int = 1, dtype: Optional[torch.dtype] = None,
-                     engine_factory: Optional[Callable] = None, release_torch_weights: bool = True):
+                     engine_factory: Optional[Callable] = None, release_torch_weights: bool = True,
+                     decoder_weights: Optional[str] = None):
         """Create the context for T = 50*chunk_length_s encoder frames and upload the weights (A0 is applied by
         the library: tw_finalize_weights interpolates the positional table like patch_hf_model)."""
         if chunk_length_s > 30 or chunk_length_s < 1:
@@ -184,6 +185,10 @@ class AMDWhisperForConditionalGeneration(WhisperForConditionalGeneration, _Engin
         if dt == torch.float16:
             logger.warning("fp16 requested: the MI355X engine computes in bf16 (same MFMA rate, wider range)")
         eng_dtype = "f32" if dt == torch.float32 else "bf16"
+        if decoder_weights == "fp8":
+            if eng_dtype != "bf16":
+                raise ValueError("decoder_weights='fp8' needs a bf16 (or fp16) torch_dtype")
+            eng_dtype = "fp8"
         heads = getattr(self.generation_config, "alignment_heads", None) or []
         factory = engine_factory or type(self)._engine_factory
         dev_index = p0.device.index if p0.device.type == "cuda" and p0.device.index is not None else 0
