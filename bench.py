@@ -198,6 +198,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=8)
+    ap.add_argument("--encoder-cus", type=int, default=64,
+                    help="overlap the encoder of batch k+1 (confined to this many CUs, second context) with the decode loop of "
+                         "batch k (thewhisper_amd/overlap.py); 0 = one context, strictly sequential stages")
     ap.add_argument("--latency-iters", type=int, default=100, help="single-stream chunk calls timed for the p50 (after 10 warm-ups; SURVEY.md section 8d)")
     args = ap.parse_args()
 
@@ -221,6 +224,13 @@ def main():
                         use_graph=not args.no_graph)
     sd = random_state_dict(dims, dev, seed=0)
     eng.load_state_dict(sd)
+    overlap = None
+    if args.encoder_cus > 0:
+        from thewhisper_amd.overlap import EncoderOverlap
+        eng2 = WhisperEngine(dims, T, max_batch=B, dtype=args.dtype, alignment_heads=heads, device=local,
+                             use_graph=not args.no_graph)
+        eng2.load_state_dict(sd)
+        overlap = EncoderOverlap([eng, eng2], encoder_cus=args.encoder_cus)
     del sd
     torch.cuda.empty_cache()
 
@@ -244,16 +254,40 @@ def main():
     def barrier():
         rep.barrier()                      # dist.barrier() + torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    new_tok = 0
     stage = {"logmel_ms": 0.0, "encode_ms": 0.0, "cross_kv_ms": 0.0, "greedy_ms": 0.0, "token_timestamps_ms": 0.0}
     dec_steps = 0
-    for _ in range(args.steps):
-        new_tok += step() * B
-        tm = eng.last_timings()  # HIP events recorded on the launch stream inside the library
+    new_tok = 0
+
+    def encode_stage(e, pc):      # log-mel + encoder + cross-K/V: asynchronous launches
+        e.encode(e.logmel(pc))
+        e.cross_kv(pc.shape[0])
+        return None
+
+    def decode_stage(e, pc, _enc):
+        nb = pc.shape[0]
+        out = e.generate_greedy(prompt[:nb], max_new_tokens=args.new_tokens, min_new_tokens=args.new_tokens,
+                                timestamps=True, want_alignment=True)
+        L = out["length"]
+        e.token_timestamps(nb, n_prompt, L, [2 * T] * nb)
+        return (L - n_prompt) * nb, e.last_timings()
+
+    def run_steps(n):
+        """n passes of the hot path over one batch each; with the overlap the encoder stage of pass i+1 runs on its own CUs
+        while pass i decodes (same kernels, same results, different schedule)."""
+        if overlap is not None:
+            return overlap.run([pcm] * n, encode_stage, decode_stage)
+        res = []
+        for _ in range(n):
+            encode_stage(eng, pcm)
+            res.append(decode_stage(eng, pcm, None))
+        return res
+
+    if args.warmup > 0:  # with the overlap at least two passes, so that both contexts capture their step graph untimed
+        run_steps(max(args.warmup, 2) if overlap is not None else args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    for ntok, tm in run_steps(args.steps):
+        new_tok += ntok
         for k in stage:
             stage[k] += tm[k]
         dec_steps += tm["decode_steps"]
@@ -302,6 +336,8 @@ def main():
                 "streams_per_gpu": B, "chunk_seconds": args.chunk_s, "new_tokens": args.new_tokens,
                 "parallelism": f"replicas x{world} (streams sharded, no collective on the data path)",
                 "decode_step_graph": not args.no_graph,
+                "encoder_overlap": (f"encoder stage of batch k+1 on {args.encoder_cus} CUs (second context) under the decode loop of "
+                                    f"batch k on the other CUs" if overlap is not None else "off"),
             },
             "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage.items()},
             "decode_tok_per_s": round(B * args.new_tokens / (greedy_ms * 1e-3), 1) if greedy_ms > 0 else None,

@@ -407,3 +407,40 @@ def test_batching_hub_on_gpu_matches_reference_golden():
             for a, b in zip(got, c["result"]):
                 assert abs(a["start"] - b["start"]) <= 0.0201 and abs(a["end"] - b["end"]) <= 0.0201
     assert max(hub.batches) > 1
+
+
+def test_encoder_overlap_gives_the_sequential_results():
+    """thewhisper_amd/overlap.py: two contexts, encoder stage of batch k+1 on a CU-masked stream under the decode loop of batch
+    k.  Same kernels, different schedule: token ids, alignment rows and timestamps equal those of one context run sequentially."""
+    from thewhisper_amd.overlap import EncoderOverlap
+
+    dims = wo.PRESETS["micro"]
+    w = wo.make_weights(dims, 0)
+    heads = [(dims.dec_layers - 1, 0), (dims.dec_layers - 1, 1)]
+    engs = [make_engine(dims, w, T=100, max_batch=3, dtype="f32", heads=heads, use_graph=True) for _ in range(2)]
+    batches = [torch.from_numpy(np.ascontiguousarray(clips(100 * 320, 3)[::s])).cuda() for s in (1, -1, 1, -1, 1)]
+    prompt = np.tile(np.array(PROMPT, dtype=np.int32), (3, 1))
+
+    def enc(e, pc):
+        e.encode(e.logmel(pc, out_dtype=torch.float32))
+        e.cross_kv(pc.shape[0])
+
+    def dec(e, pc, _):
+        out = e.generate_greedy(prompt, max_new_tokens=16, timestamps=True, want_alignment=True)
+        L = out["length"]
+        return out["sequences"].copy(), e.get_alignment(3, L - 1).copy(), e.token_timestamps(3, 3, L, [200] * 3).copy()
+
+    seq = []
+    for b in batches:
+        enc(engs[0], b)
+        seq.append(dec(engs[0], b, None))
+    ov = EncoderOverlap(engs, encoder_cus=32)
+    got = ov.run(batches, enc, dec)
+    ov.close()
+    assert len(got) == len(seq)
+    for a, b in zip(got, seq):
+        assert np.array_equal(a[0], b[0])
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert not np.array_equal(seq[0][0], seq[1][0])          # the two kinds of batch do differ
+    for e in engs:
+        e.close()

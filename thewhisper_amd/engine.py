@@ -26,6 +26,16 @@ class WhisperEngine:
     """One MI355X context: weights + workspace + KV arenas for up to ``max_batch`` concurrent streams
     of ``T`` encoder frames (= 50 x chunk seconds)."""
 
+    #: optional raw ``hipStream_t`` (int) to enqueue on instead of torch's current stream, e.g. a stream created with
+    #: ``hipExtStreamCreateWithCUMask`` to confine this context to a subset of the CUs
+    raw_stream: Optional[int] = None
+
+    def _sp(self) -> C.c_void_p:
+        if self.raw_stream is not None:
+            return C.c_void_p(self.raw_stream)
+        return _stream_ptr(self.device)
+
+
     def __init__(
         self,
         dims: Dict[str, int],
@@ -102,12 +112,12 @@ class WhisperEngine:
             t = t.float()
         shape = (C.c_int64 * t.dim())(*t.shape)
         rc = self.lib.tw_load_weight(self.ctx, name.encode(), C.c_void_p(t.data_ptr()), _TORCH2TW[t.dtype], t.dim(), shape,
-                                     _stream_ptr(self.device))
+                                     self._sp())
         self._chk(rc, f"tw_load_weight({name})")
         torch.cuda.current_stream(self.device).synchronize()  # `t` may be a temporary
 
     def finalize(self):
-        self._chk(self.lib.tw_finalize_weights(self.ctx, _stream_ptr(self.device)), "tw_finalize_weights")
+        self._chk(self.lib.tw_finalize_weights(self.ctx, self._sp()), "tw_finalize_weights")
         self._finalized = True
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
@@ -140,7 +150,7 @@ class WhisperEngine:
         out_dtype = out_dtype or self.torch_dtype
         out = torch.empty((B, self.n_mels, n_samples // 160), dtype=out_dtype, device=self.device)
         rc = self.lib.tw_logmel(self.ctx, C.c_void_p(pcm.data_ptr()), pcm.stride(0), nv, B, n_samples,
-                                C.c_void_p(out.data_ptr()), _TORCH2TW[out_dtype], _stream_ptr(self.device))
+                                C.c_void_p(out.data_ptr()), _TORCH2TW[out_dtype], self._sp())
         self._chk(rc, "tw_logmel")
         return out
 
@@ -160,23 +170,23 @@ class WhisperEngine:
             out = torch.empty((B, self.T, self.d_model), dtype=hidden_dtype, device=self.device)
         rc = self.lib.tw_encode(self.ctx, C.c_void_p(mel.data_ptr()), _TORCH2TW[mel.dtype], B,
                                 C.c_void_p(out.data_ptr()) if out is not None else None,
-                                _TORCH2TW[hidden_dtype], _stream_ptr(self.device))
+                                _TORCH2TW[hidden_dtype], self._sp())
         self._chk(rc, "tw_encode")
         return out
 
     def cross_kv(self, B: int):
-        self._chk(self.lib.tw_cross_kv(self.ctx, B, _stream_ptr(self.device)), "tw_cross_kv")
+        self._chk(self.lib.tw_cross_kv(self.ctx, B, self._sp()), "tw_cross_kv")
 
     # ---- A6-A8 (teacher-forced stepping, used by the parity tests) ---------------------------
     def decoder_reset(self, B: int):
-        self._chk(self.lib.tw_decoder_reset(self.ctx, B, _stream_ptr(self.device)), "tw_decoder_reset")
+        self._chk(self.lib.tw_decoder_reset(self.ctx, B, self._sp()), "tw_decoder_reset")
 
     def decode_step(self, ids: Sequence[int], want_logits: bool = True) -> Optional[torch.Tensor]:
         B = len(ids)
         arr = (C.c_int32 * B)(*[int(i) for i in ids])
         out = torch.empty((B, self.vocab), dtype=torch.float32, device=self.device) if want_logits else None
         rc = self.lib.tw_decode_step(self.ctx, B, arr, C.c_void_p(out.data_ptr()) if out is not None else None,
-                                     _stream_ptr(self.device))
+                                     self._sp())
         self._chk(rc, "tw_decode_step")
         return out
 
@@ -215,7 +225,7 @@ class WhisperEngine:
         out_len = C.c_int32(0)
         rc = self.lib.tw_generate_greedy(self.ctx, B, prompt.ctypes.data_as(C.POINTER(C.c_int32)), n0, C.byref(o),
                                          out.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(out_len),
-                                         _stream_ptr(self.device))
+                                         self._sp())
         self._chk(rc, "tw_generate_greedy")
         L = int(out_len.value)
         return {"sequences": out[:, :L].astype(np.int64), "length": L}
@@ -228,14 +238,14 @@ class WhisperEngine:
         if num_frames is not None:
             nf = (C.c_int32 * B)(*[int(x) for x in num_frames])
         rc = self.lib.tw_token_timestamps(self.ctx, B, n_prompt, seq_len, nf, float(time_precision),
-                                          out.ctypes.data_as(C.POINTER(C.c_float)), _stream_ptr(self.device))
+                                          out.ctypes.data_as(C.POINTER(C.c_float)), self._sp())
         self._chk(rc, "tw_token_timestamps")
         return out
 
     def get_alignment(self, B: int, n_rows: int) -> np.ndarray:
         out = np.zeros((B, len(self.alignment_heads), n_rows, self.T), dtype=np.float32)
         rc = self.lib.tw_get_alignment(self.ctx, B, n_rows, out.ctypes.data_as(C.POINTER(C.c_float)),
-                                       _stream_ptr(self.device))
+                                       self._sp())
         self._chk(rc, "tw_get_alignment")
         return out
 

@@ -1,0 +1,144 @@
+"""Encoder / decoder overlap across consecutive batches on ONE MI355X.
+
+The decode loop of a batch is a chain of ~8000 dependent, latency-bound launches that never fills the chip, while the
+encoder of the next batch is dense MFMA work.  Two HIP streams alone do not overlap them - the encoder's workgroups take
+every CU for ~100 us at a time and the decode chain starves (measured: wall time = sum).  Confining the encoder to a few
+CUs with a CU-masked stream (``hipExtStreamCreateWithCUMask``) does: with 64 of 256 CUs the encoder + cross-K/V of 16 ten
+second chunks take ~75 ms instead of 24 ms, which hides completely behind the 210 ms decode loop running on the other 192
+CUs, and the decode loop slows down by only ~2 % (its launches never use more than 320 workgroups).  Measured on 5 batches of
+16 streams (tools/dbg/dbg_overlap.py): 1179 ms sequential, 1149 / 1121 / 1106 / 1101 / 1108 / 1186 ms with 24 / 32 / 48 /
+64 / 96 / 128 encoder CUs.
+
+Two contexts of the same model alternate roles (the cross-K/V arena of a context is read by its decode loop, so the next
+batch needs its own): while context k % 2 decodes batch k, context (k + 1) % 2 runs log-mel + encoder + cross-K/V of batch
+k + 1.  Results are those of the sequential order - every batch still goes through exactly the same kernels - only the
+schedule changes.  The reference has no counterpart (R:examples/server.py shares one pipeline and processes one request at
+a time); this belongs to the serving layer of SURVEY.md section 8f rank 1.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import queue
+import threading
+from typing import Any, Callable, Iterable, List, Optional, Sequence
+
+import torch
+
+from .engine import WhisperEngine
+
+__all__ = ["EncoderOverlap", "masked_stream"]
+
+_hip = None
+
+
+def _hiplib():
+    global _hip
+    if _hip is None:
+        lib = C.CDLL("libamdhip64.so")
+        lib.hipExtStreamCreateWithCUMask.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]
+        lib.hipStreamDestroy.argtypes = [C.c_void_p]
+        lib.hipStreamSynchronize.argtypes = [C.c_void_p]
+        lib.hipEventCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+        lib.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+        lib.hipStreamWaitEvent.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+        lib.hipEventDestroy.argtypes = [C.c_void_p]
+        lib.hipSetDevice.argtypes = [C.c_int]
+        _hip = lib
+    return _hip
+
+
+def _chk(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with hipError {rc}")
+
+
+def masked_stream(first_cu: int, last_cu: int, n_cus: int) -> int:
+    """A HIP stream whose kernels may only run on compute units [first_cu, last_cu) of the current device."""
+    words = (n_cus + 31) // 32
+    mask = (C.c_uint32 * words)(*([0] * words))
+    for i in range(first_cu, last_cu):
+        mask[i // 32] |= 1 << (i % 32)
+    st = C.c_void_p()
+    _chk(_hiplib().hipExtStreamCreateWithCUMask(C.byref(st), words, mask), "hipExtStreamCreateWithCUMask")
+    return int(st.value)
+
+
+class EncoderOverlap:
+    """Runs ``encode_fn(engine, batch)`` of batch k + 1 on ``encoder_cus`` compute units while ``decode_fn(engine, batch,
+    encoded)`` of batch k runs on the others.  ``engines``: two contexts built from the same weights, same device."""
+
+    def __init__(self, engines: Sequence[WhisperEngine], encoder_cus: int = 64):
+        if len(engines) != 2:
+            raise ValueError("EncoderOverlap needs exactly two contexts")
+        self.engines = list(engines)
+        self.device = engines[0].device
+        n_cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        if not 0 < encoder_cus < n_cus:
+            raise ValueError(f"encoder_cus must be in (0, {n_cus})")
+        self.encoder_cus, self.n_cus = int(encoder_cus), int(n_cus)
+        hip = _hiplib()
+        _chk(hip.hipSetDevice(self.device.index or 0), "hipSetDevice")
+        self.s_dec = masked_stream(0, n_cus - encoder_cus, n_cus)
+        self.s_enc = masked_stream(n_cus - encoder_cus, n_cus, n_cus)
+        self._events: List[int] = []
+        for _ in range(2):
+            ev = C.c_void_p()
+            _chk(hip.hipEventCreateWithFlags(C.byref(ev), 0x2), "hipEventCreateWithFlags")  # hipEventDisableTiming
+            self._events.append(int(ev.value))
+
+    def close(self):
+        hip = _hiplib()
+        for e in self.engines:
+            e.raw_stream = None
+        for ev in self._events:
+            hip.hipEventDestroy(ev)
+        for s in (self.s_dec, self.s_enc):
+            hip.hipStreamSynchronize(s)
+            hip.hipStreamDestroy(s)
+        self._events, self.s_dec, self.s_enc = [], None, None
+
+    def run(self, batches: Iterable[Any], encode_fn: Callable[[WhisperEngine, Any], Any],
+            decode_fn: Callable[[WhisperEngine, Any, Any], Any]) -> List[Any]:
+        """Processes the batches in order and returns ``decode_fn``'s results in order."""
+        hip = _hiplib()
+        batches = list(batches)
+        free = [threading.Semaphore(1), threading.Semaphore(1)]  # context i may be (re)used by the encode stage
+        ready: "queue.Queue" = queue.Queue()
+        dev_index = self.device.index or 0
+
+        def producer():
+            try:
+                torch.cuda.set_device(dev_index)
+                _chk(hip.hipSetDevice(dev_index), "hipSetDevice")
+                for i, b in enumerate(batches):
+                    k = i % 2
+                    free[k].acquire()                      # decode of batch i - 2 has returned
+                    eng = self.engines[k]
+                    # the first batch has no decode loop to hide behind: its encoder stage gets the decoder's (idle) CUs
+                    s_i = self.s_dec if i == 0 else self.s_enc
+                    eng.raw_stream = s_i
+                    enc = encode_fn(eng, b)                # asynchronous launches
+                    _chk(hip.hipEventRecord(self._events[k], s_i), "hipEventRecord")
+                    ready.put((i, k, enc, None))
+            except BaseException as e:  # noqa: BLE001  (hand the failure to the consumer)
+                ready.put((-1, -1, None, e))
+
+        th = threading.Thread(target=producer, name="tw-encoder-stage", daemon=True)
+        th.start()
+        out: List[Any] = []
+        try:
+            for _ in range(len(batches)):
+                i, k, enc, err = ready.get()
+                if err is not None:
+                    raise err
+                eng = self.engines[k]
+                _chk(hip.hipStreamWaitEvent(self.s_dec, self._events[k], 0), "hipStreamWaitEvent")
+                eng.raw_stream = self.s_dec
+                out.append(decode_fn(eng, batches[i], enc))  # blocking: returns when the batch is decoded
+                _chk(hip.hipStreamSynchronize(self.s_dec), "hipStreamSynchronize")
+                free[k].release()
+        finally:
+            th.join(timeout=60)
+            for e in self.engines:   # back to torch's current stream for whoever uses the contexts next
+                e.raw_stream = None
+        return out
