@@ -27,38 +27,13 @@ __device__ unsigned long long* g_probe_ts;
 #define TW_TS(k) do { } while (0)
 #endif
 
-__device__ __forceinline__ float row16_sum(float v) { return tw_row16_sum(v); }
 __device__ __forceinline__ float wave_sum(float v) { return tw_wave_sum(v); }
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <typename T> __device__ __forceinline__ float dot16(const u32x4_t& w, const u32x4_t& x, float acc);
-template <> __device__ __forceinline__ float dot16<bf16_t>(const u32x4_t& w, const u32x4_t& x, float acc) {
-  // NB: written without a loop over w[i]: hipcc (ROCm 7.2) folded `bit_cast<bf16x2>(w[i])` in an unrolled
-  // loop to element 0 for every i (seen in the ISA: four identical v_dot2c), so the pairs are named.
-  const bf16x8_t a = __builtin_bit_cast(bf16x8_t, w), b = __builtin_bit_cast(bf16x8_t, x);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1), acc, false);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3), acc, false);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 4, 5), __builtin_shufflevector(b, b, 4, 5), acc, false);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 6, 7), __builtin_shufflevector(b, b, 6, 7), acc, false);
-  return acc;
-}
-template <> __device__ __forceinline__ float dot16<float>(const u32x4_t& w, const u32x4_t& x, float acc) {
-  const f32x4_t a = __builtin_bit_cast(f32x4_t, w), b = __builtin_bit_cast(f32x4_t, x);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) acc = fmaf(a[i], b[i], acc);
-  return acc;
-}
+// NB for every helper below that takes bf16 pairs out of a 16-byte vector: hipcc (ROCm 7.2) folds `bit_cast<bf16x2>(v[i])`
+// inside an unrolled loop to element 0 for every i (seen in the ISA: identical instructions), so pairs are always taken
+// with named __builtin_shufflevector selections of the whole bf16x8 vector.
 
-template <typename T> __device__ __forceinline__ void unpack16(const u32x4_t& v, float* out);
-template <> __device__ __forceinline__ void unpack16<float>(const u32x4_t& v, float* out) {
-  const f32x4_t f = __builtin_bit_cast(f32x4_t, v);
-  out[0] = f[0]; out[1] = f[1]; out[2] = f[2]; out[3] = f[3];
-}
-template <> __device__ __forceinline__ void unpack16<bf16_t>(const u32x4_t& v, float* out) {
-  const bf16x8_t f = __builtin_bit_cast(bf16x8_t, v);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) out[i] = (float)f[i];
-}
 template <typename T> __device__ __forceinline__ u32x4_t pack16(const float* in);
 template <> __device__ __forceinline__ u32x4_t pack16<float>(const float* in) {
   return __builtin_bit_cast(u32x4_t, f32x4_t{in[0], in[1], in[2], in[3]});
@@ -158,7 +133,7 @@ __device__ __forceinline__ v8i_t sk_quant_mx8(const u32x4_t (&xv)[4], int& scale
   v8i_t out;
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
-    // named pairs of the whole vector, not bit_cast<bf16x2>(xv[m][q]): hipcc (ROCm 7.2) folds the latter to element 0 (dot16)
+    // named pairs of the whole vector, not bit_cast<bf16x2>(xv[m][q]): hipcc (ROCm 7.2) folds the latter to element 0 (NB at the top)
     const bf16x8_t a = __builtin_bit_cast(bf16x8_t, xv[m]);
     const float X = m < 2 ? X0 : X1;
     s16x2_t lo = {0, 0}, hi = {0, 0};
@@ -184,7 +159,7 @@ template <typename T> __device__ __forceinline__ void sk_stats(const u32x4_t& v,
 template <> __device__ __forceinline__ void sk_stats<bf16_t>(const u32x4_t& v, float& s, float& ss) {
   const bf16x8_t a = __builtin_bit_cast(bf16x8_t, v);
   const bf16x2_t one = {(bf16_t)1.0f, (bf16_t)1.0f};
-  // named pairs, not a loop over v[i]: see dot16 above
+  // named pairs, not a loop over v[i]: see the NB at the top of this file
   const bf16x2_t p0 = __builtin_shufflevector(a, a, 0, 1), p1 = __builtin_shufflevector(a, a, 2, 3);
   const bf16x2_t p2 = __builtin_shufflevector(a, a, 4, 5), p3 = __builtin_shufflevector(a, a, 6, 7);
   s = __builtin_amdgcn_fdot2_f32_bf16(p0, one, s, false);

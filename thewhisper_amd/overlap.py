@@ -67,19 +67,22 @@ class EncoderOverlap:
     """Runs ``encode_fn(engine, batch)`` of batch k + 1 on ``encoder_cus`` compute units while ``decode_fn(engine, batch,
     encoded)`` of batch k runs on the others.  ``engines``: two contexts built from the same weights, same device."""
 
-    def __init__(self, engines: Sequence[WhisperEngine], encoder_cus: int = 64):
+    def __init__(self, engines: Sequence[WhisperEngine], encoder_cus: int = 64, cu_range: Optional[Sequence[int]] = None):
+        """``cu_range = (first, last)`` restricts the whole pipeline to a slice of the chip (several pipelines side by side);
+        default: all compute units.  The last ``encoder_cus`` CUs of the range run the encoder stage."""
         if len(engines) != 2:
             raise ValueError("EncoderOverlap needs exactly two contexts")
         self.engines = list(engines)
         self.device = engines[0].device
         n_cus = torch.cuda.get_device_properties(self.device).multi_processor_count
-        if not 0 < encoder_cus < n_cus:
-            raise ValueError(f"encoder_cus must be in (0, {n_cus})")
+        lo, hi = (0, n_cus) if cu_range is None else (int(cu_range[0]), int(cu_range[1]))
+        if not (0 <= lo < hi <= n_cus) or not 0 < encoder_cus < hi - lo:
+            raise ValueError(f"bad CU partition: range [{lo}, {hi}) of {n_cus}, {encoder_cus} encoder CUs")
         self.encoder_cus, self.n_cus = int(encoder_cus), int(n_cus)
         hip = _hiplib()
         _chk(hip.hipSetDevice(self.device.index or 0), "hipSetDevice")
-        self.s_dec = masked_stream(0, n_cus - encoder_cus, n_cus)
-        self.s_enc = masked_stream(n_cus - encoder_cus, n_cus, n_cus)
+        self.s_dec = masked_stream(lo, hi - encoder_cus, n_cus)
+        self.s_enc = masked_stream(hi - encoder_cus, hi, n_cus)
         self._events: List[int] = []
         for _ in range(2):
             ev = C.c_void_p()
@@ -104,6 +107,7 @@ class EncoderOverlap:
         batches = list(batches)
         free = [threading.Semaphore(1), threading.Semaphore(1)]  # context i may be (re)used by the encode stage
         ready: "queue.Queue" = queue.Queue()
+        stop = threading.Event()                                 # set when the consumer gives up (a stage failed)
         dev_index = self.device.index or 0
 
         def producer():
@@ -113,6 +117,8 @@ class EncoderOverlap:
                 for i, b in enumerate(batches):
                     k = i % 2
                     free[k].acquire()                      # decode of batch i - 2 has returned
+                    if stop.is_set():
+                        return
                     eng = self.engines[k]
                     # the first batch has no decode loop to hide behind: its encoder stage gets the decoder's (idle) CUs
                     s_i = self.s_dec if i == 0 else self.s_enc
@@ -138,6 +144,9 @@ class EncoderOverlap:
                 _chk(hip.hipStreamSynchronize(self.s_dec), "hipStreamSynchronize")
                 free[k].release()
         finally:
+            stop.set()
+            for f in free:
+                f.release()
             th.join(timeout=60)
             for e in self.engines:   # back to torch's current stream for whoever uses the contexts next
                 e.raw_stream = None
