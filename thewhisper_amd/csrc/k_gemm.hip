@@ -6,15 +6,17 @@
 //  * 256 threads = 4 waves in a 2x2 arrangement; block tile BM (activation rows) x BN (weight rows),
 //    K tile = 8 x 16 B per row (64 bf16 / 32 f32).  128x128 for large M, 64x64 when the grid
 //    would otherwise not cover the 256 CUs.
-//  * LDS image: [k-slot 0..7][row ^ slot] of 16-B vectors.  The global->LDS write (8 lanes cover
-//    one 128-B row segment) and the MFMA fragment read (16 lanes read 16 consecutive rows of one
-//    k-slot with ds_read_b128) are both bank-conflict free with this XOR placement.
+//  * LDS image: [row][k-slot ^ ((row>>1)&7)] of 16-B vectors, filled by direct global->LDS DMA
+//    (global_load_lds_dwordx4, swizzle applied on the source side: 8 lanes still cover one 128-B
+//    row segment); the MFMA fragment read (16 lanes = 16 consecutive rows of one k-slot,
+//    ds_read_b128) touches every bank once.
 //  * "swapped" MFMA: the weight tile is the A operand and the activation tile the B operand of
 //    v_mfma_f32_16x16x32_bf16 (or 4 x v_mfma_f32_16x16x4_f32 in strict-f32 mode, using a
 //    k-permutation so that the same 16-B fragment feeds both), so every lane ends up with 4
 //    consecutive output columns of one row -> 8/16-B epilogue stores and vector bias loads.
-//  * register-staged double buffering: the next K tile's global loads are issued before the MFMAs
-//    of the current tile and written to the other LDS buffer afterwards (one barrier per tile).
+//  * double-buffered LDS, one barrier per K tile: the DMA of tile k+1 is issued right after the
+//    barrier that retires tile k and runs under the MFMAs of tile k (no staging registers, no
+//    ds_write pass: 1.2-1.5x the register-staged version of this kernel).
 //  * fused epilogues: bias, exact GELU, residual / positional add, and the head-split / transposed
 //    layouts the attention kernels consume (no separate permute kernels).
 #include "tw_common.h"
@@ -85,27 +87,40 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A, RowM
   const int n0 = blockIdx.x * BN;
   const int m0 = blockIdx.y * BM;
 
-  // per-thread global source pointers (fixed rows, advancing along K)
+  // Global -> LDS by direct DMA (global_load_lds_dwordx4): no staging registers, no ds_write pass.  The DMA writes the 64
+  // lanes of a wavefront to 64 consecutive 16-B LDS slots, so the swizzle is applied on the SOURCE side: linear LDS
+  // position p (16-B units) of a tile holds row p>>3, k-slot (p&7) ^ ((row>>1)&7); 8 consecutive lanes still cover one
+  // 128-B row segment of global memory (coalesced), and the fragment read - 16 lanes = 16 consecutive rows of one k-slot,
+  // ds_read_b128 - touches every bank exactly once.
   const T* asrc[AV];
-  int adst[AV];
 #pragma unroll
   for (int i = 0; i < AV; ++i) {
-    const int v = i * 256 + tid;
-    const int row = v >> 3, slot = v & 7;
+    const int p = (i * 4 + wave) * 64 + lane;
+    const int row = p >> 3, slot = (p & 7) ^ ((row >> 1) & 7);
     int m = m0 + row;
     if (m >= M) m = M - 1;
     asrc[i] = A + rowmap(amap, m) + slot * E;
-    adst[i] = slot * BM + (row ^ slot);
   }
   const T* wsrc[WV];
-  int wdst[WV];
 #pragma unroll
   for (int i = 0; i < WV; ++i) {
-    const int v = i * 256 + tid;
-    const int row = v >> 3, slot = v & 7;
+    const int p = (i * 4 + wave) * 64 + lane;
+    const int row = p >> 3, slot = (p & 7) ^ ((row >> 1) & 7);
     wsrc[i] = W + (long long)(n0 + row) * K + slot * E;
-    wdst[i] = slot * BN + (row ^ slot);
   }
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto issue_tile = [&](int kt, int b) {
+    const int koff = kt * BKE;
+    u32x4_t* sa = ldsA + b * 8 * BM;
+    u32x4_t* sw = ldsW + b * 8 * BN;
+#pragma unroll
+    for (int i = 0; i < AV; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + koff), (lptr_t)(sa + (i * 4 + wave) * 64), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < WV; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + koff), (lptr_t)(sw + (i * 4 + wave) * 64), 16, 0, 0);
+  };
 
   f32x4_t acc[NT][MT];
 #pragma unroll
@@ -113,30 +128,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A, RowM
 #pragma unroll
     for (int b = 0; b < MT; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  u32x4_t areg[AV], wreg[WV];
   const int nk = K / BKE;
-#pragma unroll
-  for (int i = 0; i < AV; ++i) areg[i] = *reinterpret_cast<const u32x4_t*>(asrc[i]);
-#pragma unroll
-  for (int i = 0; i < WV; ++i) wreg[i] = *reinterpret_cast<const u32x4_t*>(wsrc[i]);
-#pragma unroll
-  for (int i = 0; i < AV; ++i) ldsA[adst[i]] = areg[i];
-#pragma unroll
-  for (int i = 0; i < WV; ++i) ldsW[wdst[i]] = wreg[i];
-  __syncthreads();
-
   const int fr = lane & 15;  // fragment row within a 16-row tile
   const int fq = lane >> 4;  // k-slot quad
+  issue_tile(0, 0);
   int buf = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    const bool more = (kt + 1) < nk;
-    if (more) {
-      const int koff = (kt + 1) * BKE;
-#pragma unroll
-      for (int i = 0; i < AV; ++i) areg[i] = *reinterpret_cast<const u32x4_t*>(asrc[i] + koff);
-#pragma unroll
-      for (int i = 0; i < WV; ++i) wreg[i] = *reinterpret_cast<const u32x4_t*>(wsrc[i] + koff);
-    }
+    // tile kt has landed (this wavefront's DMA: vmcnt; the other wavefronts': barrier) and every wavefront is done
+    // reading the other buffer (it was consumed in iteration kt-1), so the next tile can be streamed into it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) issue_tile(kt + 1, buf ^ 1);
     const u32x4_t* la = ldsA + buf * 8 * BM;
     const u32x4_t* lw = ldsW + buf * 8 * BN;
 #pragma unroll
@@ -146,27 +148,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A, RowM
 #pragma unroll
       for (int b = 0; b < MT; ++b) {
         const int row = wm * (BM / 2) + b * 16 + fr;
-        af[b] = la[slot * BM + (row ^ slot)];
+        af[b] = la[row * 8 + (slot ^ ((row >> 1) & 7))];
       }
 #pragma unroll
       for (int a = 0; a < NT; ++a) {
         const int row = wn * (BN / 2) + a * 16 + fr;
-        wf[a] = lw[slot * BN + (row ^ slot)];
+        wf[a] = lw[row * 8 + (slot ^ ((row >> 1) & 7))];
       }
 #pragma unroll
       for (int a = 0; a < NT; ++a)
 #pragma unroll
         for (int b = 0; b < MT; ++b) acc[a][b] = mfma_step<T>(wf[a], af[b], acc[a][b]);
     }
-    if (more) {
-      u32x4_t* sa = ldsA + (buf ^ 1) * 8 * BM;
-      u32x4_t* sw = ldsW + (buf ^ 1) * 8 * BN;
-#pragma unroll
-      for (int i = 0; i < AV; ++i) sa[adst[i]] = areg[i];
-#pragma unroll
-      for (int i = 0; i < WV; ++i) sw[wdst[i]] = wreg[i];
-    }
-    __syncthreads();
     buf ^= 1;
   }
 
