@@ -191,7 +191,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--chunk-s", type=int, default=10)
-    ap.add_argument("--streams", type=int, default=16, help="concurrent streams per GPU")
+    ap.add_argument("--streams", type=int, default=16, help="concurrent streams per GPU (1..64; 16 = the per-GPU share of BASELINE configs[3])")
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"],
                     help="fp8 = bf16 activations/encoder + MXFP8 decoder projection weights (BASELINE config 5)")

@@ -66,7 +66,7 @@ typedef struct tw_config {
                                     load time exactly like patch_hf_model
                                     (R:thestage_speechkit/nvidia/asr_pipeline.py:15-27). */
   int32_t target_positions;      /* decoder positions, 448 */
-  int32_t max_batch;             /* concurrent streams per call */
+  int32_t max_batch;             /* concurrent streams per call: 1..64 (1..16 with TW_BF16_MXFP8) */
   int32_t dtype;                 /* TW_BF16 (production), TW_F32 (strict-parity mode) or TW_BF16_MXFP8 (fp8 decoder weights) */
   int32_t n_align_heads;         /* alignment heads for word timestamps (generation_config.alignment_heads) */
   int32_t align_heads[2 * TW_MAX_ALIGN_HEADS]; /* (layer, head) pairs */

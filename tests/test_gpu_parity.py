@@ -97,6 +97,8 @@ DEC_CASES = [
     ("micro", 100, 16, "bf16", 2, 3e-2), ("large-v3", 500, 1, "f32", 1, 2e-5), ("large-v3", 500, 2, "bf16", 1, 3e-2),
     ("large-v3", 500, 16, "bf16", 1, 3e-2), ("tiny.en", 1500, 5, "f32", 4, 5e-5), ("micro", 100, 2, "f32", 0, 2e-5),
     ("micro", 750, 2, "f32", 2, 2e-5), ("micro", 750, 3, "bf16", 2, 3e-2),   # 15 s chunks: two key chunks, second one partial
+    ("micro", 100, 17, "f32", 2, 2e-5), ("micro", 100, 40, "bf16", 2, 3e-2), ("micro", 100, 64, "f32", 1, 2e-5),  # > 16 streams: groups of 16
+    ("large-v3", 500, 32, "bf16", 1, 3e-2),
 ]
 
 
@@ -203,7 +205,8 @@ def test_logits_golden_reference_topk():
 
 # ---------------------------------------------------------------- A9-A11
 GREEDY_CASES = [("micro", 100, 1, 24, False, 0), ("micro", 100, 3, 24, True, 0), ("micro", 500, 2, 40, True, 40),
-                ("micro80", 100, 2, 24, False, 0), ("micro", 100, 16, 20, True, 0), ("micro", 750, 2, 24, True, 0)]
+                ("micro80", 100, 2, 24, False, 0), ("micro", 100, 16, 20, True, 0), ("micro", 750, 2, 24, True, 0),
+                ("micro", 100, 33, 12, True, 0)]
 
 
 @pytest.mark.parametrize("preset,T,B,max_new,graph,min_new", GREEDY_CASES)

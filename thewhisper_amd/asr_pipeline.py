@@ -83,7 +83,7 @@ class ASRPipeline(AutomaticSpeechRecognitionPipeline):
         # A0 (patch_hf_model) happens inside the library when the engine is built for T = 50*chunk_length_s.
         batch_size = int(kwargs.get("batch_size") or 1)
         engine = self.model.build_engine(
-            chunk_length_s=chunk_length_s, max_batch=max(1, min(16, batch_size)), dtype=torch_dtype,
+            chunk_length_s=chunk_length_s, max_batch=max(1, min(64, batch_size)), dtype=torch_dtype,
             engine_factory=engine_factory, decoder_weights=decoder_weights,
         )
         self.feature_extractor.attach_engine(engine)

@@ -76,7 +76,7 @@ struct tw_ctx {
   int* begin_suppress_dev = nullptr; int* suppress_dev = nullptr;
   SamplerPartial* sampler_partials = nullptr;
   unsigned* suppress_bits = nullptr;  // [(V+31)/32] static suppress list as a bitmap, rebuilt per generate call
-  int* h_pinned = nullptr;  // pinned host scratch: finished ring [8][Bmax] + misc
+  int* h_pinned = nullptr;  // pinned host scratch: finished ring [8][64] | n_valid [64] | DecState upload [16]
   hipEvent_t ring_ev[8]{};
   int last_seq_len = 0, last_n_prompt = 0;
   int dec_key_bound = 0;  // upper bound of decoder positions for the current decode (prompt + max new tokens)
@@ -214,7 +214,8 @@ int tw_create(const tw_config* cfg, tw_ctx** out) {
     return fail(nullptr, TW_EINVAL, "TW_BF16_MXFP8 needs d_model and ffn to be multiples of 128");
   if (cfg->d_model % 64 || cfg->ffn % 64 || cfg->d_model > 1280)
     return fail(nullptr, TW_EINVAL, "d_model/ffn must be multiples of 64 and d_model <= 1280");
-  if (cfg->max_batch < 1 || cfg->max_batch > 16) return fail(nullptr, TW_EINVAL, "max_batch must be in [1,16]");
+  if (cfg->max_batch < 1 || cfg->max_batch > 64) return fail(nullptr, TW_EINVAL, "max_batch must be in [1,64]");
+  if (cfg->dtype == TW_BF16_MXFP8 && cfg->max_batch > 16) return fail(nullptr, TW_EINVAL, "TW_BF16_MXFP8: max_batch must be in [1,16]");
   if (cfg->source_positions < 8 || cfg->source_positions > 1500 || cfg->target_positions < 8 || cfg->target_positions > 511)
     return fail(nullptr, TW_EINVAL, "source_positions must be in [8,1500], target_positions in [8,511]");
   if (cfg->n_align_heads < 0 || cfg->n_align_heads > TW_MAX_ALIGN_HEADS) return fail(nullptr, TW_EINVAL, "bad n_align_heads");
@@ -241,7 +242,7 @@ int tw_create(const tw_config* cfg, tw_ctx** out) {
   CHIP(hipStreamCreate(&c->own_stream));
   for (int i = 0; i < 5; ++i) { CHIP(hipEventCreate(&c->ev0[i])); CHIP(hipEventCreate(&c->ev1[i])); }
   for (int i = 0; i < 8; ++i) CHIP(hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming));
-  CHIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), sizeof(int) * (8 * 16 + 64), hipHostMallocDefault));
+  CHIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), sizeof(int) * (8 * 64 + 64 + 16), hipHostMallocDefault));
 
   const size_t e = c->esz;
   const size_t d = c->d, H = c->H, F = c->ffn, V = c->V, T = c->T, Tp = c->Tp, P = c->P, C = c->C, B = c->Bmax;
@@ -326,9 +327,10 @@ int tw_create(const tw_config* cfg, tw_ctx** out) {
   CALLOC(c->self_v, Ld * B * Pp * d * e, true);
   CALLOC(c->cross_k, Ld * B * Tp * d * e, true);
   CALLOC(c->cross_v, Ld * B * Tp * d * e, true);
-  // per-token decoder activations that feed a projection are fragment-major and always 16 streams wide (tw_xt_index)
-  CALLOC(c->dx0, 16 * d * e, true); CALLOC(c->dx1, 16 * d * e, true); CALLOC(c->dq, B * d * e, true);
-  CALLOC(c->datt, 16 * d * e, true); CALLOC(c->dh, 16 * F * e, true);
+  // per-token decoder activations that feed a projection are fragment-major in groups of 16 streams (tw_xt_index)
+  const size_t Bg = (B + 15) / 16 * 16;  // whole groups of 16 streams
+  CALLOC(c->dx0, Bg * d * e, true); CALLOC(c->dx1, Bg * d * e, true); CALLOC(c->dq, B * d * e, true);
+  CALLOC(c->datt, Bg * d * e, true); CALLOC(c->dh, Bg * F * e, true);
   CALLOC(c->logits, B * V * 4, true);
   const size_t Ha = c->Ha > 0 ? c->Ha : 1;
   CALLOC(c->align, B * Ha * P * T * 4, true);
@@ -346,7 +348,7 @@ int tw_create(const tw_config* cfg, tw_ctx** out) {
   CALLOC(c->last_ts, B * 4, true); CALLOC(c->stt, sizeof(DecState), true);
   CALLOC(c->begin_suppress_dev, 64 * 4, true); CALLOC(c->suppress_dev, 1024 * 4, true);
   CALLOC(c->suppress_bits, ((V + 31) / 32 + 2048) * 4, true);
-  CALLOC(c->sampler_partials, 16 * 8 * sizeof(SamplerPartial), true);
+  CALLOC(c->sampler_partials, 64 * 8 * sizeof(SamplerPartial), true);
   // ---- dtw workspace ----
   CALLOC(c->zbuf, B * Ha * P * T * 4, false);
   CALLOC(c->mat, B * P * T * 4, false);
@@ -541,8 +543,8 @@ int tw_logmel(tw_ctx* c, const float* pcm, int64_t pcm_stride, const int32_t* n_
   hipStream_t st = pick_stream(c, stream);
   const int* nv = nullptr;
   if (n_valid_host) {
-    memcpy(c->h_pinned + 128, n_valid_host, sizeof(int) * B);
-    HIPCHK(c, hipMemcpyAsync(c->n_valid_dev, c->h_pinned + 128, sizeof(int) * B, hipMemcpyHostToDevice, st));
+    memcpy(c->h_pinned + 512, n_valid_host, sizeof(int) * B);
+    HIPCHK(c, hipMemcpyAsync(c->n_valid_dev, c->h_pinned + 512, sizeof(int) * B, hipMemcpyHostToDevice, st));
     nv = c->n_valid_dev;
   }
   tic(c, 0, st);
@@ -711,8 +713,8 @@ int decode_core(tw_ctx* c, int B, hipStream_t st) {
 
 int reset_state(tw_ctx* c, int n_prompt, hipStream_t st) {
   DecState s{0, n_prompt, 0, 0};
-  memcpy(c->h_pinned + 192 - 8, &s, sizeof s);
-  HIPCHK(c, hipMemcpyAsync(c->stt, c->h_pinned + 192 - 8, sizeof s, hipMemcpyHostToDevice, st));
+  memcpy(c->h_pinned + 576, &s, sizeof s);
+  HIPCHK(c, hipMemcpyAsync(c->stt, c->h_pinned + 576, sizeof s, hipMemcpyHostToDevice, st));
   return TW_OK;
 }
 
@@ -829,13 +831,13 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
     }
     ++steps;
     const int slot = s % 8;
-    HIPCHK(c, hipMemcpyAsync(c->h_pinned + slot * 16, c->finished, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(c->h_pinned + slot * 64, c->finished, sizeof(int) * B, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipEventRecord(c->ring_ev[slot], st));
     if (s >= LAG) {
       const int ps = (s - LAG) % 8;
       HIPCHK(c, hipEventSynchronize(c->ring_ev[ps]));
       bool done = true;
-      for (int b = 0; b < B; ++b) done &= (c->h_pinned[ps * 16 + b] != 0);
+      for (int b = 0; b < B; ++b) done &= (c->h_pinned[ps * 64 + b] != 0);
       all_done = done;
     }
   }

@@ -198,14 +198,18 @@ template <> __device__ __forceinline__ void sk_stats<float>(const u32x4_t& v, fl
 // one 128-wide k step are exactly one scale block, so no cross-lane reduction is needed), and the product runs on
 // v_mfma_scale_f32_16x16x128_f8f6f4, which applies both block scales in hardware.  One step is then 128 k: 2 KiB of
 // weights + 64 scale bytes per tile, half the bytes of the bf16 kernel.
-template <typename T, int NW, int SK_MAXS, bool LN, int EPI, bool MULTI, bool W8>
-__global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (W8 ? (SK_MAXS <= 2 ? 4 : 2) : (SK_MAXS <= 5 ? 4 : 2)))) void skinny_mfma_kernel(GemvArgs a) {
+// CG = groups of 16 streams (1, 2 or 4: up to 64 streams per launch).  Every weight fragment is used for all groups, so the
+// weight stream - the dominant cost - is paid once per launch whatever the number of streams; activations, accumulators
+// and the epilogue are per group (group g of a fragment-major activation buffer starts at element g*16*K).
+template <typename T, int NW, int SK_MAXS, bool LN, int EPI, bool MULTI, bool W8, int CG>
+__global__ __launch_bounds__(NW * 64, (CG > 1 ? (NW >= 16 ? 4 : 2) : (NW >= 16 ? 4 : (W8 ? (SK_MAXS <= 2 ? 4 : 2) : (SK_MAXS <= 5 ? 4 : 2)))))
+void skinny_mfma_kernel(GemvArgs a) {
   static_assert(!W8 || sizeof(T) == 2, "MXFP8 weights go with bf16 activations");
   constexpr int E = ElemTraits<T>::kPer16B;
   constexpr int XPS = W8 ? 4 : 1;  // 32-wide activation fragments per MFMA step
   constexpr int WPS = W8 ? 2 : 1;  // 16-B weight requests per MFMA step
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ float pstat[NW][16][2];  // per wavefront and stream: (sum, sum of squares) over the wavefront's K slice
+  __shared__ float pstat[NW][CG * 16][2];  // per wavefront and stream: (sum, sum of squares) over the wavefront's K slice
   const T* x = reinterpret_cast<const T*>(a.x);
   const T* W = reinterpret_cast<const T*>(a.W);
   const unsigned char* wscale = a.wscale;
@@ -235,25 +239,30 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (W8 ? (SK_MAXS <= 2 ? 4 : 
   const int fr = lane & 15, kq = lane >> 4;
   const int S = K / (4 * E * XPS);  // MFMA steps per row (32 k each; 128 k with MXFP8 weights)
   const int s_lo = (int)((long long)wave * S / NW), s_hi = (int)((long long)(wave + 1) * S / NW);
-  float* red = reinterpret_cast<float*>(smem);  // [NW][256]
+  float* red = reinterpret_cast<float*>(smem);  // [NW][CG][256]
   const int n_tiles = (N + 15) / 16;
   const int tile0 = blockIdx.x * RG;
   const int ej = (tid >> 4) & 15, ei = tid & 15;  // epilogue role of threads 0..255: stream ej, tile row ei
 
-  u32x4_t wq[SK_MAXS * WPS], xq[SK_MAXS * XPS];
+  u32x4_t wq[SK_MAXS * WPS], xq[CG][SK_MAXS * XPS];
   int wsc[SK_MAXS];  // MXFP8: scale byte of this lane's 32-value weight block
-  float e_c = 0.f, e_gw = 0.f, e_res = 0.f;
+  float e_c = 0.f, e_gw = 0.f, e_res[CG];
+#pragma unroll
+  for (int g = 0; g < CG; ++g) e_res[g] = 0.f;
   // --- request helpers: all unconditional, addresses clamped into the matrix ---
-  auto load_epi = [&](int tile, float& c, float& g, float& r) {
+  auto load_epi = [&](int tile, float& c, float& gwv, float (&r)[CG]) {
     const int n = min(tile * 16 + ei, N - 1);
     if (LN) {
-      g = gw_p[n];
+      gwv = gw_p[n];
       c = cb_p[n];
     } else {
       const float v = (float)(bias ? bias : W)[bias ? n : 0];
       c = bias ? v : 0.f;
     }
-    if (EPI == SK_RES) r = (float)res[tw_xt_index<T>(ej, n)];
+    if (EPI == SK_RES) {
+#pragma unroll
+      for (int g = 0; g < CG; ++g) r[g] = (float)res[(long long)g * 16 * N + tw_xt_index<T>(ej, n)];
+    }
   };
   auto load_w = [&](int tile, int s0) {  // fragment-major weights: 1 KiB contiguous per wavefront request
     const int tl = min(tile, n_tiles - 1);
@@ -276,10 +285,13 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (W8 ? (SK_MAXS <= 2 ? 4 : 
   auto load_x = [&](int s0) {            // fragment-major activations: lane (stream fr, k-group kq) of each 32-k step
     const T* xt = x + (long long)lane * E;
 #pragma unroll
-    for (int i = 0; i < SK_MAXS; ++i)
+    for (int g = 0; g < CG; ++g)
 #pragma unroll
-      for (int m = 0; m < XPS; ++m)
-        xq[i * XPS + m] = *reinterpret_cast<const u32x4_t*>(xt + ((long long)min(s0 + i, S - 1) * XPS + m) * (64 * E));
+      for (int i = 0; i < SK_MAXS; ++i)
+#pragma unroll
+        for (int m = 0; m < XPS; ++m)
+          xq[g][i * XPS + m] = *reinterpret_cast<const u32x4_t*>(xt + (long long)g * 16 * K +
+                                                                   ((long long)min(s0 + i, S - 1) * XPS + m) * (64 * E));
   };
 
   load_x(s_lo);
@@ -289,33 +301,44 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (W8 ? (SK_MAXS <= 2 ? 4 : 
   __builtin_amdgcn_sched_barrier(0);  // ... nor hoist arithmetic between the requests
   TW_TS(1);
 
-  float mean = 0.f, rstd = 1.f;
+  float mean[CG], rstd[CG];
+#pragma unroll
+  for (int g = 0; g < CG; ++g) { mean[g] = 0.f; rstd[g] = 1.f; }
   const int n_grp = MULTI ? RG : 1;
   for (int grp = 0; grp < n_grp; ++grp) {
     const int tile = tile0 + grp;
-    f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    float ps = 0.f, pss = 0.f;
+    f32x4_t acc[CG];
+    float ps[CG], pss[CG];
+#pragma unroll
+    for (int g = 0; g < CG; ++g) { acc[g] = f32x4_t{0.f, 0.f, 0.f, 0.f}; ps[g] = 0.f; pss[g] = 0.f; }
     auto mfma_round = [&](int s0) {
 #pragma unroll
       for (int i = 0; i < SK_MAXS; ++i) {
         const bool on = s0 + i < s_hi;  // wave-uniform: steps past this wavefront's K slice contribute zero
         const u32x4_t zero = u32x4_t{0u, 0u, 0u, 0u};
         if (W8) {
-          u32x4_t xv[4];
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            xv[m] = on ? xq[i * 4 + m] : zero;
-            if (LN && (!MULTI || grp == 0)) sk_stats<T>(xv[m], ps, pss);
-          }
-          int xs;
-          const v8i_t xb = sk_quant_mx8(xv, xs);
           const u32x4_t w0 = on ? wq[2 * i] : zero, w1 = on ? wq[2 * i + 1] : zero;
           const v8i_t wb = {(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
-          acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wb, xb, acc, 0, 0, 0, wsc[i], 0, xs);
+#pragma unroll
+          for (int g = 0; g < CG; ++g) {
+            u32x4_t xv[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              xv[m] = on ? xq[g][i * 4 + m] : zero;
+              if (LN && (!MULTI || grp == 0)) sk_stats<T>(xv[m], ps[g], pss[g]);
+            }
+            int xs;
+            const v8i_t xb = sk_quant_mx8(xv, xs);
+            acc[g] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wb, xb, acc[g], 0, 0, 0, wsc[i], 0, xs);
+          }
         } else {
-          const u32x4_t xv = on ? xq[i] : zero;
-          if (LN && (!MULTI || grp == 0)) sk_stats<T>(xv, ps, pss);
-          acc = sk_mfma<T>(on ? wq[i] : zero, xv, acc);
+          const u32x4_t wv = on ? wq[i] : zero;
+#pragma unroll
+          for (int g = 0; g < CG; ++g) {
+            const u32x4_t xv = on ? xq[g][i] : zero;
+            if (LN && (!MULTI || grp == 0)) sk_stats<T>(xv, ps[g], pss[g]);
+            acc[g] = sk_mfma<T>(wv, xv, acc[g]);
+          }
         }
       }
     };
@@ -327,7 +350,9 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (W8 ? (SK_MAXS <= 2 ? 4 : 
     }
     // operands of the tile after this one are requested now, behind the reduction and the epilogue of the current one
     // (MULTI is only launched with a single round of fragments per tile, so the activation fragments stay in registers)
-    float n_c = 0.f, n_gw = 0.f, n_res = 0.f;
+    float n_c = 0.f, n_gw = 0.f, n_res[CG];
+#pragma unroll
+    for (int g = 0; g < CG; ++g) n_res[g] = 0.f;
     if (MULTI) {
       const int nt = min(tile + 1, n_tiles - 1);
       load_w(nt, s_lo);
@@ -337,53 +362,65 @@ __global__ __launch_bounds__(NW * 64, (NW >= 16 ? 4 : (W8 ? (SK_MAXS <= 2 ? 4 : 
     // D[i = weight row (lane>>4)*4 + reg][j = stream lane&15]
     if (MULTI && grp > 0) __syncthreads();  // previous tile's readers are done with `red`
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave * 256 + (kq * 4 + r) * 16 + fr] = acc[r];
+    for (int g = 0; g < CG; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wave * CG + g) * 256 + (kq * 4 + r) * 16 + fr] = acc[g][r];
     if (LN && (!MULTI || grp == 0)) {
-      ps = tw_xor32_sum(tw_xor16_sum(ps));
-      pss = tw_xor32_sum(tw_xor16_sum(pss));
-      if (lane < 16) { pstat[wave][fr][0] = ps; pstat[wave][fr][1] = pss; }
+#pragma unroll
+      for (int g = 0; g < CG; ++g) {
+        const float s1 = tw_xor32_sum(tw_xor16_sum(ps[g])), s2 = tw_xor32_sum(tw_xor16_sum(pss[g]));
+        if (lane < 16) { pstat[wave][g * 16 + fr][0] = s1; pstat[wave][g * 16 + fr][1] = s2; }
+      }
     }
     __syncthreads();
     TW_TS(3);
     if (tid < 256) {
-      const int j = ej, i = ei;  // stream, row: 16 consecutive rows of one stream per 16 threads
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) v += red[w * 256 + i * 16 + j];
+      const int j = ej, i = ei;  // stream (within its group), row: 16 consecutive rows of one stream per 16 threads
       const int n = tile * 16 + i;
-      if (LN) {
-        if (!MULTI || grp == 0) {
-          float sx = 0.f, sxx = 0.f;
 #pragma unroll
-          for (int w = 0; w < NW; ++w) { sx += pstat[w][j][0]; sxx += pstat[w][j][1]; }
-          const float inv_k = __builtin_amdgcn_rcpf((float)K);
-          mean = sx * inv_k;
-          rstd = __frsqrt_rn(fmaxf(sxx * inv_k - mean * mean, 0.f) + 1e-5f);
-        }
-        v = rstd * (v - mean * e_gw) + e_c;
-      } else {
-        v += e_c;
-      }
-      if (EPI == SK_GELU) v = gelu_exact(v);
-      if (EPI == SK_RES) v += e_res;
-      if (tile < n_tiles && n < N && j < B) {
-        if (EPI == SK_F32) {
-          y_f32[(long long)j * N + n] = v;
-        } else if (EPI == SK_KV) {
-          const int seg = n / d_model;  // 0: query -> y, 1: key -> K cache, 2: value -> V^T cache   (one predicated store)
-          const int nn = n - seg * d_model, hh = nn >> 6, cc = nn & 63;
-          const long long hb = (long long)j * cache_bstride + (long long)hh * (cache_bstride / (d_model >> 6));  // (stream, head)
-          T* dst = seg == 0 ? y + (long long)j * ldy + n
-                            : (seg == 1 ? kcache + hb + tw_kf_index<T>(cur_pos, cc) : vcache + hb + tw_vtf_index<T>(cur_pos, cc));
-          *dst = (T)v;
-        } else if (EPI == SK_STORE) {
-          y[(long long)j * ldy + n] = (T)v;  // row-major [B][ldy] (the attention kernels' query operand)
+      for (int g = 0; g < CG; ++g) {
+        const int jg = g * 16 + j;  // stream
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[(w * CG + g) * 256 + i * 16 + j];
+        if (LN) {
+          if (!MULTI || grp == 0) {
+            float sx = 0.f, sxx = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { sx += pstat[w][jg][0]; sxx += pstat[w][jg][1]; }
+            const float inv_k = __builtin_amdgcn_rcpf((float)K);
+            mean[g] = sx * inv_k;
+            rstd[g] = __frsqrt_rn(fmaxf(sxx * inv_k - mean[g] * mean[g], 0.f) + 1e-5f);
+          }
+          v = rstd[g] * (v - mean[g] * e_gw) + e_c;
         } else {
-          y[tw_xt_index<T>(j, n)] = (T)v;    // feeds the next projection: fragment-major
+          v += e_c;
+        }
+        if (EPI == SK_GELU) v = gelu_exact(v);
+        if (EPI == SK_RES) v += e_res[g];
+        if (tile < n_tiles && n < N && jg < B) {
+          if (EPI == SK_F32) {
+            y_f32[(long long)jg * N + n] = v;
+          } else if (EPI == SK_KV) {
+            const int seg = n / d_model;  // 0: query -> y, 1: key -> K cache, 2: value -> V^T cache   (one predicated store)
+            const int nn = n - seg * d_model, hh = nn >> 6, cc = nn & 63;
+            const long long hb = (long long)jg * cache_bstride + (long long)hh * (cache_bstride / (d_model >> 6));  // (stream, head)
+            T* dst = seg == 0 ? y + (long long)jg * ldy + n
+                              : (seg == 1 ? kcache + hb + tw_kf_index<T>(cur_pos, cc) : vcache + hb + tw_vtf_index<T>(cur_pos, cc));
+            *dst = (T)v;
+          } else if (EPI == SK_STORE) {
+            y[(long long)jg * ldy + n] = (T)v;  // row-major [B][ldy] (the attention kernels' query operand)
+          } else {
+            y[(long long)g * 16 * N + tw_xt_index<T>(j, n)] = (T)v;    // feeds the next projection: fragment-major
+          }
         }
       }
     }
-    if (MULTI) { e_c = n_c; e_gw = n_gw; e_res = n_res; }
+    if (MULTI) {
+      e_c = n_c; e_gw = n_gw;
+#pragma unroll
+      for (int g = 0; g < CG; ++g) e_res[g] = n_res[g];
+    }
     TW_TS(4);
   }
 }
@@ -603,7 +640,8 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const T* __restrict_
   const int n_keys = stt->pos + 1;
   const long long base = ((long long)b * H + h) * rows * 64;
   // the host guarantees pos < key_bound (a multiple of 64, <= rows): the requests do not wait for `pos`
-  attn_mfma_block<T, 4, SINGLE>(q + ((long long)b * H + h) * 64, kc + base, vc + base, n_keys, key_bound, sc, red, out, b, h * 64);
+  attn_mfma_block<T, 4, SINGLE>(q + ((long long)b * H + h) * 64, kc + base, vc + base, n_keys, key_bound, sc, red,
+                                out + (long long)(b >> 4) * 16 * H * 64, b & 15, h * 64);  // fragment-major, groups of 16 streams
 }
 
 template <typename T, bool SINGLE>
@@ -619,8 +657,8 @@ __global__ __launch_bounds__(512) void dec_cross_attn_kernel(const T* __restrict
                "s"(stt));
   const int h = blockIdx.x, b = blockIdx.y;
   const long long base = ((long long)b * H + h) * Tp * 64;
-  const float inv = attn_mfma_block<T, 8, SINGLE>(q + ((long long)b * H + h) * 64, ck + base, cv + base, Tlen, Tp, sc, red, out,
-                                                  b, h * 64);
+  const float inv = attn_mfma_block<T, 8, SINGLE>(q + ((long long)b * H + h) * 64, ck + base, cv + base, Tlen, Tp, sc, red,
+                                                  out + (long long)(b >> 4) * 16 * H * 64, b & 15, h * 64);
   const int slot = align_slot ? align_slot[h] : -1;
   if (slot >= 0) {  // A11 side output: softmax row of an alignment head
     __syncthreads();
@@ -805,8 +843,8 @@ __global__ __launch_bounds__(256) void sampler_part_kernel(SamplerArgs a) {
 
 // wavefront b <- stream b; thread 0 advances the position once every wavefront has used it
 __global__ __launch_bounds__(1024) void sampler_finish_kernel(SamplerArgs a) {
-  const int tid = threadIdx.x, lane = tid & 63, b = tid >> 6;
-  if (b < a.B) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int b = tid >> 6; b < a.B; b += 16) {  // wavefront w <- streams w, w+16, ...
     const SamplerMask k = sampler_mask(a, b);
     SamplerPartial p = a.partials[b * SAMPLER_NS + min(lane, SAMPLER_NS - 1)];
     const bool on = lane < SAMPLER_NS;
@@ -853,10 +891,11 @@ static int env_int(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-template <typename T, int NW, int SK_MAXS, bool MULTI, bool W8>
-static hipError_t skinny_launch_v(const GemvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+template <typename T, int NW, int SK_MAXS, bool MULTI, bool W8, int CG>
+static hipError_t skinny_launch_cg(const GemvArgs& a, dim3 grid, size_t lds1, hipStream_t st) {
   const bool ln = a.ln_gw != nullptr;
-#define SK_GO(LNV, EPIV) hipLaunchKernelGGL((skinny_mfma_kernel<T, NW, SK_MAXS, LNV, EPIV, MULTI, W8>), grid, dim3(NW * 64), lds, st, a)
+  const size_t lds = lds1 * CG;
+#define SK_GO(LNV, EPIV) hipLaunchKernelGGL((skinny_mfma_kernel<T, NW, SK_MAXS, LNV, EPIV, MULTI, W8, CG>), grid, dim3(NW * 64), lds, st, a)
   if constexpr (NW >= 16) {  // 16 wavefronts per tile only for the long-K residual projections (fc2)
     if (ln || a.y_f32 || a.kcache || a.gelu) return hipErrorInvalidValue;
     if (a.res) SK_GO(false, SK_RES);
@@ -882,24 +921,38 @@ static hipError_t skinny_launch_v(const GemvArgs& a, dim3 grid, size_t lds, hipS
   return hipGetLastError();
 }
 
+template <typename T, int NW, int SK_MAXS, bool MULTI, bool W8>
+static hipError_t skinny_launch_v(const GemvArgs& a, dim3 grid, size_t lds1, hipStream_t st) {
+  if (a.B <= 16) return skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 1>(a, grid, lds1, st);
+  // several groups of 16 streams: 8 wavefronts x 5 fragments in flight (more rounds for long K) keeps the per-group
+  // activation fragments inside the register file; MXFP8 contexts are limited to one group
+  if constexpr (W8 || NW != 8 || SK_MAXS != 5) {
+    return hipErrorInvalidValue;
+  } else {
+    if (a.B <= 32) return skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 2>(a, grid, lds1, st);
+    return skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 4>(a, grid, lds1, st);
+  }
+}
+
 template <typename T, int NW>
 static hipError_t skinny_launch_nw(const GemvArgs& a0, hipStream_t st) {
   constexpr int E = ElemTraits<T>::kPer16B;
   GemvArgs a = a0;
-  if (a.K % (4 * E) != 0 || a.B > 16) return hipErrorInvalidValue;
+  if (a.K % (4 * E) != 0 || a.B > 64) return hipErrorInvalidValue;
   const size_t lds = (size_t)NW * 256 * 4;
   const int tiles = (a.N + 15) / 16;
   // at most `max_blocks` workgroups: tall matrices (the tied logits projection) walk several tiles per workgroup
   static const int max_blocks = env_int("TW_SK_MAX_BLOCKS", 512);
   const int steps_per_wave = (a.K / E / 4 + NW - 1) / NW;
+  const bool groups = a.B > 16;  // several groups of 16 streams: 5 fragments in flight, further rounds for longer K
   a.rg = (tiles + max_blocks - 1) / max_blocks;
-  if (a.rg < 1 || steps_per_wave > 10) a.rg = 1;  // several tiles per workgroup only with one round of fragments per tile
+  if (a.rg < 1 || steps_per_wave > (groups ? 5 : 10)) a.rg = 1;  // several tiles per workgroup only with one round per tile
   dim3 grid((tiles + a.rg - 1) / a.rg);
   if (a.rg > 1) {
-    if (steps_per_wave <= 5) return skinny_launch_v<T, NW, 5, true, false>(a, grid, lds, st);
+    if (steps_per_wave <= 5 || groups) return skinny_launch_v<T, NW, 5, true, false>(a, grid, lds, st);
     return skinny_launch_v<T, NW, 10, true, false>(a, grid, lds, st);
   }
-  if (steps_per_wave <= 5) return skinny_launch_v<T, NW, 5, false, false>(a, grid, lds, st);
+  if (steps_per_wave <= 5 || groups) return skinny_launch_v<T, NW, 5, false, false>(a, grid, lds, st);
   return skinny_launch_v<T, NW, 10, false, false>(a, grid, lds, st);
 }
 
@@ -907,7 +960,7 @@ static hipError_t skinny_launch_nw(const GemvArgs& a0, hipStream_t st) {
 template <int NW>
 static hipError_t skinny_launch_w8(const GemvArgs& a0, hipStream_t st) {
   GemvArgs a = a0;
-  if (a.K % 128 != 0 || a.B > 16) return hipErrorInvalidValue;
+  if (a.K % 128 != 0 || a.B > 64) return hipErrorInvalidValue;
   const size_t lds = (size_t)NW * 256 * 4;
   const int tiles = (a.N + 15) / 16;
   static const int max_blocks = env_int("TW_SK_MAX_BLOCKS", 512);
@@ -926,7 +979,7 @@ static hipError_t skinny_launch_w8(const GemvArgs& a0, hipStream_t st) {
 template <typename T>
 static hipError_t skinny_launch(const GemvArgs& a, hipStream_t st) {
   static const int nw_big = env_int("TW_SK_NW_BIGK", 16);  // wavefronts per tile when K is long (fc2: K = 5120)
-  const bool big = a.K >= 4096 && nw_big == 16 && !a.ln_gw && !a.y_f32 && !a.kcache && !a.gelu;
+  const bool big = a.K >= 4096 && nw_big == 16 && !a.ln_gw && !a.y_f32 && !a.kcache && !a.gelu && a.B <= 16;
   if (a.wscale) {
     if (sizeof(T) != 2) return hipErrorInvalidValue;
     return big ? skinny_launch_w8<16>(a, st) : skinny_launch_w8<8>(a, st);
@@ -936,7 +989,7 @@ static hipError_t skinny_launch(const GemvArgs& a, hipStream_t st) {
 
 template <typename T>
 static hipError_t gemv_b(const GemvArgs& a, hipStream_t st) {
-  if (a.B < 1 || a.B > 16) return hipErrorInvalidValue;
+  if (a.B < 1 || a.B > 64) return hipErrorInvalidValue;
   return skinny_launch<T>(a, st);
 }
 
@@ -973,7 +1026,7 @@ hipError_t launch_dec_cross_attn(int dtype, const void* q, const void* ck, const
 }
 
 hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st) {
-  if (a.B < 1 || a.B > 16 || !a.partials || !a.suppress_bits) return hipErrorInvalidValue;
+  if (a.B < 1 || a.B > 64 || !a.partials || !a.suppress_bits) return hipErrorInvalidValue;
   hipLaunchKernelGGL(sampler_part_kernel, dim3(SAMPLER_NS, a.B), dim3(256), 0, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;

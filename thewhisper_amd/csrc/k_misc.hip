@@ -156,7 +156,7 @@ __global__ void embed_kernel(const int* __restrict__ ids, const DecState* __rest
   const int id = ids[b];
   const int p = stt->pos;
   for (int i = threadIdx.x; i < d; i += blockDim.x)  // decoder activations are fragment-major (tw_common.h: tw_xt_index)
-    x[tw_xt_index<T>(b, i)] = (T)((float)tok[(long long)id * d + i] + (float)pos[(long long)p * d + i]);
+    x[(long long)(b >> 4) * 16 * d + tw_xt_index<T>(b & 15, i)] = (T)((float)tok[(long long)id * d + i] + (float)pos[(long long)p * d + i]);
 }
 
 }  // namespace

@@ -49,8 +49,8 @@ template <> struct ElemTraits<bf16_t> { static constexpr int kPer16B = 8; static
 
 // Fragment-major ("xt") layout of the decoder's per-token activations, a [16 streams][K] block stored as the MFMA B
 // operand of the decode projections reads it: 64-B step s = k / (4E), then lane = ((k / E) & 3) * 16 + stream, then the
-// E elements of that lane's 16-B vector.  One wavefront request for step s is 1 KiB contiguous.  Buffers are always 16
-// streams wide (streams >= B are never written and never read back).
+// E elements of that lane's 16-B vector.  One wavefront request for step s is 1 KiB contiguous.  Buffers hold whole groups
+// of 16 streams (group g of a [.., K] buffer starts at element g*16*K; streams >= B are never written nor read back).
 template <typename T>
 __device__ __forceinline__ long long tw_xt_index(int stream, int k) {
   constexpr int E = ElemTraits<T>::kPer16B;

@@ -16,9 +16,9 @@ ap.add_argument("--dtype", default="bf16")
 args = ap.parse_args()
 dims = dict(bench.DIMS["large-v3"], enc_layers=1, dec_layers=args.layers)
 dev = torch.device("cuda", 0)
-eng = WhisperEngine(dims, args.T, max_batch=16, dtype=args.dtype, alignment_heads=bench.alignment_heads(dims), use_graph=True)
+eng = WhisperEngine(dims, args.T, max_batch=max(int(x) for x in args.batches.split(',')), dtype=args.dtype, alignment_heads=bench.alignment_heads(dims), use_graph=True)
 eng.load_state_dict(bench.random_state_dict(dims, dev, 0))
-pcm = torch.randn((16, args.T * 320), device=dev) * 0.1
+pcm = torch.randn((max(int(x) for x in args.batches.split(',')), args.T * 320), device=dev) * 0.1
 for B in [int(x) for x in args.batches.split(",")]:
     eng.encode(eng.logmel(pcm[:B])); eng.cross_kv(B)
     prompt = np.tile(np.array([[50258, 50259, 50360]], dtype=np.int32), (B, 1))
