@@ -1,0 +1,135 @@
+"""thewhisper_amd/gateway.py on CPU (oracle-backed engine): the reference's remote-backend wire format in, the same words out
+as a direct backend call; concurrent requests share batches; when the reference checkout is present its own
+RemoteAPITimestampsBackend is pointed at the gateway."""
+import io
+import os
+import threading
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import whisper_oracle as wo
+from tests.test_pipeline_glue import build_amd_pipeline, normalise
+
+torch.set_grad_enabled(False)
+fastapi = pytest.importorskip("fastapi")
+from fastapi.testclient import TestClient  # noqa: E402
+
+
+def wav_bytes(audio: np.ndarray, sr: int = 16000) -> bytes:
+    """What the reference client sends (R:thestage_speechkit/streaming/streaming_pipeline.py:93-112): clip, * 32767, int16."""
+    pcm = (np.clip(audio.astype(np.float32), -1.0, 1.0) * 32767.0).astype(np.int16)
+    buf = io.BytesIO()
+    with wave.open(buf, "wb") as wf:
+        wf.setnchannels(1)
+        wf.setsampwidth(2)
+        wf.setframerate(sr)
+        wf.writeframes(pcm.tobytes())
+    return buf.getvalue()
+
+
+@pytest.fixture(scope="module")
+def served():
+    from thewhisper_amd import AMDWhisperBackend
+    from thewhisper_amd.gateway import create_app
+    from thewhisper_amd.serving import BatchingHub
+
+    pipe = build_amd_pipeline("micro", 10, 4)
+    backend = AMDWhisperBackend(None, chunk_length_s=10, asr_pipeline=pipe)
+    hub = BatchingHub(backend, max_batch=4, max_wait_s=0.3)
+    app = create_app(hub, auth_token="s3cret", model_name="micro", lang_id="en")
+    yield backend, hub, TestClient(app)
+    hub.close()
+
+
+def test_wav_roundtrip_and_multipart_parser():
+    from thewhisper_amd.gateway import decode_wav, multipart_file
+
+    a = wo.synth_audio(4000, 1, "speechlike")
+    x, sr = decode_wav(wav_bytes(a))
+    assert sr == 16000 and x.dtype == np.float32 and len(x) == 4000
+    assert np.abs(x - np.clip(a, -1, 1)).max() <= 1.0 / 32767 + 1e-7     # one int16 step
+    body = (b"--XyZ\r\nContent-Disposition: form-data; name=\"other\"\r\n\r\nabc\r\n"
+            b"--XyZ\r\nContent-Disposition: form-data; name=\"file\"; filename=\"chunk.wav\"\r\nContent-Type: audio/wav\r\n\r\n"
+            b"RIFF\r\n--binary\r\n\r\n--XyZ--\r\n")
+    assert multipart_file(body, 'multipart/form-data; boundary="XyZ"') == b"RIFF\r\n--binary\r\n"
+    with pytest.raises(ValueError):
+        multipart_file(body, "application/json")
+    with pytest.raises(ValueError):
+        decode_wav(b"not a wav")
+
+
+def test_gateway_returns_the_backend_words(served):
+    backend, hub, client = served
+    audio = wo.synth_audio(16000 * 7, 5, "speechlike")
+    # the gateway sees the int16-quantised audio, so the direct call gets the same samples
+    from thewhisper_amd.gateway import decode_wav
+
+    q, _ = decode_wav(wav_bytes(audio))
+    want = backend.transcribe(q.copy(), 0.0, 16000)
+    r = client.post("/transcribe", files={"file": ("chunk.wav", wav_bytes(audio), "audio/wav")},
+                    headers={"Authorization": "Bearer s3cret", "X-Lang-Id": "en", "X-Model-Name": "micro"})
+    assert r.status_code == 200, r.text
+    data = r.json()
+    got = [{"text": c["text"], "start": c["timestamp"][0], "end": c["timestamp"][1]} for c in data["metadata"]["chunks"]]
+    assert normalise(got) == normalise(want)
+    assert data["transcription"] == "".join(w["text"] for w in want).strip() == data["text"]
+    # raw audio/wav body is accepted too
+    r2 = client.post("/transcribe", content=wav_bytes(audio), headers={"Authorization": "Bearer s3cret", "Content-Type": "audio/wav"})
+    assert r2.status_code == 200 and r2.json()["metadata"] == data["metadata"]
+
+
+def test_gateway_rejects_bad_requests(served):
+    _, _, client = served
+    audio = wo.synth_audio(16000, 2, "noise")
+    f = {"file": ("chunk.wav", wav_bytes(audio), "audio/wav")}
+    assert client.post("/transcribe", files=f).status_code == 401
+    assert client.post("/transcribe", files=f, headers={"Authorization": "Bearer nope"}).status_code == 401
+    ok = {"Authorization": "Bearer s3cret"}
+    assert client.post("/transcribe", files=f, headers={**ok, "X-Lang-Id": "de"}).status_code == 400
+    assert client.post("/transcribe", files=f, headers={**ok, "X-Model-Name": "other"}).status_code == 404
+    assert client.post("/transcribe", files={"file": ("chunk.wav", wav_bytes(audio, 8000), "audio/wav")}, headers=ok).status_code == 400
+    assert client.post("/transcribe", files={"file": ("chunk.wav", b"junk", "audio/wav")}, headers=ok).status_code == 400
+    assert client.post("/transcribe", files={"nofile": ("x", b"y", "text/plain")}, headers=ok).status_code == 400
+    assert client.get("/health").json()["status"] == "ready"
+
+
+def test_concurrent_requests_share_batches(served):
+    backend, hub, client = served
+    clips = [wo.synth_audio(16000 * s, 10 + s, "speechlike") for s in (3, 5, 4, 6)]
+    before = len(hub.batches)
+    out = [None] * 4
+
+    def go(i):
+        out[i] = client.post("/transcribe", files={"file": ("chunk.wav", wav_bytes(clips[i]), "audio/wav")},
+                             headers={"Authorization": "Bearer s3cret"}).json()
+
+    th = [threading.Thread(target=go, args=(i,)) for i in range(4)]
+    [t.start() for t in th]
+    [t.join(300) for t in th]
+    assert all(o is not None and "metadata" in o for o in out)
+    assert max(hub.batches[before:]) > 1            # different HTTP requests were decoded in one batched pass
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference checkout not present")
+def test_reference_remote_backend_against_the_gateway(served, monkeypatch):
+    """The reference's own client class, unmodified, talking to the gateway (httpx.post routed to the test client)."""
+    from oracle.make_golden import _import_reference
+
+    backend, hub, client = served
+    _, sp = _import_reference()
+
+    def fake_post(url, headers=None, files=None, timeout=None):
+        return client.post("/transcribe", headers=headers, files=files)
+
+    monkeypatch.setattr(sp.httpx, "post", fake_post)
+    remote = sp.RemoteAPITimestampsBackend(api_url="http://gateway/transcribe", auth_token="s3cret", model_name="micro", lang_id="en")
+    audio = wo.synth_audio(16000 * 8, 21, "speechlike")
+    from thewhisper_amd.gateway import decode_wav
+
+    q, _ = decode_wav(wav_bytes(audio))
+    want = backend.transcribe(q.copy(), 12.5, 16000)          # what LocalWhisperBackend-equivalent code returns for this buffer
+    got = remote.transcribe(audio, 12.5, 16000)
+    assert normalise(got) == normalise(want)
