@@ -11,7 +11,8 @@ from __future__ import annotations
 
 __version__ = "0.1.0"
 
-__all__ = ["ASRPipeline", "AMDWhisperBackend", "WhisperEngine", "AMDWhisperForConditionalGeneration"]
+__all__ = ["ASRPipeline", "AMDWhisperBackend", "WhisperEngine", "AMDWhisperForConditionalGeneration", "BatchingHub",
+           "EncoderOverlap", "create_gateway_app"]
 
 
 def __getattr__(name):  # lazy: importing the package must not pull torch/transformers
@@ -31,4 +32,16 @@ def __getattr__(name):  # lazy: importing the package must not pull torch/transf
         from .streaming import AMDWhisperBackend
 
         return AMDWhisperBackend
+    if name == "BatchingHub":
+        from .serving import BatchingHub
+
+        return BatchingHub
+    if name == "EncoderOverlap":
+        from .overlap import EncoderOverlap
+
+        return EncoderOverlap
+    if name == "create_gateway_app":
+        from .gateway import create_app
+
+        return create_app
     raise AttributeError(name)
