@@ -282,16 +282,25 @@ void skinny_mfma_kernel(GemvArgs a) {
       for (int i = 0; i < SK_MAXS; ++i) wq[i] = sk_load_w<T>(wt + (long long)min(s0 + i, S - 1) * (64 * E));
     }
   };
-  auto load_x = [&](int s0) {            // fragment-major activations: lane (stream fr, k-group kq) of each 32-k step
-    const T* xt = x + (long long)lane * E;
+  // fragment-major activations: lane (stream fr, k-group kq) of each 32-k step.  Requested through a buffer descriptor so
+  // that the lanes of streams >= B are out of range: they return zeros WITHOUT a memory request, i.e. a launch for one
+  // stream moves 1/16 of the activation bytes of a launch for 16 (the block is re-read by every workgroup: at B = 1 that
+  // is the difference between 160 KB and 10 KB per workgroup for fc2).
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, CG * 16 * K * (int)sizeof(T), 0x00020000);
+  unsigned xoff[CG];
+#pragma unroll
+  for (int g = 0; g < CG; ++g)
+    xoff[g] = (g * 16 + fr < B) ? (unsigned)((g * 16 * K + lane * E) * (int)sizeof(T)) : 0x80000000u;
+  auto load_x = [&](int s0) {
 #pragma unroll
     for (int g = 0; g < CG; ++g)
 #pragma unroll
       for (int i = 0; i < SK_MAXS; ++i)
 #pragma unroll
-        for (int m = 0; m < XPS; ++m)
-          xq[g][i * XPS + m] = *reinterpret_cast<const u32x4_t*>(xt + (long long)g * 16 * K +
-                                                                   ((long long)min(s0 + i, S - 1) * XPS + m) * (64 * E));
+        for (int m = 0; m < XPS; ++m) {
+          const unsigned step_bytes = (unsigned)((min(s0 + i, S - 1) * XPS + m) * (64 * E) * (int)sizeof(T));
+          xq[g][i * XPS + m] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(xr, xoff[g] + step_bytes, 0, 0));
+        }
   };
 
   load_x(s_lo);
