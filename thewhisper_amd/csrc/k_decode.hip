@@ -194,10 +194,11 @@ template <> __device__ __forceinline__ void sk_stats<float>(const u32x4_t& v, fl
 //    runtime-uniform branch around a load hipcc waits for EVERY outstanding load.
 //
 // W8 = MXFP8 weights (TW_BF16_MXFP8 contexts): the weight operand is OCP e4m3 with one power-of-two scale per 32 values
-// (quant_mx8_kernel below), the bf16 activation fragments are quantised the same way in registers (a lane's 32 values of
-// one 128-wide k step are exactly one scale block, so no cross-lane reduction is needed), and the product runs on
-// v_mfma_scale_f32_16x16x128_f8f6f4, which applies both block scales in hardware.  One step is then 128 k: 2 KiB of
-// weights + 64 scale bytes per tile, half the bytes of the bf16 kernel.
+// (quant_mx8_kernel below), the bf16 activation fragments are quantised the same way in registers (sk_quant_mx8: a scale
+// block is the same 16-byte half of two neighbouring lane groups, so one lane exchange finds its maximum and a second one
+// puts the scale byte where the instruction reads it), and the product runs on v_mfma_scale_f32_16x16x128_f8f6f4, which
+// applies both block scales in hardware.  One step is then 128 k: 2 KiB of weights + 64 scale bytes per tile, half the
+// bytes of the bf16 kernel.
 // CG = groups of 16 streams (1, 2 or 4: up to 64 streams per launch).  Every weight fragment is used for all groups, so the
 // weight stream - the dominant cost - is paid once per launch whatever the number of streams; activations, accumulators
 // and the epilogue are per group (group g of a fragment-major activation buffer starts at element g*16*K).
