@@ -208,9 +208,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     from thewhisper_amd.dist import Replicas
 
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("TW_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))  # TW_BENCH_DEVICE: plumbing tests only
     torch.cuda.set_device(local)
-    rep = Replicas()                       # nccl (= RCCL) when WORLD_SIZE > 1; barrier / max / sum only
+    rep = Replicas(device=torch.device("cuda", local))  # nccl (= RCCL) when WORLD_SIZE > 1; barrier / max / sum only
     rank, world = rep.rank, rep.world
 
     from thewhisper_amd.engine import WhisperEngine

@@ -30,16 +30,20 @@ class Replicas:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.device = device or (torch.device("cuda", self.local_rank) if torch.cuda.is_available() else torch.device("cpu"))
         self.dist = None
+        self._coll_device = self.device
         if self.world > 1:
             import torch.distributed as dist
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29531")
-            backend = backend or ("nccl" if self.device.type == "cuda" else "gloo")
+            # TW_DIST_BACKEND=gloo: plumbing tests of the N > 1 path on a box with fewer GPUs than ranks (RCCL refuses two
+            # ranks on one device); the collectives here are three scalars, so the backend does not matter for the numbers
+            backend = backend or os.environ.get("TW_DIST_BACKEND") or ("nccl" if self.device.type == "cuda" else "gloo")
             if not dist.is_initialized():
                 kw = {"device_id": self.device} if backend == "nccl" else {}
                 dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
             self.dist = dist
+            self._coll_device = self.device if backend == "nccl" else torch.device("cpu")
 
     def barrier(self):
         if self.dist is not None:
@@ -50,14 +54,14 @@ class Replicas:
     def max_float(self, x: float) -> float:
         if self.dist is None:
             return float(x)
-        t = torch.tensor([x], dtype=torch.float64, device=self.device)
+        t = torch.tensor([x], dtype=torch.float64, device=self._coll_device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
     def sum_int(self, x: int) -> int:
         if self.dist is None:
             return int(x)
-        t = torch.tensor([x], dtype=torch.int64, device=self.device)
+        t = torch.tensor([x], dtype=torch.int64, device=self._coll_device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return int(t.item())
 
@@ -73,7 +77,7 @@ class Replicas:
         for i, s in enumerate(stream_ids):
             buf[i, 0] = int(s)
             buf[i, 1:] = torch.from_numpy(tokens[i])
-        buf = buf.to(self.device)
+        buf = buf.to(self._coll_device)
         out = [torch.empty_like(buf) for _ in range(self.world)]
         self.dist.all_gather(out, buf)
         if self.rank != 0:
