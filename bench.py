@@ -266,9 +266,10 @@ def main():
     new_tok = 0
 
     def encode_stage(e, pc):      # log-mel + encoder + cross-K/V: asynchronous launches
-        e.encode(e.logmel(pc))
+        mel = e.logmel(pc)
+        e.encode(mel)
         e.cross_kv(pc.shape[0])
-        return None
+        return mel                # kept alive until the batch is decoded: the launches above are still reading it
 
     def decode_stage(e, pc, _enc):
         nb = pc.shape[0]

@@ -425,8 +425,10 @@ def test_encoder_overlap_gives_the_sequential_results():
     prompt = np.tile(np.array(PROMPT, dtype=np.int32), (3, 1))
 
     def enc(e, pc):
-        e.encode(e.logmel(pc, out_dtype=torch.float32))
+        mel = e.logmel(pc, out_dtype=torch.float32)
+        e.encode(mel)
         e.cross_kv(pc.shape[0])
+        return mel  # must outlive the asynchronous launches (EncoderOverlap.run keeps it until the batch is decoded)
 
     def dec(e, pc, _):
         out = e.generate_greedy(prompt, max_new_tokens=16, timestamps=True, want_alignment=True)

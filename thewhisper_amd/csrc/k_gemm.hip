@@ -27,7 +27,22 @@ __device__ __forceinline__ long long rowmap(const RowMap& r, int m) {
   return (long long)(m / r.rpb) * r.bstride + (long long)(m % r.rpb) * r.rstride;
 }
 
-__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf-GELU (activation_function = "gelu").  Strict-f32 contexts use the library erff; bf16 contexts, whose outputs are
+// rounded to 8 mantissa bits anyway, use the Abramowitz-Stegun 7.1.26 rational form (|error| < 2e-7 on erf + one fast
+// exp: ~12 instead of ~45 VALU instructions per element, which is a third of the fc1 GEMM's epilogue-bound run time).
+template <typename T>
+__device__ __forceinline__ float gelu_exact(float x) {
+  const float z = x * 0.70710678118654752440f;
+  if (sizeof(T) == 4) return 0.5f * x * (1.0f + erff(z));
+  const float az = fabsf(z);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(t, p, 1.421413741f);
+  p = fmaf(t, p, -0.284496736f);
+  p = fmaf(t, p, 0.254829592f);
+  const float e = 1.0f - p * t * __expf(-az * az);
+  return 0.5f * x * (1.0f + copysignf(e, z));
+}
 
 template <typename T> struct Vec4;  // 4 consecutive elements
 template <> struct Vec4<float> {
@@ -187,7 +202,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A, RowM
       }
       if (ep.gelu) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_exact(v[r]);
+        for (int r = 0; r < 4; ++r) v[r] = gelu_exact<T>(v[r]);
       }
       if (res) {
         Vec4<T> rv;

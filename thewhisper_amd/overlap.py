@@ -102,7 +102,12 @@ class EncoderOverlap:
 
     def run(self, batches: Iterable[Any], encode_fn: Callable[[WhisperEngine, Any], Any],
             decode_fn: Callable[[WhisperEngine, Any, Any], Any]) -> List[Any]:
-        """Processes the batches in order and returns ``decode_fn``'s results in order."""
+        """Processes the batches in order and returns ``decode_fn``'s results in order.
+
+        ``encode_fn`` only enqueues work; it must RETURN every torch tensor it handed to the engine (e.g. the log-mel tensor):
+        the pipeline keeps the returned object alive until the batch has been decoded.  Dropping such a tensor earlier hands
+        its memory back to torch's caching allocator while the CU-masked stream - which the allocator knows nothing about -
+        is still reading it, and the next batch's tensor lands on top of it."""
         hip = _hiplib()
         batches = list(batches)
         free = [threading.Semaphore(1), threading.Semaphore(1)]  # context i may be (re)used by the encode stage

@@ -17,7 +17,9 @@ for l in range(L):
     lanes.append(EncoderOverlap(engs, encoder_cus=ENC, cu_range=(l * 256 // L, (l + 1) * 256 // L)))
 pcm = torch.randn((Bs, 160000), device=dev) * 0.1
 prompt = np.tile(np.array([[50258, 50259, 50360]], dtype=np.int32), (Bs, 1))
-def enc(e, pc): e.encode(e.logmel(pc)); e.cross_kv(Bs)
+def enc(e, pc):
+    mel = e.logmel(pc); e.encode(mel); e.cross_kv(Bs)
+    return mel
 def dec(e, pc, _):
     out = e.generate_greedy(prompt, max_new_tokens=128, min_new_tokens=128, timestamps=True, want_alignment=True)
     e.token_timestamps(Bs, 3, out["length"], [1000] * Bs)

@@ -14,8 +14,9 @@ prompt = np.tile(np.array([[50258, 50259, 50360]], dtype=np.int32), (16, 1))
 T0 = time.perf_counter(); log = []
 def enc(e, pc):
     a = time.perf_counter() - T0
-    e.encode(e.logmel(pc)); e.cross_kv(16)
+    mel = e.logmel(pc); e.encode(mel); e.cross_kv(16)
     log.append(("enc-submit", engs.index(e), round(a * 1e3, 1), round((time.perf_counter() - T0) * 1e3, 1)))
+    return mel
 def dec(e, pc, _):
     a = time.perf_counter() - T0
     out = e.generate_greedy(prompt, max_new_tokens=128, min_new_tokens=128, timestamps=True, want_alignment=True)
