@@ -1,0 +1,149 @@
+"""Full-depth golden vectors at BASELINE.json's real configurations.
+
+    python -m oracle.make_golden_full [case ...]        (CPU, this container; minutes per case; never on the GPU box)
+
+The arithmetic behind the reference's NVIDIA HF branch (R:thestage_speechkit/nvidia/asr_pipeline.py:57-60) is
+``transformers.WhisperForConditionalGeneration`` - run here in float32 on CPU at the TRUE model sizes with the
+oracle's seeded weights (``oracle.whisper_oracle.make_weights``: regenerated from the seed wherever the fixtures
+are consumed, so only small outputs are stored under tests/golden/full_*.npz):
+
+  full_large-v3_c10    whisper-large-v3   32+32 layers, 10 s chunks (T = 500), 2 clips     (BASELINE configs 3/4)
+  full_turbo_c30       large-v3-turbo     32+4  layers, 30 s chunk  (T = 1500), 1 clip     (BASELINE config 2)
+  full_large-v3_c15    whisper-large-v3   32+32 layers, 15 s chunks (T = 750), 1 clip      (BASELINE config 5)
+
+Per case: log-mel rows (HF feature extractor), encoder-state samples, HF ``generate`` greedy ids with the timestamp
+grammar on (``max_new_tokens`` 32) + token timestamps (DTW), and - teacher-forced along that greedy path - per step the
+top-8 raw logits, a strided sample of the logits row, its norm, and the top1-top2 margin of the PROCESSED scores
+(the quantity the greedy decision is made on); the same logits summary for a teacher-forced pass over random tokens.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from . import hf_reference as hr  # noqa: E402
+from . import whisper_oracle as wo  # noqa: E402
+
+#          name                 preset            chunk_s  clips (kind, seed)                    weight seed  max_new
+CASES = {
+    "full_large-v3_c10": ("large-v3", 10, [("speechlike", 21), ("noise", 22)], 0, 32),
+    "full_turbo_c30": ("large-v3-turbo", 30, [("speechlike", 23)], 0, 32),
+    "full_large-v3_c15": ("large-v3", 15, [("speechlike", 24)], 0, 32),
+}
+WSCALE, QGAIN = 0.5, 8.0   # make_weights(scale, q_gain): see its docstring (unit-gain random models degenerate at 32 layers)
+LOGIT_STRIDE = 29   # strided sample of every logits row kept for the relative-L2 estimate
+ENC_TSTRIDE, ENC_DSTRIDE = 25, 16
+PROMPT = [50258, 50259, 50360]
+
+
+def run_case(name: str):
+    from transformers.generation.utils import GenerationMixin
+
+    preset, chunk_s, clip_spec, wseed, max_new = CASES[name]
+    dims = wo.PRESETS[preset]
+    T = 50 * chunk_s
+    t0 = time.time()
+    w = wo.make_weights(dims, wseed, scale=WSCALE, q_gain=QGAIN)
+    model = hr.build_hf_model(dims, w)
+    del w
+    hr.patch_chunk_length(model, chunk_s)
+    fe = hr.build_feature_extractor(dims, chunk_s)
+    print(f"[{name}] model ready in {time.time() - t0:.0f} s", flush=True)
+    pcm = np.stack([wo.synth_audio(16000 * chunk_s, seed, kind) for kind, seed in clip_spec])
+    B = pcm.shape[0]
+    feats = fe([p for p in pcm], sampling_rate=16000, return_tensors="pt", return_attention_mask=True)
+    mel = feats.input_features
+    assert tuple(mel.shape) == (B, dims.n_mels, 2 * T)
+    t0 = time.time()
+    enc = model.model.encoder(mel).last_hidden_state
+    print(f"[{name}] encoder {time.time() - t0:.1f} s", flush=True)
+
+    calls = []
+    orig = GenerationMixin.generate
+
+    def spy(self, *a, **k):
+        out = orig(self, *a, **k)
+        calls.append(out)
+        return out
+
+    GenerationMixin.generate = spy
+    t0 = time.time()
+    try:
+        model.generate(input_features=mel, attention_mask=feats.attention_mask, return_timestamps=True,
+                       return_token_timestamps=True, language="en", max_new_tokens=max_new, num_beams=1,
+                       do_sample=False, use_cache=True)
+    finally:
+        GenerationMixin.generate = orig
+    print(f"[{name}] generate {time.time() - t0:.1f} s", flush=True)
+    first = calls[0]   # the inner greedy call of the first seek iteration: prompt + new tokens, eos-padded
+    seq = first["sequences"].numpy().astype(np.int64)
+    tok_ts = first["token_timestamps"].numpy().astype(np.float32)
+    assert (seq[:, :3] == np.array(PROMPT)).all()
+
+    # teacher-forced along the greedy path (no cache: one pass)
+    t0 = time.time()
+    logits = model(input_features=mel, decoder_input_ids=torch.from_numpy(seq)).logits.numpy()   # [B, L, V]
+    print(f"[{name}] teacher-forced pass {time.time() - t0:.1f} s", flush=True)
+    L = seq.shape[1]
+    top = torch.topk(torch.from_numpy(logits), 8, dim=-1)
+    opt = wo.GreedyOptions(max_new_tokens=max_new, timestamps=True)
+    margins = np.full((B, L), np.inf, dtype=np.float32)   # margin of the decision that produced seq[:, s + 1]
+    choice_ok = np.ones((B, L), dtype=bool)
+    for b in range(B):
+        for s in range(2, L - 1):
+            sc = wo.apply_logits_processors(logits[b, s].astype(np.float32), seq[b, : s + 1].tolist(), 3, opt)
+            order = np.argsort(-sc)[:2]
+            margins[b, s] = sc[order[0]] - sc[order[1]]
+            nxt = seq[b, s + 1]
+            choice_ok[b, s] = (order[0] == nxt) or nxt == opt.eos   # after eos HF pads with eos
+    assert choice_ok.all(), "teacher-forced argmax along the greedy path disagrees with generate()"
+
+    # a second teacher-forced pass over RANDOM text tokens (the greedy path of a random-weight model turns repetitive
+    # after a dozen steps; random tokens keep every step informative)
+    rnd = np.random.default_rng(1234).integers(0, 50000, size=(B, 13))
+    ids2 = np.concatenate([np.tile(np.array(PROMPT + [50364]), (B, 1)), rnd], axis=1).astype(np.int64)
+    logits2 = model(input_features=mel, decoder_input_ids=torch.from_numpy(ids2)).logits.numpy()
+    top2 = torch.topk(torch.from_numpy(logits2), 8, dim=-1)
+
+    np.savez_compressed(
+        os.path.join(OUT, f"{name}.npz"),
+        rand_ids=ids2.astype(np.int32),
+        rand_logits_top=top2.values.numpy().astype(np.float32), rand_logits_top_idx=top2.indices.numpy().astype(np.int32),
+        rand_logits_sample=logits2[:, :, ::LOGIT_STRIDE].astype(np.float32),
+        rand_logits_norm=np.linalg.norm(logits2, axis=-1).astype(np.float32),
+        preset=preset, chunk_s=chunk_s, weight_seed=wseed, weight_scale=WSCALE, q_gain=QGAIN, max_new=max_new,
+        clip_kinds=np.array([k for k, _ in clip_spec]), clip_seeds=np.array([s for _, s in clip_spec]),
+        mel_rows=mel[:, ::16, ::25].numpy().astype(np.float32),
+        enc_rows=enc[:, ::ENC_TSTRIDE, ::ENC_DSTRIDE].numpy().astype(np.float32),
+        enc_norm=np.linalg.norm(enc.numpy().reshape(B, -1), axis=1).astype(np.float32),
+        sequences=seq.astype(np.int32),
+        token_timestamps=tok_ts,
+        logits_top=top.values.numpy().astype(np.float32), logits_top_idx=top.indices.numpy().astype(np.int32),
+        logits_sample=logits[:, :, ::LOGIT_STRIDE].astype(np.float32),
+        logits_norm=np.linalg.norm(logits, axis=-1).astype(np.float32),
+        margins=margins,
+        alignment_heads=np.array(model.generation_config.alignment_heads, dtype=np.int32),
+        versions=np.array([f"transformers {__import__('transformers').__version__}", f"torch {torch.__version__}"]),
+    )
+    print(f"[{name}] seq[0] = {seq[0].tolist()}")
+    print(f"[{name}] min margin per clip = {margins[:, 2:L - 1].min(axis=1)}, raw top1-top2 min = "
+          f"{(top.values[..., 0] - top.values[..., 1]).min().item():.4f}", flush=True)
+
+
+def main():
+    torch.set_grad_enabled(False)
+    torch.set_num_threads(os.cpu_count() or 1)
+    os.makedirs(OUT, exist_ok=True)
+    for name in (sys.argv[1:] or list(CASES)):
+        run_case(name)
+
+
+if __name__ == "__main__":
+    main()

@@ -84,13 +84,19 @@ class SpecialTokens:
 # --------------------------------------------------------------------------------------
 
 
-def make_weights(dims: WhisperDims, seed: int = 0, scale: float = 1.0) -> Dict[str, np.ndarray]:
+def make_weights(dims: WhisperDims, seed: int = 0, scale: float = 1.0, q_gain: float = 1.0) -> Dict[str, np.ndarray]:
     """Deterministic float32 weights keyed by HF parameter names.
 
     Independent of torch/transformers RNG so that the oracle, the HF harness and the HIP engine
     can all be fed the *same* tensors on any machine.  Linear/conv/embedding weights are uniform
     with std ~ 0.05*scale (large enough that attention is not uniform and argmax margins are
     not vanishing); LayerNorm gains are 1 +- 0.1, biases +-0.05.
+
+    ``q_gain`` multiplies every attention query projection (weight and bias) after generation (the random
+    stream is unchanged).  With unit gain a 32-layer random model attends almost uniformly, its output barely
+    depends on the audio and greedy decoding collapses onto one token; ``scale=0.5, q_gain=8`` (the full-depth
+    goldens, oracle/make_golden_full.py) gives peaked attention, audio-dependent token paths and an active
+    timestamp grammar - a harder parity target.
     """
     rng = np.random.default_rng(seed)
     d, f, v = dims.d_model, dims.ffn, dims.vocab
@@ -143,6 +149,10 @@ def make_weights(dims: WhisperDims, seed: int = 0, scale: float = 1.0) -> Dict[s
         lin(p + ".fc2", d, f)
         ln(p + ".final_layer_norm")
     ln(dd + ".layer_norm")
+    if q_gain != 1.0:
+        for k in w:
+            if ".q_proj." in k:
+                w[k] = (w[k] * np.float32(q_gain)).astype(np.float32)
     return w
 
 
