@@ -8,17 +8,29 @@ reference's streaming backend always runs it, R:thestage_speechkit/streaming/str
 chunks = configs[3]'s per-GPU share (128 streams / 8 GPUs); N GPUs run N independent replicas on
 disjoint streams (weak scaling, no data-path collective - SURVEY.md section 8e).
 
-Launch: `python bench.py` (1 GPU) or
-`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`
-Rank 0 prints ONE JSON line.
+Launch: `python bench.py [--gpus N]` - with N > 1 and no WORLD_SIZE in the environment the script re-executes itself as
+N ranks (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`, one rank per GPU,
+RCCL for the barrier / max / sum); launched by the driver through torch.distributed.run it reads RANK / LOCAL_RANK /
+WORLD_SIZE from the environment.  Rank 0 prints ONE JSON line.
+
+Besides the engine-level headline the line carries (rank 0, N = 1 only):
+  * `pipeline`: the same workload THROUGH the drop-in API - tokens/s of 16 session threads behind the BatchingHub
+    (thewhisper_amd/serving.py) and the p50 wall time of `AMDWhisperBackend.transcribe` on a 10 s host buffer
+    (the metric as SURVEY.md section 8d defines it, R:thestage_speechkit/streaming/streaming_pipeline.py:388-435);
+  * `cpu_baseline`: the reference's PyTorch-CPU path on this box's host cores (bounded sample);
+  * `roofline`: decode step, algorithmic bytes (W = 2*(Ld*14*d^2 + V*d)) over HIP-event time.
 """
 from __future__ import annotations
 
 import argparse
-import dataclasses
+import glob
+import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -28,81 +40,26 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-DIMS = {
-    "large-v3": dict(d_model=1280, enc_layers=32, dec_layers=32, heads=20, ffn=5120, vocab=51866, n_mels=128,
-                     max_source_positions=1500, max_target_positions=448),
-    "large-v3-turbo": dict(d_model=1280, enc_layers=32, dec_layers=4, heads=20, ffn=5120, vocab=51866, n_mels=128,
-                           max_source_positions=1500, max_target_positions=448),
-    "tiny.en": dict(d_model=384, enc_layers=4, dec_layers=4, heads=6, ffn=1536, vocab=51864, n_mels=80,
-                    max_source_positions=1500, max_target_positions=448),
-}
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+from thewhisper_amd import synthetic  # noqa: E402
 
-
-def random_state_dict(dims, device, seed=0):
-    """Random-init weights of the named architecture, generated on the GPU in the HF state_dict layout."""
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    d, f, v = dims["d_model"], dims["ffn"], dims["vocab"]
-
-    def uni(shape, amp):
-        return (torch.rand(shape, device=device, generator=g, dtype=torch.float32) - 0.5) * (2 * amp)
-
-    sd = {}
-
-    def lin(name, o, i, bias=True):
-        sd[name + ".weight"] = uni((o, i), 1.7 / i ** 0.5)
-        if bias:
-            sd[name + ".bias"] = uni((o,), 0.05)
-
-    def ln(name):
-        sd[name + ".weight"] = 1.0 + uni((d,), 0.1)
-        sd[name + ".bias"] = uni((d,), 0.05)
-
-    def attn(p):
-        lin(p + ".k_proj", d, d, False)
-        lin(p + ".v_proj", d, d)
-        lin(p + ".q_proj", d, d)
-        lin(p + ".out_proj", d, d)
-
-    e = "model.encoder"
-    sd[e + ".conv1.weight"] = uni((d, dims["n_mels"], 3), 1.7 / (3 * dims["n_mels"]) ** 0.5)
-    sd[e + ".conv1.bias"] = uni((d,), 0.05)
-    sd[e + ".conv2.weight"] = uni((d, d, 3), 1.7 / (3 * d) ** 0.5)
-    sd[e + ".conv2.bias"] = uni((d,), 0.05)
-    sd[e + ".embed_positions.weight"] = uni((dims["max_source_positions"], d), 0.5)
-    for i in range(dims["enc_layers"]):
-        p = f"{e}.layers.{i}"
-        attn(p + ".self_attn"); ln(p + ".self_attn_layer_norm"); lin(p + ".fc1", f, d); lin(p + ".fc2", d, f); ln(p + ".final_layer_norm")
-    ln(e + ".layer_norm")
-    dd = "model.decoder"
-    sd[dd + ".embed_tokens.weight"] = uni((v, d), 0.12)
-    sd[dd + ".embed_positions.weight"] = uni((dims["max_target_positions"], d), 0.12)
-    for i in range(dims["dec_layers"]):
-        p = f"{dd}.layers.{i}"
-        attn(p + ".self_attn"); ln(p + ".self_attn_layer_norm"); attn(p + ".encoder_attn"); ln(p + ".encoder_attn_layer_norm")
-        lin(p + ".fc1", f, d); lin(p + ".fc2", d, f); ln(p + ".final_layer_norm")
-    ln(dd + ".layer_norm")
-    return sd
+DIMS = synthetic.DIMS
+random_state_dict = synthetic.random_state_dict
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_CEILING_GBS = 6290.0  # ... 6.29 TB/s measured float4 copy
 
 
 def alignment_heads(dims):
-    n = min(10, max(2, dims["dec_layers"] * 2))
-    out = []
-    for j in range(n):
-        layer = dims["dec_layers"] - 1 - (j % max(1, dims["dec_layers"] // 2))
-        head = (3 * j + 1) % dims["heads"]
-        if (layer, head) not in out:
-            out.append((layer, head))
-    return out
+    return [tuple(h) for h in synthetic.default_alignment_heads(dims["dec_layers"], dims["heads"])]
 
 
 def algorithmic_decode_bytes(dims, B, T, n_prompt, steps, esz=2, wsz=None):
-    """bytes/step = W + B*163840*(T + t) (large-v3 numbers generalised):
-    W = esz*(Ld*14*d^2 + V*d); per stream and step the cross K/V (2*Ld*T*d*esz) and the self K/V read so far."""
+    """bytes/step = W + B*163840*(T + t) (large-v3 numbers generalised).
+    W = esz*(Ld*14*d^2 + V*d) for ffn = 4d: per decoder layer the self q/k/v/out (4 d^2), the cross q/out (2 d^2 - the
+    cross K/V projection weights are NOT read during decode) and fc1 + fc2 (2*d*ffn); plus the tied logits matrix.
+    Per stream and step the cross K/V (2*Ld*T*d*esz) and the self K/V read so far."""
     d, Ld, V = dims["d_model"], dims["dec_layers"], dims["vocab"]
     wsz = esz if wsz is None else wsz  # bytes per projection weight (MXFP8: 1 + 1/32 for the block scales)
-    W = wsz * (Ld * (4 * d * d + 4 * d * d + 2 * d * dims["ffn"]) + V * d)
+    W = wsz * (Ld * (6 * d * d + 2 * d * dims["ffn"]) + V * d)
     total = 0
     for s in range(steps):
         t = s + 1
@@ -123,8 +80,15 @@ def _host_cores() -> int:
     return max(1, min(n, 64))
 
 
-def _cpu_baseline_worker(model_name, chunk_s, new_tokens):
-    """Child process: the reference's PyTorch-CPU arithmetic (HF transformers generate, fp32, all host cores)."""
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline (reported, not the target): the reference's own pipeline class on the host cores, bounded sample
+# ------------------------------------------------------------------------------------------------------------------
+def _cpu_baseline_worker(model_name, chunk_s, new_tokens, calls):
+    """Child process.  BASELINE.md section 3: `thestage_speechkit.nvidia.ASRPipeline` (HF branch, model_size=None,
+    R:thestage_speechkit/nvidia/asr_pipeline.py:57-60) with device="cpu", fp32, greedy, word timestamps on as the reference's
+    streaming backend runs it (R:thestage_speechkit/streaming/streaming_pipeline.py:395-410), `calls` calls x `new_tokens`
+    forced tokens.  Where /root/reference is absent (the GPU box) the class it subclasses without changing any arithmetic -
+    transformers' AutomaticSpeechRecognitionPipeline - is called the same way; the JSON says which one ran."""
     from oracle import hf_reference as hr
     from oracle import whisper_oracle as wo
     from transformers import WhisperForConditionalGeneration
@@ -137,40 +101,58 @@ def _cpu_baseline_worker(model_name, chunk_s, new_tokens):
     t0 = time.time()
     with no_init_weights():
         model = WhisperForConditionalGeneration(hr.build_hf_config(dims))
-    for name, p in model.named_parameters():   # timing does not depend on the values: cheap deterministic fill
+    g = torch.Generator().manual_seed(0)
+    for name, p in model.named_parameters():   # timing does not depend on the values; random so that decoding is not degenerate
         if p.dim() >= 2:
-            p.fill_(0.5 / p.shape[-1])
+            p.uniform_(-1.7 / p.shape[-1] ** 0.5, 1.7 / p.shape[-1] ** 0.5, generator=g)
         elif "layer_norm" in name and name.endswith("weight"):
             p.fill_(1.0)
         else:
             p.zero_()
     model.eval()
     hr.fill_generation_config(model.generation_config, dims)
-    hr.patch_chunk_length(model, chunk_s)
-    fe = hr.build_feature_extractor(dims, chunk_s)
+    fe, tok = hr.build_feature_extractor(dims, chunk_s), hr.build_tokenizer(dims)
+    ref = os.environ.get("TW_REFERENCE_DIR", "/root/reference")
+    if os.path.isdir(os.path.join(ref, "thestage_speechkit")):
+        sys.path.insert(0, ref)
+        from thestage_speechkit.nvidia import ASRPipeline  # the reference's own class (also installs its LCS patch)
+
+        pipe = ASRPipeline(model, feature_extractor=fe, tokenizer=tok, chunk_length_s=chunk_s, device="cpu",
+                           torch_dtype=torch.float32, batch_size=1)
+        enc = model.model.encoder   # version-drift fix D1: 5.x looks positions up through num_embeddings
+        enc.embed_positions.num_embeddings = enc.embed_positions.weight.shape[0]
+        which = "thestage_speechkit.nvidia.ASRPipeline (the reference's class, HF branch)"
+    else:
+        from transformers import AutomaticSpeechRecognitionPipeline
+
+        from thewhisper_amd import lcs_patch  # noqa: F401  the reference's chunk-merge fix, as importing thestage_speechkit installs it
+
+        hr.patch_chunk_length(model, chunk_s)
+        pipe = AutomaticSpeechRecognitionPipeline(model, feature_extractor=fe, tokenizer=tok, device="cpu", chunk_length_s=chunk_s,
+                                                  torch_dtype=torch.float32, batch_size=1)
+        which = ("transformers AutomaticSpeechRecognitionPipeline + patch_hf_model arithmetic (what thestage_speechkit.nvidia."
+                 "ASRPipeline is a constructor around; /root/reference is absent on this box)")
     t_init = time.time() - t0
-    pcm = wo.synth_audio(chunk_s * 16000, 0, "noise")
-    fe(pcm[:16000], sampling_rate=16000, return_tensors="pt")   # untimed: first-call cost of torch.stft
-    t0 = time.time()
-    feats = fe(pcm, sampling_rate=16000, return_tensors="pt", return_attention_mask=True)
-    model.generate(input_features=feats.input_features, attention_mask=feats.attention_mask, language="en",
-                   return_timestamps=True, num_beams=1, do_sample=False, use_cache=True,
-                   max_new_tokens=new_tokens, min_new_tokens=new_tokens, force_unique_generate_call=True)
-    dt = time.time() - t0
-    print("CPU_BASELINE " + json.dumps({"tok": new_tokens, "dt": dt, "init": t_init, "cores": cores}), flush=True)
+    gk = {"use_cache": True, "num_beams": 1, "do_sample": False, "language": "en", "max_new_tokens": new_tokens,
+          "min_new_tokens": new_tokens}
+    fe(wo.synth_audio(16000, 0, "noise"), sampling_rate=16000, return_tensors="pt")   # untimed: first-call cost of torch.stft
+    dts = []
+    for i in range(calls):
+        pcm = wo.synth_audio(chunk_s * 16000, i, "noise")
+        t0 = time.time()
+        pipe(pcm, return_timestamps="word", generate_kwargs=dict(gk), chunk_length_s=chunk_s)
+        dts.append(time.time() - t0)
+    print("CPU_BASELINE " + json.dumps({"tok": new_tokens * calls, "dt": sum(dts), "calls": dts, "init": t_init, "cores": cores,
+                                        "which": which}), flush=True)
 
 
-def cpu_baseline(model_name, chunk_s, new_tokens, budget_s=150):
-    """Reported baseline (not the target): the reference's CPU path on a BOUNDED sample - one `chunk_s` s chunk,
-    `new_tokens` forced tokens - in a child process with a hard wall-clock budget.  oracle/ is imported only here."""
-    import subprocess
-
+def cpu_baseline(model_name, chunk_s, new_tokens, calls, budget_s=240):
+    """Bounded sample in a child process with a hard wall-clock budget.  oracle/ is imported only here."""
     cores = _host_cores()
-    code = f"import bench; bench._cpu_baseline_worker({model_name!r}, {chunk_s}, {new_tokens})"
+    code = f"import bench; bench._cpu_baseline_worker({model_name!r}, {chunk_s}, {new_tokens}, {calls})"
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
-    what = (f"HF transformers WhisperForConditionalGeneration.generate on CPU fp32 (the arithmetic behind the reference's nvidia HF "
-            f"branch, R:thestage_speechkit/nvidia/asr_pipeline.py:57-60), {model_name} dims, 1 stream x {chunk_s} s chunk: "
-            f"log-mel + encoder + {new_tokens} forced tokens")
+    what = (f"{model_name} dims (random init), fp32, {cores} threads, 1 stream, {calls} pipeline calls on a {chunk_s} s chunk, each: "
+            f"feature extraction + encoder + {new_tokens} forced greedy tokens + word-timestamp DTW + merge")
     try:
         r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=budget_s)
         line = [l for l in r.stdout.splitlines() if l.startswith("CPU_BASELINE ")]
@@ -178,13 +160,124 @@ def cpu_baseline(model_name, chunk_s, new_tokens, budget_s=150):
             raise RuntimeError((r.stderr or r.stdout)[-300:])
         d = json.loads(line[-1][len("CPU_BASELINE "):])
         return {"value": round(d["tok"] / d["dt"], 3), "unit": "tok/s", "cores": d["cores"], "kind": "reference",
-                "sample": what + f", {d['dt']:.1f} s wall (+{d['init']:.1f} s model init)"}
+                "sample": f"{d['which']}: {what}; {d['dt']:.1f} s wall ({', '.join(f'{x:.1f}' for x in d['calls'])} s per call; "
+                          f"+{d['init']:.0f} s untimed model init)"}
     except subprocess.TimeoutExpired:
-        return {"value": round(new_tokens / budget_s, 3), "unit": "tok/s", "cores": cores, "kind": "reference",
+        return {"value": round(new_tokens * calls / budget_s, 3), "unit": "tok/s", "cores": cores, "kind": "reference",
                 "sample": what + f": did NOT finish within the {budget_s} s budget - value is an upper bound"}
 
 
-def main():
+# ------------------------------------------------------------------------------------------------------------------
+# the same workload through the drop-in API (rank 0, N = 1)
+# ------------------------------------------------------------------------------------------------------------------
+def pipeline_leg(eng, dims, args, device_index, heads, latency_calls, hub_rounds):
+    """tokens/s of `sessions` threads calling the reference's `TranscriptionBackend.transcribe` contract through the
+    BatchingHub, and p50/p90 wall time of a single `AMDWhisperBackend.transcribe` call on a host float32 buffer (PCIe upload,
+    HF chunking, feature extraction, generate control flow, tokenizer decode and LCS merge included)."""
+    from transformers import WhisperFeatureExtractor
+
+    from thewhisper_amd import AMDWhisperBackend, ASRPipeline
+    from thewhisper_amd.serving import BatchingHub
+
+    B = args.streams
+    model = synthetic.skeleton_model(dims, device=f"cuda:{device_index}", dtype=torch.bfloat16, alignment_heads=heads)
+    pipe = ASRPipeline(model, feature_extractor=WhisperFeatureExtractor(feature_size=dims["n_mels"], chunk_length=args.chunk_s),
+                       tokenizer=synthetic.build_tokenizer(dims["vocab"]), chunk_length_s=args.chunk_s, device=f"cuda:{device_index}",
+                       torch_dtype=torch.bfloat16, batch_size=B, engine=eng)
+    backend = AMDWhisperBackend(None, chunk_length_s=args.chunk_s, asr_pipeline=pipe)
+    counted = {"tok": 0}
+    inner = eng.generate_greedy
+
+    def counting(prompt, **kw):
+        out = inner(prompt, **kw)
+        seq, n0 = out["sequences"], np.asarray(prompt).shape[1]
+        eos = int(kw.get("eos_id", 50257))
+        for row in seq[:, n0:]:
+            hit = np.nonzero(row == eos)[0]
+            counted["tok"] += int(hit[0]) + 1 if len(hit) else len(row)
+        return out
+
+    eng.generate_greedy = counting
+    try:
+        rng = np.random.default_rng(7)
+        clips = [(rng.standard_normal(args.chunk_s * 16000) * 0.1).clip(-1, 1).astype(np.float32) for _ in range(B)]
+        for i in range(3):
+            backend.transcribe(clips[i % B], 0.0, 16000)
+        lat = []
+        for i in range(latency_calls):
+            t0 = time.perf_counter()
+            backend.transcribe(clips[i % B], 0.0, 16000)
+            lat.append((time.perf_counter() - t0) * 1e3)
+        lat.sort()
+        hub = BatchingHub(backend, max_batch=B, max_wait_s=0.05)
+        gate = threading.Barrier(B)
+
+        def session(k, rounds):
+            be = hub.stream_backend()
+            for _ in range(rounds):
+                gate.wait()
+                be.transcribe(clips[k], 0.0, 16000)
+
+        def run(rounds):
+            th = [threading.Thread(target=session, args=(k, rounds)) for k in range(B)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+
+        run(1)                                   # warm-up round (graph capture for this batch size)
+        counted["tok"] = 0
+        hub.batches.clear()
+        t0 = time.perf_counter()
+        run(hub_rounds)
+        dt = time.perf_counter() - t0
+        hub.close()
+        return {
+            "hub_tok_per_s": round(counted["tok"] / dt, 1), "hub_sessions": B, "hub_rounds": hub_rounds,
+            "hub_ms_per_round": round(dt / hub_rounds * 1e3, 2), "hub_batch_sizes": sorted(set(hub.batches)),
+            "backend_transcribe_p50_ms": round(lat[len(lat) // 2], 2) if lat else None,
+            "backend_transcribe_p90_ms": round(lat[min(len(lat) - 1, (len(lat) * 9) // 10)], 2) if lat else None,
+            "backend_transcribe_calls": len(lat),
+            "note": f"host float32 {args.chunk_s} s buffers through thewhisper_amd.AMDWhisperBackend.transcribe (reference contract "
+                    f"R:thestage_speechkit/streaming/streaming_pipeline.py:388-435: word timestamps on, max_new_tokens=128, natural eos); "
+                    f"{B} session threads share one engine through BatchingHub",
+        }
+    finally:
+        eng.generate_greedy = inner
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: re-execute as N ranks of one node, one GPU each."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def load_pmc_traffic(args):
+    """HBM bytes per decode step from the committed rocprofv3 PMC passes of the same command line
+    (tools/profile_round.sh -> profiles/*_pmc_step_traffic.json); None when no summary matches this configuration."""
+    best = None
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_step_traffic.json"))):
+        try:
+            d = json.load(open(p))
+        except Exception:  # noqa: BLE001
+            continue
+        c = d.get("config", {})
+        if (c.get("model"), c.get("streams"), c.get("chunk_s"), c.get("dtype"), c.get("new_tokens")) == \
+                (args.model, args.streams, args.chunk_s, args.dtype, args.new_tokens):
+            best = (d, os.path.basename(p))
+    return best
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -197,40 +290,58 @@ def main():
                     help="fp8 = bf16 activations/encoder + MXFP8 decoder projection weights (BASELINE config 5)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-tokens", type=int, default=8)
+    ap.add_argument("--cpu-tokens", type=int, default=32, help="forced tokens per CPU-baseline call (BASELINE.md section 3: >= 3 calls x 32)")
+    ap.add_argument("--cpu-calls", type=int, default=3)
     ap.add_argument("--encoder-cus", type=int, default=64,
                     help="overlap the encoder of batch k+1 (confined to this many CUs, second context) with the decode loop of "
                          "batch k (thewhisper_amd/overlap.py); 0 = one context, strictly sequential stages")
     ap.add_argument("--latency-iters", type=int, default=100, help="single-stream chunk calls timed for the p50 (after 10 warm-ups; SURVEY.md section 8d)")
-    args = ap.parse_args()
+    ap.add_argument("--no-pipeline-leg", action="store_true", help="skip the measurement through ASRPipeline / BatchingHub")
+    ap.add_argument("--hub-rounds", type=int, default=4)
+    args = ap.parse_args(argv)
 
-    if not torch.cuda.is_available():
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus, argv))
+
+    # TW_BENCH_ENGINE="module:callable": control-flow tests of the N > 1 path on a box without GPUs (tests/test_bench_cpu.py)
+    stub = os.environ.get("TW_BENCH_ENGINE")
+    if not stub and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     from thewhisper_amd.dist import Replicas
 
     local = int(os.environ.get("TW_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))  # TW_BENCH_DEVICE: plumbing tests only
-    torch.cuda.set_device(local)
-    rep = Replicas(device=torch.device("cuda", local))  # nccl (= RCCL) when WORLD_SIZE > 1; barrier / max / sum only
+    dev = torch.device("cpu") if stub else torch.device("cuda", local)
+    if not stub:
+        torch.cuda.set_device(local)
+    rep = Replicas(device=dev)  # nccl (= RCCL) when WORLD_SIZE > 1; barrier / max / sum only
     rank, world = rep.rank, rep.world
-
-    from thewhisper_amd.engine import WhisperEngine
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but the process group has {world} rank(s): launch with "
+                         f"`python bench.py --gpus {args.gpus}` or torch.distributed.run --nproc-per-node {args.gpus}")
 
     dims = DIMS[args.model]
     T = 50 * args.chunk_s
     B = args.streams
-    dev = torch.device("cuda", local)
     heads = alignment_heads(dims)
-    eng = WhisperEngine(dims, T, max_batch=B, dtype=args.dtype, alignment_heads=heads, device=local,
-                        use_graph=not args.no_graph)
-    sd = random_state_dict(dims, dev, seed=0)
-    eng.load_state_dict(sd)
+    if stub:
+        mod, fn = stub.split(":")
+        make_engine = getattr(importlib.import_module(mod), fn)
+    else:
+        from thewhisper_amd.engine import WhisperEngine
+
+        def make_engine():
+            return WhisperEngine(dims, T, max_batch=B, dtype=args.dtype, alignment_heads=heads, device=local, use_graph=not args.no_graph)
+
+    eng = make_engine()
+    sd = None if stub else random_state_dict(dims, dev, seed=0)
+    if sd is not None:
+        eng.load_state_dict(sd)
     overlap = None
     overlap_note = "off"
-    if args.encoder_cus > 0:
+    if args.encoder_cus > 0 and not stub:
         try:
             from thewhisper_amd.overlap import EncoderOverlap
-            eng2 = WhisperEngine(dims, T, max_batch=B, dtype=args.dtype, alignment_heads=heads, device=local,
-                                 use_graph=not args.no_graph)
+            eng2 = make_engine()
             eng2.load_state_dict(sd)
             overlap = EncoderOverlap([eng, eng2], encoder_cus=args.encoder_cus)
             overlap_note = (f"encoder stage of batch k+1 on {args.encoder_cus} CUs (second context) under the decode loop of "
@@ -239,7 +350,8 @@ def main():
             overlap = None
             overlap_note = f"off (could not set up CU-masked streams: {e!r})"
     del sd
-    torch.cuda.empty_cache()
+    if not stub:
+        torch.cuda.empty_cache()
 
     n_samples = args.chunk_s * 16000
     g = torch.Generator(device=dev)
@@ -257,9 +369,6 @@ def main():
         L = out["length"]
         eng.token_timestamps(nb, n_prompt, L, [2 * T] * nb)
         return L - n_prompt
-
-    def barrier():
-        rep.barrier()                      # dist.barrier() + torch.cuda.synchronize()
 
     stage = {"logmel_ms": 0.0, "encode_ms": 0.0, "cross_kv_ms": 0.0, "greedy_ms": 0.0, "token_timestamps_ms": 0.0}
     dec_steps = 0
@@ -292,21 +401,22 @@ def main():
 
     if args.warmup > 0:  # with the overlap at least two passes, so that both contexts capture their step graph untimed
         run_steps(max(args.warmup, 2) if overlap is not None else args.warmup)
-    barrier()
+    rep.barrier()                          # dist.barrier() + torch.cuda.synchronize()
     t0 = time.perf_counter()
     for ntok, tm in run_steps(args.steps):
         new_tok += ntok
         for k in stage:
             stage[k] += tm[k]
         dec_steps += tm["decode_steps"]
-    barrier()
-    dt = time.perf_counter() - t0
-    dt = rep.max_float(dt)                 # max over ranks
+    rep.barrier()
+    dt_local = time.perf_counter() - t0
+    dt = rep.max_float(dt_local)           # max over ranks
+    per_rank = rep.gather_floats(new_tok / dt_local)   # tokens/s of every rank on its own clock
     new_tok = rep.sum_int(new_tok)         # whole-job token count
 
-    # single-stream chunk latency (config 3 shape): same engine, B = 1
+    # single-stream chunk latency (config 3 shape) on the raw engine: same context, B = 1, PCM already in HBM
     lat = []
-    if rank == 0 and args.latency_iters > 0:
+    if rank == 0 and args.latency_iters > 0 and not stub:
         for _ in range(min(10, args.latency_iters)):   # warm-ups
             step(1)
         for _ in range(args.latency_iters):
@@ -324,6 +434,8 @@ def main():
         alg_bytes, W = int(alg_bytes), int(W)
         greedy_ms = stage["greedy_ms"] / args.steps
         achieved = alg_bytes / (greedy_ms * 1e-3) / 1e9 if greedy_ms > 0 else 0.0
+        avg_step_ms = greedy_ms / max(1, steps_per_call)
+        pmc = load_pmc_traffic(args)
         result = {
             "metric": "transcription tokens/sec (node), whisper-large-v3 10s chunks" if args.model == "large-v3" and args.chunk_s == 10
             else f"transcription tokens/sec (node), whisper-{args.model} {args.chunk_s}s chunks",
@@ -346,28 +458,43 @@ def main():
                 "decode_step_graph": not args.no_graph,
                 "encoder_overlap": overlap_note,
             },
+            "per_rank_tok_per_s": [round(x, 1) for x in per_rank],
             "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage.items()},
             "decode_tok_per_s": round(B * args.new_tokens / (greedy_ms * 1e-3), 1) if greedy_ms > 0 else None,
             "roofline": {
-                "kernel": "decode step (weight-streaming gemv + single-query attention over the KV caches), all steps of one call",
+                "kernel": "decode step = one replay of the captured step graph (weight-streaming projections + single-query attention "
+                          "over the K/V caches + sampler); averaged over all steps of a greedy call",
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "algorithmic_bytes_per_call": alg_bytes, "weight_bytes_per_step": W, "launches_per_call": steps_per_call,
-                "avg_launch_ms": round(greedy_ms / max(1, steps_per_call), 4),
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 4), "copy_ceiling": HBM_COPY_CEILING_GBS,
+                "traffic": (round(pmc[0]["hbm_bytes_per_step"]) if pmc else None),
+                "traffic_source": (f"profiles/{pmc[1]}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command line, FETCH_SIZE x2 "
+                                   f"(gfx950 correction, MI355X_MICROARCH.md)" if pmc else None),
+                "algorithmic_bytes_per_step": int(alg_bytes / max(1, steps_per_call)),
+                "algorithmic_bytes_per_call": alg_bytes, "weight_bytes_per_step": W, "decode_steps_per_call": steps_per_call,
+                "avg_step_ms": round(avg_step_ms, 4),
             },
         }
         if lat:
             lat.sort()
             result["p50_chunk_latency_ms"] = round(lat[len(lat) // 2], 2)
             result["p90_chunk_latency_ms"] = round(lat[min(len(lat) - 1, (len(lat) * 9) // 10)], 2)
-            result["chunk_latency_note"] = f"1 stream, {args.chunk_s} s chunk, {args.new_tokens} tokens + DTW, {len(lat)} calls"
-        if world == 1 and not args.no_cpu_baseline:
+            result["chunk_latency_note"] = (f"raw engine, 1 stream, {args.chunk_s} s chunk resident in HBM, {args.new_tokens} tokens + DTW, "
+                                            f"{len(lat)} calls; the API-level latency is pipeline.backend_transcribe_p50_ms")
+        if world == 1 and not stub and not args.no_pipeline_leg:
             try:
-                result["cpu_baseline"] = cpu_baseline(args.model, args.chunk_s, args.cpu_tokens)
+                result["pipeline"] = pipeline_leg(eng, dims, args, local, heads, args.latency_iters, args.hub_rounds)
+            except Exception as e:  # noqa: BLE001
+                result["pipeline"] = {"error": repr(e)}
+        if world == 1 and not stub and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(args.model, args.chunk_s, args.cpu_tokens, args.cpu_calls)
             except Exception as e:  # noqa: BLE001
                 result["cpu_baseline"] = {"value": None, "unit": "tok/s", "cores": os.cpu_count(), "kind": "reference",
                                           "sample": f"failed: {e!r}"}
         print(json.dumps(result), flush=True)
+    if overlap is not None:
+        overlap.close()
     rep.close()
 
 

@@ -16,28 +16,15 @@ import numpy as np
 
 from .whisper_oracle import SpecialTokens, WhisperDims, interpolate_positions
 
-LANGS = [
-    "en", "zh", "de", "es", "ru", "ko", "fr", "ja", "pt", "tr", "pl", "ca", "nl", "ar", "sv", "it", "id", "hi",
-    "fi", "vi", "he", "uk", "el", "ms", "cs", "ro", "da", "hu", "ta", "no", "th", "ur", "hr", "bg", "lt", "la",
-    "mi", "ml", "cy", "sk", "te", "fa", "lv", "bn", "sr", "az", "sl", "kn", "et", "mk", "br", "eu", "is", "hy",
-    "ne", "mn", "bs", "kk", "sq", "sw", "gl", "mr", "pa", "si", "km", "sn", "yo", "so", "af", "oc", "ka", "be",
-    "tg", "sd", "gu", "am", "yi", "lo", "uz", "fo", "ht", "ps", "tk", "nn", "mt", "sa", "lb", "my", "bo", "tl",
-    "mg", "as", "tt", "haw", "ln", "ha", "ba", "jw", "su", "yue",
-]
+# Checkpoint-free fixtures (synthetic tokenizer, generation config, alignment heads) are not arithmetic of the path; they
+# live in one place, thewhisper_amd/synthetic.py, because benchmarks and examples of the product need them too.
+from thewhisper_amd import synthetic as _syn
+
+LANGS = _syn.LANGS
 
 
 def default_alignment_heads(dims: WhisperDims):
-    """Synthetic alignment heads (the upstream checkpoints' lists are not available offline):
-    the upper half of the decoder layers, rotating heads - 10 pairs for 32-layer models like
-    large-v3, fewer for small ones."""
-    n = min(10, max(2, dims.dec_layers * 2))
-    out = []
-    for j in range(n):
-        layer = dims.dec_layers - 1 - (j % max(1, dims.dec_layers // 2))
-        head = (3 * j + 1) % dims.heads
-        if [layer, head] not in out:
-            out.append([layer, head])
-    return out
+    return _syn.default_alignment_heads(dims.dec_layers, dims.heads)
 
 
 def build_hf_config(dims: WhisperDims):
@@ -70,24 +57,7 @@ def build_hf_config(dims: WhisperDims):
 
 def fill_generation_config(gc, dims: WhisperDims, alignment_heads=None):
     """Hand-filled multilingual generation config."""
-    st = SpecialTokens()
-    gc.lang_to_id = {f"<|{l}|>": st.lang_en + i for i, l in enumerate(LANGS)}
-    gc.task_to_id = {"transcribe": st.transcribe, "translate": st.translate}
-    gc.no_timestamps_token_id = st.no_timestamps
-    gc.prev_sot_token_id = st.sot_prev
-    gc.is_multilingual = True
-    gc.alignment_heads = alignment_heads if alignment_heads is not None else default_alignment_heads(dims)
-    gc.max_initial_timestamp_index = 50
-    gc.suppress_tokens = []
-    gc.begin_suppress_tokens = [220, st.eos]
-    gc.max_length = dims.max_target_positions
-    gc.forced_decoder_ids = None
-    gc.bos_token_id = st.eos
-    gc.eos_token_id = st.eos
-    gc.pad_token_id = st.eos
-    gc.decoder_start_token_id = st.sot
-    gc.return_timestamps = False
-    return gc
+    return _syn.fill_generation_config(gc, dims.dec_layers, dims.heads, dims.max_target_positions, alignment_heads)
 
 
 def build_hf_model(dims: WhisperDims, weights: Dict[str, np.ndarray], dtype=None, alignment_heads=None, model_cls=None):
@@ -118,56 +88,9 @@ def build_hf_model(dims: WhisperDims, weights: Dict[str, np.ndarray], dtype=None
     return model
 
 
-def _bytes_to_unicode():
-    bs = list(range(ord("!"), ord("~") + 1)) + list(range(ord("\u00a1"), ord("\u00ac") + 1)) + list(range(ord("\u00ae"), ord("\u00ff") + 1))
-    cs = bs[:]
-    n = 0
-    for b in range(256):
-        if b not in bs:
-            bs.append(b)
-            cs.append(256 + n)
-            n += 1
-    return dict(zip(bs, [chr(c) for c in cs]))
-
-
 def build_tokenizer(dims: WhisperDims):
-    """In-memory synthetic ``WhisperTokenizer`` with the large-v3 special-token id layout
-    (ctor HF:models/whisper/tokenization_whisper.py:206-276)."""
-    from transformers import WhisperTokenizer
-
-    st = SpecialTokens()
-    vocab: Dict[str, int] = {}
-    # byte-level alphabet first (the GPT-2 byte<->unicode table used by the ByteLevel pre-tokenizer/decoder)
-    for ch in _bytes_to_unicode().values():
-        vocab[ch] = len(vocab)
-    i = 0
-    while len(vocab) < st.eos:
-        tok = f"Ġw{i}"
-        if tok not in vocab:
-            vocab[tok] = len(vocab)
-        i += 1
-    specials = ["<|endoftext|>", "<|startoftranscript|>"]
-    specials += [f"<|{l}|>" for l in LANGS]
-    specials += ["<|translate|>", "<|transcribe|>", "<|startoflm|>", "<|startofprev|>", "<|nospeech|>", "<|notimestamps|>"]
-    n_ts = dims.vocab - (st.eos + len(specials))
-    specials += [f"<|{k * 0.02:.2f}|>" for k in range(n_ts)]
-    for s in specials:
-        vocab[s] = len(vocab)
-    assert len(vocab) == dims.vocab, (len(vocab), dims.vocab)
-    assert vocab["<|notimestamps|>"] == st.no_timestamps
-    tok = WhisperTokenizer(
-        vocab=vocab,
-        merges=[],
-        language="en",
-        task="transcribe",
-        # timestamps are ordinary added tokens upstream: `timestamp_begin = all_special_ids[-1] + 1`
-        additional_special_tokens=[t for t in specials[1:] if vocab[t] <= st.no_timestamps],
-        pad_token="<|endoftext|>",
-        bos_token="<|endoftext|>",
-        eos_token="<|endoftext|>",
-        unk_token="<|endoftext|>",
-    )
-    return tok
+    """In-memory synthetic ``WhisperTokenizer`` with the large-v3 special-token id layout."""
+    return _syn.build_tokenizer(dims.vocab)
 
 
 def build_feature_extractor(dims: WhisperDims, chunk_length_s: int):

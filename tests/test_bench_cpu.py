@@ -1,0 +1,51 @@
+"""bench.py's N > 1 control flow without GPUs: `python bench.py --gpus 2` self-spawns two ranks (torch.distributed.run,
+gloo), each drives a stub engine; rank 0 prints ONE JSON line with n_gpus = 2, per-rank rates and the whole-job sum."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env_extra=None):
+    env = dict(os.environ, TW_BENCH_ENGINE="tests.stub_engine:make", TW_DIST_BACKEND="gloo", PYTHONPATH=ROOT,
+               HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", *extra],
+                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+
+
+@pytest.mark.timeout(300)
+def test_bench_self_spawns_ranks_and_prints_one_json_line():
+    r = _run(["--gpus", "2"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert len(d["per_rank_tok_per_s"]) == 2 and all(x > 0 for x in d["per_rank_tok_per_s"])
+    # whole-job value: 2 ranks x 2 steps x 16 streams x 128 tokens over the slowest rank's time
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 * d["steps"] - 2 * 2 * 16 * 128) < 1.0
+    assert d["roofline"]["decode_steps_per_call"] == 130 and "cpu_baseline" not in d and "pipeline" not in d
+    # SURVEY 8d bytes: W = 2*(32*14*1280^2 + 51866*1280)
+    assert d["roofline"]["weight_bytes_per_step"] == 2 * (32 * 14 * 1280 * 1280 + 51866 * 1280)
+
+
+@pytest.mark.timeout(120)
+def test_bench_refuses_a_rank_count_mismatch():
+    r = _run(["--gpus", "2"], {"WORLD_SIZE": "1", "RANK": "0"})     # a launcher gave one rank, the command line says two
+    assert r.returncode != 0 and "process group has 1 rank" in (r.stderr + r.stdout)
+
+
+def test_algorithmic_bytes_follow_survey_8d():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    total, W = bench.algorithmic_decode_bytes(bench.DIMS["large-v3"], 16, 500, 3, 130)
+    assert W == 1601044480 + 0 * 1 or abs(W - 1.601e9) < 1e6
+    assert abs(total - 400.8e9) < 0.2e9      # the figure the round-1 review derived for the driver's call

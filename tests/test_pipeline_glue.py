@@ -110,3 +110,29 @@ def test_lcs_patch_is_the_reference_compare():
     assert lp._ordered((1.0, None), (0.5, 0.7)) is True       # open-ended left token: in order
     assert lp._ordered((1.0, 1.2), (0.5, 0.7)) is False
     assert lp._ordered((0.2, 0.4), (0.5, 0.7)) is True
+
+
+def test_shared_engine_and_skeleton_model_give_the_reference_result():
+    """ASRPipeline(engine=...): a context loaded elsewhere under a weight-less skeleton model (thewhisper_amd/synthetic.py) -
+    the construction bench.py's pipeline-level leg and multi-pipeline serving use - returns what the reference returned."""
+    import dataclasses
+
+    from thewhisper_amd import ASRPipeline, synthetic
+
+    g = golden()["micro_c10"]
+    dims = wo.PRESETS[g["preset"]]
+    d = dataclasses.asdict(dims)
+    heads = hr.default_alignment_heads(dims)
+    eng = oracle_engine_factory(d, 500, g["batch_size"], "f32", heads, 0)
+    eng.load_state_dict({k: torch.from_numpy(v) for k, v in wo.make_weights(dims, 0).items()})
+    model = synthetic.skeleton_model(d, device="cpu", dtype=torch.float32, alignment_heads=heads)
+    assert sum(p.numel() for p in model.parameters()) == 0
+    pipe = ASRPipeline(model, feature_extractor=hr.build_feature_extractor(dims, 10), tokenizer=synthetic.build_tokenizer(dims.vocab),
+                       chunk_length_s=10, device="cpu", torch_dtype=torch.float32, batch_size=g["batch_size"], engine=eng)
+    audio = wo.synth_audio(16000 * g["seconds"], g["seed"], g["kind"])
+    gk = {"num_beams": 1, "do_sample": False, "use_cache": True, "language": "en", "max_new_tokens": g["max_new_tokens"]}
+    out = pipe(audio.copy(), generate_kwargs=dict(gk), chunk_length_s=9, return_timestamps="word")
+    assert normalise(out) == g["outputs"]["word"]
+    with pytest.raises(ValueError, match="encoder frames"):
+        ASRPipeline(model, feature_extractor=hr.build_feature_extractor(dims, 30), tokenizer=synthetic.build_tokenizer(dims.vocab),
+                    chunk_length_s=30, device="cpu", torch_dtype=torch.float32, engine=eng)

@@ -40,6 +40,7 @@ class ASRPipeline(AutomaticSpeechRecognitionPipeline):
         revision = kwargs.pop("revision", "main")
         engine_factory: Optional[Callable] = kwargs.pop("engine_factory", None)  # test seam only
         decoder_weights: Optional[str] = kwargs.pop("decoder_weights", None)     # MI355X-only option: "fp8" = MXFP8 decoder weights
+        shared_engine = kwargs.pop("engine", None)  # MI355X-only option: an already loaded WhisperEngine (shared context)
         if model_size not in (None, "S", "M", "L", "XL"):
             raise ValueError(f"Invalid model_size: {model_size}")
         # model_size selects a TheStage engine flavour on NVIDIA (S = quantised, XL = fp16).  On MI355X every size maps to the
@@ -82,6 +83,14 @@ class ASRPipeline(AutomaticSpeechRecognitionPipeline):
         )
         # A0 (patch_hf_model) happens inside the library when the engine is built for T = 50*chunk_length_s.
         batch_size = int(kwargs.get("batch_size") or 1)
+        if shared_engine is not None:
+            if shared_engine.T != int(1500 * (chunk_length_s / 30)):
+                raise ValueError(f"engine was built for {shared_engine.T} encoder frames, chunk_length_s={chunk_length_s} needs "
+                                 f"{int(1500 * (chunk_length_s / 30))}")
+            if batch_size > shared_engine.max_batch:
+                raise ValueError(f"batch_size={batch_size} exceeds the engine capacity max_batch={shared_engine.max_batch}")
+            self.feature_extractor.attach_engine(self.model.attach_engine(shared_engine))
+            return
         engine = self.model.build_engine(
             chunk_length_s=chunk_length_s, max_batch=max(1, min(64, batch_size)), dtype=torch_dtype,
             engine_factory=engine_factory, decoder_weights=decoder_weights,

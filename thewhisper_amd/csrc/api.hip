@@ -29,6 +29,8 @@ struct LayerW {
   void *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr;
   // folded pre-LayerNorm companions of the decoder's LN'd projections (float32 [N]): see k_decode.hip
   float *qkv_gw = nullptr, *qkv_cb = nullptr, *qc_gw = nullptr, *qc_cb = nullptr, *fc1_gw = nullptr, *fc1_cb = nullptr;
+  // weight rows per workgroup tile each decoder projection was laid out for (k_decode.hip: 16, or 8 / 4 for the narrow ones)
+  int tr_qkv = 16, tr_o = 16, tr_qc = 16, tr_oc = 16, tr_1 = 16, tr_2 = 16;
 };
 
 }  // namespace
@@ -495,15 +497,22 @@ int tw_finalize_weights(tw_ctx* c, void* stream) {
     if ((size_t)c->ffn * c->d > mx) mx = (size_t)c->ffn * c->d;
     void* scratch = nullptr;
     HIPCHK(c, hipMalloc(&scratch, mx * e));
-    auto retile = [&](void* w, int N, int K, unsigned char** scales) -> int {
+    // narrow projections (N <= 2048: the three d x d matrices and fc2) are laid out for 8-row tiles so that their launches
+    // cover 160 instead of 80 compute units (k_decode.hip); TW_SK_TR overrides (16 / 8 / 4) for experiments
+    const char* tr_env = getenv("TW_SK_TR");
+    const int tr_narrow = tr_env ? atoi(tr_env) : 8;
+    auto retile = [&](void* w, int N, int K, unsigned char** scales, int* tr_out) -> int {
       const size_t Np = (size_t)(N + 15) / 16 * 16;
+      int tr = 16;
+      if (tr_out && !c->w8 && N <= 2048 && (tr_narrow == 8 || tr_narrow == 4) && N % tr_narrow == 0) tr = tr_narrow;
+      if (tr_out) *tr_out = tr;
       if (c->w8) {  // MXFP8 fragments + block scales replace the bf16 rows in the same buffer (half the bytes + 1/32)
         unsigned char* sc = reinterpret_cast<unsigned char*>(scratch);
         HIPCHK(c, launch_quant_mx8(w, sc, sc + Np * K, N, K, st));
         HIPCHK(c, hipMemcpyAsync(w, scratch, Np * K + Np * K / 32, hipMemcpyDeviceToDevice, st));
         *scales = reinterpret_cast<unsigned char*>(w) + Np * K;
       } else {
-        HIPCHK(c, launch_tile_weights(c->dtype, w, scratch, N, K, st));
+        HIPCHK(c, launch_tile_weights(c->dtype, w, scratch, N, K, tr, st));
         HIPCHK(c, hipMemcpyAsync(w, scratch, Np * K * e, hipMemcpyDeviceToDevice, st));
         *scales = nullptr;
       }
@@ -512,14 +521,14 @@ int tw_finalize_weights(tw_ctx* c, void* stream) {
     int r = TW_OK;
     for (int l = 0; l < c->Ld && r == TW_OK; ++l) {
       LayerW& L = c->dec[l];
-      if ((r = retile(L.wqkv, 3 * c->d, c->d, &L.s_qkv)) != TW_OK) break;
-      if ((r = retile(L.wo, c->d, c->d, &L.s_o)) != TW_OK) break;
-      if ((r = retile(L.wq_c, c->d, c->d, &L.s_qc)) != TW_OK) break;
-      if ((r = retile(L.wo_c, c->d, c->d, &L.s_oc)) != TW_OK) break;
-      if ((r = retile(L.w1, c->ffn, c->d, &L.s_1)) != TW_OK) break;
-      if ((r = retile(L.w2, c->d, c->ffn, &L.s_2)) != TW_OK) break;
+      if ((r = retile(L.wqkv, 3 * c->d, c->d, &L.s_qkv, nullptr)) != TW_OK) break;   // K/V scatter epilogue: 16-row tiles
+      if ((r = retile(L.wo, c->d, c->d, &L.s_o, &L.tr_o)) != TW_OK) break;
+      if ((r = retile(L.wq_c, c->d, c->d, &L.s_qc, &L.tr_qc)) != TW_OK) break;
+      if ((r = retile(L.wo_c, c->d, c->d, &L.s_oc, &L.tr_oc)) != TW_OK) break;
+      if ((r = retile(L.w1, c->ffn, c->d, &L.s_1, &L.tr_1)) != TW_OK) break;
+      if ((r = retile(L.w2, c->d, c->ffn, &L.s_2, &L.tr_2)) != TW_OK) break;
     }
-    if (r == TW_OK) r = retile(c->logit_w, c->V, c->d, &c->logit_ws);
+    if (r == TW_OK) r = retile(c->logit_w, c->V, c->d, &c->logit_ws, nullptr);
     hipError_t he = hipStreamSynchronize(st);
     hipFree(scratch);
     if (r != TW_OK) return r;
@@ -669,13 +678,13 @@ int decode_core(tw_ctx* c, int B, hipStream_t st) {
     HIPCHK(c, launch_dec_self_attn(dt, c->dq, sk, sv, Pp, c->datt, B, H, c->dec_key_bound > 0 ? c->dec_key_bound : P, c->stt, st));
     {
       GemvArgs a{};
-      a.x = c->datt; a.ldx = d; a.W = L.wo; a.wscale = L.s_o; a.bias = L.bo; a.N = d; a.K = d; a.B = B; a.res = xin; a.ldres = d;
+      a.x = c->datt; a.ldx = d; a.W = L.wo; a.wscale = L.s_o; a.tr = L.tr_o; a.bias = L.bo; a.N = d; a.K = d; a.B = B; a.res = xin; a.ldres = d;
       a.y = xmid; a.ldy = d;
       HIPCHK(c, launch_gemv(dt, a, st));
     }
     {
       GemvArgs a{};
-      a.x = xmid; a.ldx = d; a.ln_gw = L.qc_gw; a.ln_cb = L.qc_cb; a.W = L.wq_c; a.wscale = L.s_qc; a.N = d; a.K = d; a.B = B;
+      a.x = xmid; a.ldx = d; a.ln_gw = L.qc_gw; a.ln_cb = L.qc_cb; a.W = L.wq_c; a.wscale = L.s_qc; a.tr = L.tr_qc; a.N = d; a.K = d; a.B = B;
       a.y = c->dq; a.ldy = d;
       HIPCHK(c, launch_gemv(dt, a, st));
     }
@@ -684,19 +693,19 @@ int decode_core(tw_ctx* c, int B, hipStream_t st) {
                                     P, c->stt, st));
     {
       GemvArgs a{};
-      a.x = c->datt; a.ldx = d; a.W = L.wo_c; a.wscale = L.s_oc; a.bias = L.bo_c; a.N = d; a.K = d; a.B = B; a.res = xmid; a.ldres = d;
+      a.x = c->datt; a.ldx = d; a.W = L.wo_c; a.wscale = L.s_oc; a.tr = L.tr_oc; a.bias = L.bo_c; a.N = d; a.K = d; a.B = B; a.res = xmid; a.ldres = d;
       a.y = xin; a.ldy = d;
       HIPCHK(c, launch_gemv(dt, a, st));
     }
     {
       GemvArgs a{};
-      a.x = xin; a.ldx = d; a.ln_gw = L.fc1_gw; a.ln_cb = L.fc1_cb; a.W = L.w1; a.wscale = L.s_1; a.N = F; a.K = d; a.B = B;
+      a.x = xin; a.ldx = d; a.ln_gw = L.fc1_gw; a.ln_cb = L.fc1_cb; a.W = L.w1; a.wscale = L.s_1; a.tr = L.tr_1; a.N = F; a.K = d; a.B = B;
       a.gelu = 1; a.y = c->dh; a.ldy = F;
       HIPCHK(c, launch_gemv(dt, a, st));
     }
     {
       GemvArgs a{};
-      a.x = c->dh; a.ldx = F; a.W = L.w2; a.wscale = L.s_2; a.bias = L.b2; a.N = d; a.K = F; a.B = B; a.res = xin; a.ldres = d;
+      a.x = c->dh; a.ldx = F; a.W = L.w2; a.wscale = L.s_2; a.tr = L.tr_2; a.bias = L.b2; a.N = d; a.K = F; a.B = B; a.res = xin; a.ldres = d;
       a.y = xmid; a.ldy = d;
       HIPCHK(c, launch_gemv(dt, a, st));
     }

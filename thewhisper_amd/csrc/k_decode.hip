@@ -217,10 +217,16 @@ template <> __device__ __forceinline__ void sk_stats<float>(const u32x4_t& v, fl
 // CG = groups of 16 streams (1, 2 or 4: up to 64 streams per launch).  Every weight fragment is used for all groups, so the
 // weight stream - the dominant cost - is paid once per launch whatever the number of streams; activations, accumulators
 // and the epilogue are per group (group g of a fragment-major activation buffer starts at element g*16*K).
-template <typename T, int NW, int SK_MAXS, bool LN, int EPI, bool MULTI, bool W8, int CG>
+// TR = weight rows per workgroup tile (16, or 8 / 4 for the narrow projections): with N = 1280 a 16-row tiling yields only 80
+// workgroups on a 256-CU chip and every CU has to take in 41 KB (K = 1280) or 164 KB (K = 5120) at ~50 GB/s; TR = 8 (4)
+// spreads the same bytes over 160 (320) CUs.  The MFMA still contracts a 16-row A operand whose rows >= TR are zero (lanes
+// fr >= TR issue no request): matrix-core time is not what bounds these launches.  Weight layout for TR < 16:
+// [tile][step][kq * TR + fr][E] (tile_weights_kernel), i.e. a wavefront request is TR * 64 contiguous bytes.
+template <typename T, int NW, int SK_MAXS, bool LN, int EPI, bool MULTI, bool W8, int CG, int TR>
 __global__ __launch_bounds__(NW * 64, (CG > 1 ? (NW >= 16 ? 4 : 2) : (NW >= 16 ? 4 : (W8 ? (SK_MAXS <= 2 ? 4 : 2) : (SK_MAXS <= 5 ? 4 : 2)))))
 void skinny_mfma_kernel(GemvArgs a) {
   static_assert(!W8 || sizeof(T) == 2, "MXFP8 weights go with bf16 activations");
+  static_assert(TR == 16 || (!W8 && !MULTI && EPI != SK_KV && EPI != SK_F32), "narrow tiles: plain / residual / GELU projections only");
   constexpr int E = ElemTraits<T>::kPer16B;
   constexpr int XPS = W8 ? 4 : 1;  // 32-wide activation fragments per MFMA step
   constexpr int WPS = W8 ? 2 : 1;  // 16-B weight requests per MFMA step
@@ -256,9 +262,9 @@ void skinny_mfma_kernel(GemvArgs a) {
   const int S = K / (4 * E * XPS);  // MFMA steps per row (32 k each; 128 k with MXFP8 weights)
   const int s_lo = (int)((long long)wave * S / NW), s_hi = (int)((long long)(wave + 1) * S / NW);
   float* red = reinterpret_cast<float*>(smem);  // [NW][CG][256]
-  const int n_tiles = (N + 15) / 16;
+  const int n_tiles = (N + TR - 1) / TR;
   const int tile0 = blockIdx.x * RG;
-  const int ej = (tid >> 4) & 15, ei = tid & 15;  // epilogue role of threads 0..255: stream ej, tile row ei
+  const int ej = (tid >> 4) & 15, ei = tid & 15;  // epilogue role of threads 0..255: stream ej, tile row ei (rows >= TR idle)
 
   u32x4_t wq[SK_MAXS * WPS], xq[CG][SK_MAXS * XPS];
   int wsc[SK_MAXS];  // MXFP8: scale byte of this lane's 32-value weight block
@@ -267,7 +273,7 @@ void skinny_mfma_kernel(GemvArgs a) {
   for (int g = 0; g < CG; ++g) e_res[g] = 0.f;
   // --- request helpers: all unconditional, addresses clamped into the matrix ---
   auto load_epi = [&](int tile, float& c, float& gwv, float (&r)[CG]) {
-    const int n = min(tile * 16 + ei, N - 1);
+    const int n = min(tile * TR + min(ei, TR - 1), N - 1);
     if (LN) {
       gwv = gw_p[n];
       c = cb_p[n];
@@ -280,6 +286,8 @@ void skinny_mfma_kernel(GemvArgs a) {
       for (int g = 0; g < CG; ++g) r[g] = (float)res[(long long)g * 16 * N + tw_xt_index<T>(ej, n)];
     }
   };
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T*>(W), 0, (TR == 16 || W8) ? 0 : (int)((long long)n_tiles * S * 4 * TR * 16), 0x00020000);
   auto load_w = [&](int tile, int s0) {  // fragment-major weights: 1 KiB contiguous per wavefront request
     const int tl = min(tile, n_tiles - 1);
     if (W8) {
@@ -292,10 +300,19 @@ void skinny_mfma_kernel(GemvArgs a) {
         wq[2 * i + 1] = sk_load_w<unsigned char>(wt + st * 2048 + 1024);
         wsc[i] = ws[st * 64];
       }
-    } else {
+    } else if (TR == 16) {
       const T* wt = W + ((long long)tl * S * 64 + lane) * E;
 #pragma unroll
       for (int i = 0; i < SK_MAXS; ++i) wq[i] = sk_load_w<T>(wt + (long long)min(s0 + i, S - 1) * (64 * E));
+    } else {
+      // narrow tile: only the lanes of weight rows fr < TR request (through a buffer descriptor: the others are out of range
+      // and return zeros without a memory transaction)
+      const unsigned lane_off = (fr < TR) ? (unsigned)((kq * TR + fr) * 16) : 0x80000000u;
+      const unsigned tile_off = (unsigned)tl * (unsigned)(S * 4 * TR * 16);
+#pragma unroll
+      for (int i = 0; i < SK_MAXS; ++i)
+        wq[i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(
+            wr, lane_off + tile_off + (unsigned)(min(s0 + i, S - 1) * (4 * TR * 16)), 0, 2 /* nt */));
     }
   };
   // fragment-major activations: lane (stream fr, k-group kq) of each 32-k step.  Requested through a buffer descriptor so
@@ -401,7 +418,7 @@ void skinny_mfma_kernel(GemvArgs a) {
     TW_TS(3);
     if (tid < 256) {
       const int j = ej, i = ei;  // stream (within its group), row: 16 consecutive rows of one stream per 16 threads
-      const int n = tile * 16 + i;
+      const int n = tile * TR + i;
 #pragma unroll
       for (int g = 0; g < CG; ++g) {
         const int jg = g * 16 + j;  // stream
@@ -423,7 +440,7 @@ void skinny_mfma_kernel(GemvArgs a) {
         }
         if (EPI == SK_GELU) v = gelu_exact<T>(v);
         if (EPI == SK_RES) v += e_res[g];
-        if (tile < n_tiles && n < N && jg < B) {
+        if (tile < n_tiles && n < N && jg < B && i < TR) {
           if (EPI == SK_F32) {
             y_f32[(long long)jg * N + n] = v;
           } else if (EPI == SK_KV) {
@@ -455,17 +472,18 @@ void skinny_mfma_kernel(GemvArgs a) {
 // 16-B vector s*4+kq.  A wavefront's K slice is then ONE contiguous run (its requests are full cache lines in address
 // order, like a plain streaming copy) instead of 16 row segments of 64 B per request.  Rows >= N are zero.
 template <typename T>
-__global__ __launch_bounds__(256) void tile_weights_kernel(const T* __restrict__ src, T* __restrict__ dst, int N, int K) {
+__global__ __launch_bounds__(256) void tile_weights_kernel(const T* __restrict__ src, T* __restrict__ dst, int N, int K, int TR) {
   constexpr int E = ElemTraits<T>::kPer16B;
   const int S = K / E / 4;
+  const int LT = 4 * TR;                                            // 16-B vectors per (tile, step): 64 for 16-row tiles
   const long long v = (long long)blockIdx.x * 256 + threadIdx.x;  // destination vector index
-  const long long total = (long long)((N + 15) / 16) * S * 64;
+  const long long total = (long long)((N + TR - 1) / TR) * S * LT;
   if (v >= total) return;
-  const int l = (int)(v & 63);
-  const long long ts = v >> 6;
+  const int l = (int)(v % LT);
+  const long long ts = v / LT;
   const int s = (int)(ts % S);
   const int t = (int)(ts / S);
-  const int n = t * 16 + (l & 15), kv = s * 4 + (l >> 4);
+  const int n = t * TR + (l % TR), kv = s * 4 + (l / TR);
   u32x4_t val = u32x4_t{0u, 0u, 0u, 0u};
   if (n < N) val = *reinterpret_cast<const u32x4_t*>(src + (long long)n * K + (long long)kv * E);
   *reinterpret_cast<u32x4_t*>(dst + v * E) = val;
@@ -916,12 +934,26 @@ static int env_int(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-template <typename T, int NW, int SK_MAXS, bool MULTI, bool W8, int CG>
+template <typename T, int NW, int SK_MAXS, bool MULTI, bool W8, int CG, int TR>
 static hipError_t skinny_launch_cg(const GemvArgs& a, dim3 grid, size_t lds1, hipStream_t st) {
   const bool ln = a.ln_gw != nullptr;
   const size_t lds = lds1 * CG;
-#define SK_GO(LNV, EPIV) hipLaunchKernelGGL((skinny_mfma_kernel<T, NW, SK_MAXS, LNV, EPIV, MULTI, W8, CG>), grid, dim3(NW * 64), lds, st, a)
-  if constexpr (NW >= 16) {  // 16 wavefronts per tile only for the long-K residual projections (fc2)
+#define SK_GO(LNV, EPIV) hipLaunchKernelGGL((skinny_mfma_kernel<T, NW, SK_MAXS, LNV, EPIV, MULTI, W8, CG, TR>), grid, dim3(NW * 64), lds, st, a)
+  if constexpr (TR != 16) {  // narrow tiles: plain / residual / GELU projections, one tile per workgroup
+    if (a.y_f32 || a.kcache) return hipErrorInvalidValue;
+    if constexpr (MULTI || W8) {
+      return hipErrorInvalidValue;
+    } else if constexpr (NW >= 16) {
+      if (ln || a.gelu) return hipErrorInvalidValue;
+      if (a.res) SK_GO(false, SK_RES);
+      else SK_GO(false, SK_STORE);
+    } else {
+      if (a.gelu) { if (!ln || a.res) return hipErrorInvalidValue; SK_GO(true, SK_GELU); }
+      else if (a.res) { if (ln) return hipErrorInvalidValue; SK_GO(false, SK_RES); }
+      else if (ln) SK_GO(true, SK_STORE);
+      else SK_GO(false, SK_STORE);
+    }
+  } else if constexpr (NW >= 16) {  // 16 wavefronts per tile only for the long-K residual projections (fc2)
     if (ln || a.y_f32 || a.kcache || a.gelu) return hipErrorInvalidValue;
     if (a.res) SK_GO(false, SK_RES);
     else SK_GO(false, SK_STORE);
@@ -946,26 +978,26 @@ static hipError_t skinny_launch_cg(const GemvArgs& a, dim3 grid, size_t lds1, hi
   return hipGetLastError();
 }
 
-template <typename T, int NW, int SK_MAXS, bool MULTI, bool W8>
+template <typename T, int NW, int SK_MAXS, bool MULTI, bool W8, int TR>
 static hipError_t skinny_launch_v(const GemvArgs& a, dim3 grid, size_t lds1, hipStream_t st) {
-  if (a.B <= 16) return skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 1>(a, grid, lds1, st);
+  if (a.B <= 16) return skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 1, TR>(a, grid, lds1, st);
   // several groups of 16 streams: 8 wavefronts x 5 fragments in flight (more rounds for long K) keeps the per-group
   // activation fragments inside the register file; MXFP8 contexts are limited to one group
   if constexpr (W8 || NW != 8 || SK_MAXS != 5) {
     return hipErrorInvalidValue;
   } else {
-    if (a.B <= 32) return skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 2>(a, grid, lds1, st);
-    return skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 4>(a, grid, lds1, st);
+    if (a.B <= 32) return skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 2, TR>(a, grid, lds1, st);
+    return skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 4, TR>(a, grid, lds1, st);
   }
 }
 
-template <typename T, int NW>
+template <typename T, int NW, int TR>
 static hipError_t skinny_launch_nw(const GemvArgs& a0, hipStream_t st) {
   constexpr int E = ElemTraits<T>::kPer16B;
   GemvArgs a = a0;
   if (a.K % (4 * E) != 0 || a.B > 64) return hipErrorInvalidValue;
   const size_t lds = (size_t)NW * 256 * 4;
-  const int tiles = (a.N + 15) / 16;
+  const int tiles = (a.N + TR - 1) / TR;
   // at most `max_blocks` workgroups: tall matrices (the tied logits projection) walk several tiles per workgroup
   static const int max_blocks = env_int("TW_SK_MAX_BLOCKS", 512);
   const int steps_per_wave = (a.K / E / 4 + NW - 1) / NW;
@@ -973,12 +1005,18 @@ static hipError_t skinny_launch_nw(const GemvArgs& a0, hipStream_t st) {
   a.rg = (tiles + max_blocks - 1) / max_blocks;
   if (a.rg < 1 || steps_per_wave > (groups ? 5 : 10)) a.rg = 1;  // several tiles per workgroup only with one round per tile
   dim3 grid((tiles + a.rg - 1) / a.rg);
-  if (a.rg > 1) {
-    if (steps_per_wave <= 5 || groups) return skinny_launch_v<T, NW, 5, true, false>(a, grid, lds, st);
-    return skinny_launch_v<T, NW, 10, true, false>(a, grid, lds, st);
+  if constexpr (TR != 16) {
+    if (a.rg > 1) return hipErrorInvalidValue;
+    if (steps_per_wave <= 5 || groups) return skinny_launch_v<T, NW, 5, false, false, TR>(a, grid, lds, st);
+    return skinny_launch_v<T, NW, 10, false, false, TR>(a, grid, lds, st);
+  } else {
+    if (a.rg > 1) {
+      if (steps_per_wave <= 5 || groups) return skinny_launch_v<T, NW, 5, true, false, 16>(a, grid, lds, st);
+      return skinny_launch_v<T, NW, 10, true, false, 16>(a, grid, lds, st);
+    }
+    if (steps_per_wave <= 5 || groups) return skinny_launch_v<T, NW, 5, false, false, 16>(a, grid, lds, st);
+    return skinny_launch_v<T, NW, 10, false, false, 16>(a, grid, lds, st);
   }
-  if (steps_per_wave <= 5 || groups) return skinny_launch_v<T, NW, 5, false, false>(a, grid, lds, st);
-  return skinny_launch_v<T, NW, 10, false, false>(a, grid, lds, st);
 }
 
 // MXFP8 weights: 128-k steps; 2 steps per wavefront cover K = 1280 with 8 wavefronts, 3 cover K = 5120 with 16
@@ -994,11 +1032,11 @@ static hipError_t skinny_launch_w8(const GemvArgs& a0, hipStream_t st) {
   if (a.rg < 1 || steps_per_wave > 3) a.rg = 1;
   dim3 grid((tiles + a.rg - 1) / a.rg);
   if (a.rg > 1) {
-    if (steps_per_wave <= 2) return skinny_launch_v<bf16_t, NW, 2, true, true>(a, grid, lds, st);
-    return skinny_launch_v<bf16_t, NW, 3, true, true>(a, grid, lds, st);
+    if (steps_per_wave <= 2) return skinny_launch_v<bf16_t, NW, 2, true, true, 16>(a, grid, lds, st);
+    return skinny_launch_v<bf16_t, NW, 3, true, true, 16>(a, grid, lds, st);
   }
-  if (steps_per_wave <= 2) return skinny_launch_v<bf16_t, NW, 2, false, true>(a, grid, lds, st);
-  return skinny_launch_v<bf16_t, NW, 3, false, true>(a, grid, lds, st);
+  if (steps_per_wave <= 2) return skinny_launch_v<bf16_t, NW, 2, false, true, 16>(a, grid, lds, st);
+  return skinny_launch_v<bf16_t, NW, 3, false, true, 16>(a, grid, lds, st);
 }
 
 template <typename T>
@@ -1009,7 +1047,10 @@ static hipError_t skinny_launch(const GemvArgs& a, hipStream_t st) {
     if (sizeof(T) != 2) return hipErrorInvalidValue;
     return big ? skinny_launch_w8<16>(a, st) : skinny_launch_w8<8>(a, st);
   }
-  return big ? skinny_launch_nw<T, 16>(a, st) : skinny_launch_nw<T, 8>(a, st);
+  if (a.tr == 8) return big ? skinny_launch_nw<T, 16, 8>(a, st) : skinny_launch_nw<T, 8, 8>(a, st);
+  if (a.tr == 4) return big ? skinny_launch_nw<T, 16, 4>(a, st) : skinny_launch_nw<T, 8, 4>(a, st);
+  if (a.tr != 0 && a.tr != 16) return hipErrorInvalidValue;
+  return big ? skinny_launch_nw<T, 16, 16>(a, st) : skinny_launch_nw<T, 8, 16>(a, st);
 }
 
 template <typename T>
@@ -1071,13 +1112,13 @@ hipError_t launch_advance(DecState* stt, hipStream_t st) {
   return hipGetLastError();
 }
 
-hipError_t launch_tile_weights(int dtype, const void* src, void* dst, int N, int K, hipStream_t st) {
+hipError_t launch_tile_weights(int dtype, const void* src, void* dst, int N, int K, int tr, hipStream_t st) {
   const int E = dtype == 1 ? 8 : 4;
-  if (K % (4 * E) != 0) return hipErrorInvalidValue;
-  const long long total = (long long)((N + 15) / 16) * (K / E / 4) * 64;
+  if (K % (4 * E) != 0 || (tr != 16 && tr != 8 && tr != 4) || N % tr != 0 && tr != 16) return hipErrorInvalidValue;
+  const long long total = (long long)((N + tr - 1) / tr) * (K / E / 4) * 4 * tr;
   dim3 grid((unsigned)((total + 255) / 256));
-  if (dtype == 1) hipLaunchKernelGGL(tile_weights_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, N, K);
-  else hipLaunchKernelGGL(tile_weights_kernel<float>, grid, dim3(256), 0, st, (const float*)src, (float*)dst, N, K);
+  if (dtype == 1) hipLaunchKernelGGL(tile_weights_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, N, K, tr);
+  else hipLaunchKernelGGL(tile_weights_kernel<float>, grid, dim3(256), 0, st, (const float*)src, (float*)dst, N, K, tr);
   return hipGetLastError();
 }
 

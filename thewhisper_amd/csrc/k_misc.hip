@@ -159,6 +159,7 @@ __global__ void embed_kernel(const int* __restrict__ ids, const DecState* __rest
     x[(long long)(b >> 4) * 16 * d + tw_xt_index<T>(b & 15, i)] = (T)((float)tok[(long long)id * d + i] + (float)pos[(long long)p * d + i]);
 }
 
+
 }  // namespace
 
 hipError_t launch_layernorm(int dtype, const void* x, const void* g, const void* b, void* y, int rows, int d,

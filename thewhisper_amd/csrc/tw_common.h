@@ -165,11 +165,12 @@ struct GemvArgs {
   // (fragment-major per (stream, head): tw_kf_index / tw_vtf_index; cache_bstride = elements per stream = H * rows * 64)
   void* kcache; void* vcache; long long cache_bstride; int d_model; const DecState* stt;
   int rg;  // skinny path: 16-row tiles walked per workgroup (set by the launcher)
+  int tr;  // weight rows per workgroup tile the weights were laid out for by launch_tile_weights (0 / 16, 8 or 4)
 };
 hipError_t launch_gemv(int dtype, const GemvArgs& a, hipStream_t st);
 hipError_t init_decode_kernels();
 // row-major [N][K] -> the fragment-major layout launch_gemv reads (k_decode.hip); dst holds ceil(N/16)*16 rows
-hipError_t launch_tile_weights(int dtype, const void* src, void* dst, int N, int K, hipStream_t st);
+hipError_t launch_tile_weights(int dtype, const void* src, void* dst, int N, int K, int tr, hipStream_t st);
 // row-major bf16 [N][K] -> MXFP8 fragments (ceil(N/16)*16*K bytes) + block scales (ceil(N/16)*16*K/32 bytes); K % 128 == 0
 hipError_t launch_quant_mx8(const void* src_bf16, void* dst_fp8, void* dst_scales, int N, int K, hipStream_t st);
 // weight preparation for the folded pre-LayerNorm: W <- Wsrc * g (may alias), gw, cb as above

@@ -65,6 +65,15 @@ class Replicas:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return int(t.item())
 
+    def gather_floats(self, x: float) -> List[float]:
+        """One float per rank, in rank order, on every rank (per-rank throughput for the benchmark line)."""
+        if self.dist is None:
+            return [float(x)]
+        t = torch.tensor([x], dtype=torch.float64, device=self._coll_device)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
+
     def gather_tokens(self, stream_ids: Sequence[int], tokens: np.ndarray, n_streams: int) -> Optional[Dict[int, np.ndarray]]:
         """Optional result gather: every rank contributes a fixed-shape int32 [cap, 1 + L] buffer (stream id + tokens);
         rank 0 returns {stream_id: tokens}.  One all_gather; never on the per-token path."""

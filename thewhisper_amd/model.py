@@ -204,6 +204,14 @@ class AMDWhisperForConditionalGeneration(WhisperForConditionalGeneration, _Engin
                 p.data = torch.empty(0, dtype=p.dtype, device=p.device)
         return eng
 
+    def attach_engine(self, engine):
+        """Run on an engine whose weights were loaded elsewhere (weights generated on the device, or one context shared by
+        several pipelines); the torch modules of this object are then only the container HF's generate() needs."""
+        self._engine = engine
+        self._engine_T = int(engine.T)
+        self.config.max_source_positions = int(engine.T)
+        return engine
+
     def _require_engine(self):
         if self._engine is None:
             raise RuntimeError("AMDWhisperForConditionalGeneration has no engine: call build_engine() "
