@@ -18,7 +18,8 @@
  *    stream; all other calls only enqueue work on `stream` (a hipStream_t passed as void*; pass
  *    torch's current stream so ordering with torch ops is automatic; NULL = default stream).
  *  - A context is bound to one device, owns its workspace / KV arenas (allocated in tw_create, freed
- *    in tw_destroy) and is NOT thread-safe: one context per (GPU, worker thread).
+ *    in tw_destroy) and is NOT thread-safe: one context per (GPU, worker thread).  Every call makes the
+ *    context's device current for its duration and restores the calling thread's device on return.
  *  - Batch entries ("streams") of one call occupy slots 0..B-1 of the context, B <= max_batch.
  */
 #ifndef THEWHISPER_H
@@ -161,6 +162,18 @@ int tw_get_alignment(tw_ctx* ctx, int32_t B, int32_t n_rows, float* out_host, vo
  * of each kind: [0]=logmel [1]=encode [2]=cross_kv [3]=greedy loop [4]=token_timestamps; also the
  * number of decode steps of the last greedy call in steps_out.  Used by bench.py for the roofline. */
 int tw_last_timings(tw_ctx* ctx, float* ms_out5, int32_t* steps_out);
+
+/* Host-side schedule helpers (no reference counterpart: the reference processes one request at a time,
+ * R:examples/server.py:22-115).  Streams and events created by the SAME HIP runtime the library and torch use, for the
+ * encoder / decoder stage overlap (thewhisper_amd/overlap.py): a stream whose kernels may only run on the compute units
+ * set in `cu_mask` (n_words x 32 bits), plain events, record / wait.  Handles are hipStream_t / hipEvent_t as void*. */
+int tw_stream_create_masked(int32_t device, const uint32_t* cu_mask, int32_t n_words, void** out_stream);
+int tw_stream_destroy(void* stream);
+int tw_stream_synchronize(void* stream);
+int tw_event_create(int32_t device, void** out_event);
+int tw_event_destroy(void* event);
+int tw_event_record(void* event, void* stream);
+int tw_stream_wait_event(void* stream, void* event);
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,8 @@ from thewhisper_amd import overlap as ov
 
 
 class _FakeHip:
+    """Stands in for overlap._Hip (the tw_stream_* / tw_event_* entry points of the library)."""
+
     def __init__(self):
         self.events, self.calls = {}, []
         self._n = 100
@@ -20,34 +22,27 @@ class _FakeHip:
         self._n += 1
         return self._n
 
-    def hipSetDevice(self, i):
-        return 0
+    def stream_create_masked(self, device, mask):
+        self.calls.append(("stream", len(mask), [int(m) for m in mask]))
+        return self._new()
 
-    def hipExtStreamCreateWithCUMask(self, ref, words, mask):
-        ref._obj.value = self._new()
-        self.calls.append(("stream", words, [int(m) for m in mask]))
-        return 0
+    def event_create(self, device):
+        return self._new()
 
-    def hipEventCreateWithFlags(self, ref, flags):
-        ref._obj.value = self._new()
-        return 0
-
-    def hipEventRecord(self, ev, st):
+    def event_record(self, ev, st):
         self.calls.append(("record", ev, st))
-        return 0
 
-    def hipStreamWaitEvent(self, st, ev, flags):
+    def stream_wait_event(self, st, ev):
         self.calls.append(("wait", st, ev))
-        return 0
 
-    def hipStreamSynchronize(self, st):
-        return 0
+    def stream_synchronize(self, st):
+        pass
 
-    def hipEventDestroy(self, ev):
-        return 0
+    def event_destroy(self, ev):
+        pass
 
-    def hipStreamDestroy(self, st):
-        return 0
+    def stream_destroy(self, st):
+        pass
 
 
 class _FakeEngine:

@@ -140,6 +140,23 @@ int dalloc(tw_ctx* c, P** p, size_t bytes, bool zero) {
 
 inline hipStream_t pick_stream(tw_ctx* c, void* s) { return s ? reinterpret_cast<hipStream_t>(s) : c->own_stream; }
 
+// Every entry point runs with the context's device current and restores the caller's device on exit: worker threads
+// (BatchingHub, the gateway's thread pool, the reference scheduler's thread) start on device 0, and kernel launches,
+// memcpys and hipMalloc go to the calling thread's CURRENT device, not to the device a stream belongs to.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define TW_ON_DEVICE(c) DeviceGuard _tw_guard((c)->cfg.device)
+
 char* at(void* base, size_t elems, size_t esz) { return reinterpret_cast<char*>(base) + elems * esz; }
 
 // slaney mel bank, float64 (HF:audio_utils.py:638-729), then cast to float32 as the reference does
@@ -190,6 +207,7 @@ const char* tw_last_error(const tw_ctx* ctx) { return ctx ? ctx->err.c_str() : g
 
 int tw_destroy(tw_ctx* c) {
   if (!c) return TW_OK;
+  TW_ON_DEVICE(c);
   (void)hipDeviceSynchronize();
   if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
   for (void* p : c->allocs) (void)hipFree(p);
@@ -226,7 +244,9 @@ int tw_create(const tw_config* cfg, tw_ctx** out) {
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, TW_EHIP, "no HIP device available (the MI355X path has no CPU fallback)");
   if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, TW_EINVAL, "device %d out of range", cfg->device);
-  if (hipSetDevice(cfg->device) != hipSuccess) return fail(nullptr, TW_EHIP, "hipSetDevice failed");
+  DeviceGuard guard(cfg->device);   // allocations below land on the context's device; the caller's device is restored on return
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != cfg->device) return fail(nullptr, TW_EHIP, "hipSetDevice(%d) failed", cfg->device);
 
   tw_ctx* c = new tw_ctx();
   c->cfg = *cfg;
@@ -370,6 +390,7 @@ int tw_load_weight(tw_ctx* c, const char* name_c, const void* src, int32_t sdt, 
                    void* stream) {
   if (!c || !name_c || !src || !shape) return fail(c, TW_EINVAL, "tw_load_weight: null argument");
   if (sdt != TW_F32 && sdt != TW_BF16 && sdt != TW_F16) return fail(c, TW_EINVAL, "unsupported source dtype %d", sdt);
+  TW_ON_DEVICE(c);
   hipStream_t st = pick_stream(c, stream);
   const std::string name(name_c);
   const int d = c->d, F = c->ffn;
@@ -469,6 +490,7 @@ int tw_load_weight(tw_ctx* c, const char* name_c, const void* src, int32_t sdt, 
 
 int tw_finalize_weights(tw_ctx* c, void* stream) {
   if (!c) return TW_EINVAL;
+  TW_ON_DEVICE(c);
   hipStream_t st = pick_stream(c, stream);
   const size_t expect = 4 + 1 + 2 + (size_t)c->Le * 15 + 2 + 2 + (size_t)c->Ld * 24;
   if (c->loaded.size() != expect) {
@@ -544,6 +566,7 @@ int tw_finalize_weights(tw_ctx* c, void* stream) {
 int tw_logmel(tw_ctx* c, const float* pcm, int64_t pcm_stride, const int32_t* n_valid_host, int32_t B, int32_t n_samples,
               void* out, int32_t out_dtype, void* stream) {
   if (!c || !pcm || !out) return fail(c, TW_EINVAL, "tw_logmel: null argument");
+  TW_ON_DEVICE(c);
   if (B < 1 || B > c->Bmax) return fail(c, TW_EINVAL, "tw_logmel: B=%d outside [1,%d]", B, c->Bmax);
   if (n_samples < 400 || n_samples % 160 != 0) return fail(c, TW_EINVAL, "n_samples must be a multiple of 160 and >= 400");
   if ((size_t)B * c->n_mels * (n_samples / 160) > c->logspec_cap)
@@ -568,6 +591,7 @@ int tw_logmel(tw_ctx* c, const float* pcm, int64_t pcm_stride, const int32_t* n_
 // ---------------------------------------------------------------------------------------------
 int tw_encode(tw_ctx* c, const void* mel, int32_t mel_dtype, int32_t B, void* out_hidden, int32_t out_dtype, void* stream) {
   if (!c || !mel) return fail(c, TW_EINVAL, "tw_encode: null argument");
+  TW_ON_DEVICE(c);
   if (!c->finalized) return fail(c, TW_ESTATE, "tw_encode before tw_finalize_weights");
   if (B < 1 || B > c->Bmax) return fail(c, TW_EINVAL, "tw_encode: B=%d outside [1,%d]", B, c->Bmax);
   hipStream_t st = pick_stream(c, stream);
@@ -630,6 +654,7 @@ int tw_encode(tw_ctx* c, const void* mel, int32_t mel_dtype, int32_t B, void* ou
 
 int tw_cross_kv(tw_ctx* c, int32_t B, void* stream) {
   if (!c) return TW_EINVAL;
+  TW_ON_DEVICE(c);
   if (B < 1 || B > c->encoded_B) return fail(c, TW_ESTATE, "tw_cross_kv: B=%d but %d clips encoded", B, c->encoded_B);
   hipStream_t st = pick_stream(c, stream);
   const int d = c->d, T = c->T;
@@ -733,6 +758,7 @@ extern "C" {
 
 int tw_decoder_reset(tw_ctx* c, int32_t B, void* stream) {
   if (!c) return TW_EINVAL;
+  TW_ON_DEVICE(c);
   if (B < 1 || B > c->cross_B) return fail(c, TW_ESTATE, "tw_decoder_reset: B=%d but cross K/V holds %d clips", B, c->cross_B);
   hipStream_t st = pick_stream(c, stream);
   int r = reset_state(c, 0, st);
@@ -744,6 +770,7 @@ int tw_decoder_reset(tw_ctx* c, int32_t B, void* stream) {
 
 int tw_decode_step(tw_ctx* c, int32_t B, const int32_t* ids_host, float* logits_dev, void* stream) {
   if (!c || !ids_host) return fail(c, TW_EINVAL, "tw_decode_step: null argument");
+  TW_ON_DEVICE(c);
   if (B < 1 || B > c->cross_B) return fail(c, TW_ESTATE, "tw_decode_step: B=%d but cross K/V holds %d clips", B, c->cross_B);
   hipStream_t st = pick_stream(c, stream);
   HIPCHK(c, hipMemcpyAsync(c->cur_ids, ids_host, sizeof(int) * B, hipMemcpyHostToDevice, st));
@@ -758,6 +785,7 @@ int tw_decode_step(tw_ctx* c, int32_t B, const int32_t* ids_host, float* logits_
 int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_prompt, const tw_greedy_opts* o,
                        int32_t* out_ids, int32_t* out_len, void* stream) {
   if (!c || !prompt || !o || !out_ids || !out_len) return fail(c, TW_EINVAL, "tw_generate_greedy: null argument");
+  TW_ON_DEVICE(c);
   if (B < 1 || B > c->cross_B) return fail(c, TW_ESTATE, "tw_generate_greedy: B=%d but cross K/V holds %d clips", B, c->cross_B);
   if (n_prompt < 1 || n_prompt >= c->P) return fail(c, TW_EINVAL, "bad n_prompt %d", n_prompt);
   if (o->n_begin_suppress > 64 || o->n_suppress > 1024) return fail(c, TW_EINVAL, "suppress lists too long");
@@ -884,6 +912,7 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
 
 int tw_get_alignment(tw_ctx* c, int32_t B, int32_t n_rows, float* out_host, void* stream) {
   if (!c || !out_host) return TW_EINVAL;
+  TW_ON_DEVICE(c);
   if (c->Ha == 0) return fail(c, TW_EINVAL, "context has no alignment heads");
   if (B < 1 || B > c->Bmax || n_rows < 1 || n_rows > c->P) return fail(c, TW_EINVAL, "bad B/n_rows");
   hipStream_t st = pick_stream(c, stream);
@@ -899,6 +928,7 @@ int tw_get_alignment(tw_ctx* c, int32_t B, int32_t n_rows, float* out_host, void
 int tw_token_timestamps(tw_ctx* c, int32_t B, int32_t n_prompt, int32_t seq_len, const int32_t* num_frames_host,
                         double time_precision, float* out_ts_host, void* stream) {
   if (!c || !out_ts_host) return fail(c, TW_EINVAL, "tw_token_timestamps: null argument");
+  TW_ON_DEVICE(c);
   if (c->Ha == 0) return fail(c, TW_EINVAL, "context has no alignment heads");
   if (B < 1 || B > c->Bmax || seq_len < 2 || seq_len > c->P || n_prompt < 1 || n_prompt >= seq_len)
     return fail(c, TW_EINVAL, "bad B/n_prompt/seq_len (%d,%d,%d)", B, n_prompt, seq_len);
@@ -934,6 +964,7 @@ int tw_token_timestamps(tw_ctx* c, int32_t B, int32_t n_prompt, int32_t seq_len,
 
 int tw_last_timings(tw_ctx* c, float* ms_out5, int32_t* steps_out) {
   if (!c || !ms_out5) return TW_EINVAL;
+  TW_ON_DEVICE(c);
   for (int i = 0; i < 5; ++i) {
     ms_out5[i] = -1.f;
     if (c->ev_valid[i]) {
@@ -944,6 +975,56 @@ int tw_last_timings(tw_ctx* c, float* ms_out5, int32_t* steps_out) {
   }
   if (steps_out) *steps_out = c->last_steps;
   return TW_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// HIP streams / events owned by THIS library's runtime (the one torch mapped): used by the host-side stage overlap
+// (thewhisper_amd/overlap.py) so that no second copy of libamdhip64 is ever dlopen'ed by name.
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int tw_stream_create_masked(int32_t device, const uint32_t* cu_mask, int32_t n_words, void** out_stream) {
+  if (!cu_mask || n_words < 1 || !out_stream) return TW_EINVAL;
+  DeviceGuard guard(device);
+  hipStream_t st = nullptr;
+  hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, cu_mask);
+  if (e != hipSuccess) { g_create_error = std::string("hipExtStreamCreateWithCUMask: ") + hipGetErrorString(e); return TW_EHIP; }
+  *out_stream = st;
+  return TW_OK;
+}
+
+int tw_stream_destroy(void* stream) {
+  if (!stream) return TW_OK;
+  (void)hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream));
+  return hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)) == hipSuccess ? TW_OK : TW_EHIP;
+}
+
+int tw_stream_synchronize(void* stream) {
+  return hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)) == hipSuccess ? TW_OK : TW_EHIP;
+}
+
+int tw_event_create(int32_t device, void** out_event) {
+  if (!out_event) return TW_EINVAL;
+  DeviceGuard guard(device);
+  hipEvent_t ev = nullptr;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return TW_EHIP;
+  *out_event = ev;
+  return TW_OK;
+}
+
+int tw_event_destroy(void* event) {
+  if (!event) return TW_OK;
+  return hipEventDestroy(reinterpret_cast<hipEvent_t>(event)) == hipSuccess ? TW_OK : TW_EHIP;
+}
+
+int tw_event_record(void* event, void* stream) {
+  return hipEventRecord(reinterpret_cast<hipEvent_t>(event), reinterpret_cast<hipStream_t>(stream)) == hipSuccess ? TW_OK : TW_EHIP;
+}
+
+int tw_stream_wait_event(void* stream, void* event) {
+  return hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), reinterpret_cast<hipEvent_t>(event), 0) == hipSuccess ? TW_OK : TW_EHIP;
 }
 
 }  // extern "C"

@@ -35,6 +35,31 @@ class WhisperEngine:
             return C.c_void_p(self.raw_stream)
         return _stream_ptr(self.device)
 
+    def _adopt(self, *tensors) -> None:
+        """With ``raw_stream`` set the work runs on a stream torch's caching allocator knows nothing about: order that
+        stream after torch's current stream (which produced the inputs: H2D copies, slicing, casts) and register every tensor
+        handed to the library with it, so that a temporary dropped on return is not recycled while the launches still read
+        or write it."""
+        if self.raw_stream is None:
+            return
+        ext = torch.cuda.ExternalStream(self.raw_stream, device=self.device)
+        ext.wait_stream(torch.cuda.current_stream(self.device))
+        for t in tensors:
+            if t is not None and t.is_cuda:
+                t.record_stream(ext)
+
+    def _publish(self) -> None:
+        """Counterpart of ``_adopt`` for tensors RETURNED to the caller: torch's current stream waits for the foreign stream,
+        so that the caller may consume the result with ordinary torch ops."""
+        if self.raw_stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(torch.cuda.ExternalStream(self.raw_stream, device=self.device))
+
+    def _sync_used_stream(self) -> None:
+        if self.raw_stream is not None:
+            torch.cuda.ExternalStream(self.raw_stream, device=self.device).synchronize()
+        else:
+            torch.cuda.current_stream(self.device).synchronize()
+
 
     def __init__(
         self,
@@ -111,10 +136,11 @@ class WhisperEngine:
         if t.dtype not in _TORCH2TW:
             t = t.float()
         shape = (C.c_int64 * t.dim())(*t.shape)
+        self._adopt(t)
         rc = self.lib.tw_load_weight(self.ctx, name.encode(), C.c_void_p(t.data_ptr()), _TORCH2TW[t.dtype], t.dim(), shape,
                                      self._sp())
         self._chk(rc, f"tw_load_weight({name})")
-        torch.cuda.current_stream(self.device).synchronize()  # `t` may be a temporary
+        self._sync_used_stream()  # `t` may be a temporary
 
     def finalize(self):
         self._chk(self.lib.tw_finalize_weights(self.ctx, self._sp()), "tw_finalize_weights")
@@ -149,9 +175,11 @@ class WhisperEngine:
             nv = (C.c_int32 * B)(*[int(min(v, n)) for v in n_valid])
         out_dtype = out_dtype or self.torch_dtype
         out = torch.empty((B, self.n_mels, n_samples // 160), dtype=out_dtype, device=self.device)
+        self._adopt(pcm, out)
         rc = self.lib.tw_logmel(self.ctx, C.c_void_p(pcm.data_ptr()), pcm.stride(0), nv, B, n_samples,
                                 C.c_void_p(out.data_ptr()), _TORCH2TW[out_dtype], self._sp())
         self._chk(rc, "tw_logmel")
+        self._publish()
         return out
 
     # ---- A2-A5 -------------------------------------------------------------------------------
@@ -168,10 +196,13 @@ class WhisperEngine:
         out = None
         if return_hidden:
             out = torch.empty((B, self.T, self.d_model), dtype=hidden_dtype, device=self.device)
+        self._adopt(mel, out)
         rc = self.lib.tw_encode(self.ctx, C.c_void_p(mel.data_ptr()), _TORCH2TW[mel.dtype], B,
                                 C.c_void_p(out.data_ptr()) if out is not None else None,
                                 _TORCH2TW[hidden_dtype], self._sp())
         self._chk(rc, "tw_encode")
+        if out is not None:
+            self._publish()
         return out
 
     def cross_kv(self, B: int):
@@ -185,9 +216,12 @@ class WhisperEngine:
         B = len(ids)
         arr = (C.c_int32 * B)(*[int(i) for i in ids])
         out = torch.empty((B, self.vocab), dtype=torch.float32, device=self.device) if want_logits else None
+        self._adopt(out)
         rc = self.lib.tw_decode_step(self.ctx, B, arr, C.c_void_p(out.data_ptr()) if out is not None else None,
                                      self._sp())
         self._chk(rc, "tw_decode_step")
+        if out is not None:
+            self._publish()
         return out
 
     # ---- A9/A10 ------------------------------------------------------------------------------

@@ -11,6 +11,7 @@ encoder/decoder pass through ``BatchingHub``.
 
 Host-side Python only; the hot path stays behind ``AMDWhisperBackend``.  ``python -m thewhisper_amd.gateway --model ...``
 """
+import hmac
 import io
 import wave
 from typing import Any, Dict, List, Optional, Tuple, Union
@@ -94,7 +95,7 @@ def create_app(backend: Union[BatchingHub, AMDWhisperBackend], auth_token: str =
     @app.post(path)
     async def post_transcribe(request: Request, authorization: Optional[str] = Header(default=None),
                               x_lang_id: Optional[str] = Header(default=None), x_model_name: Optional[str] = Header(default=None)):
-        if auth_token and authorization != f"Bearer {auth_token}":
+        if auth_token and not hmac.compare_digest((authorization or "").encode(), f"Bearer {auth_token}".encode()):
             raise HTTPException(status_code=401, detail="invalid or missing bearer token")
         if lang_id and x_lang_id and x_lang_id != lang_id:
             raise HTTPException(status_code=400, detail=f"this gateway serves language '{lang_id}'")

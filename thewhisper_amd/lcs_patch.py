@@ -13,6 +13,7 @@ reference package (``thestage_speechkit`` already imported) its own patch is lef
 from __future__ import annotations
 
 import inspect
+import logging
 import re
 import sys
 import textwrap
@@ -51,13 +52,25 @@ def install() -> bool:
         return False
     if getattr(_tw._find_longest_common_sequence, "_thewhisper_patched", False):
         return False
-    fn = _build_patched()
+    try:
+        fn = _build_patched()
+    except Exception:  # noqa: BLE001 - source unavailable (frozen build) or not compilable
+        fn = None
     if fn is None:
-        raise RuntimeError("transformers' _find_longest_common_sequence changed shape; thewhisper_amd.lcs_patch "
-                           "must be updated (tested against transformers 5.15.0)")
+        # An untested transformers layout: keep HF's own function rather than failing the import.  Only the corner the
+        # reference patches is affected (merging strided chunks with WORD timestamps when a left token's end timestamp is
+        # None raises TypeError inside HF); everything else behaves as upstream.  Tested range: transformers 5.15.x.
+        STATUS["installed"] = False
+        logging.getLogger(__name__).warning(
+            "thewhisper_amd.lcs_patch: transformers %s has a different _find_longest_common_sequence; the reference's "
+            "chunk-merge fix (R:thestage_speechkit/__init__.py:75-94) was NOT applied (tested with transformers 5.15.x)",
+            getattr(sys.modules.get("transformers"), "__version__", "?"))
+        return False
     fn._thewhisper_patched = True
     _tw._find_longest_common_sequence = fn
+    STATUS["installed"] = True
     return True
 
 
+STATUS = {"installed": None}   # True: our re-compiled function is active; False: HF layout not recognised (warning logged)
 install()

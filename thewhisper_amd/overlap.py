@@ -28,39 +28,64 @@ from .engine import WhisperEngine
 
 __all__ = ["EncoderOverlap", "masked_stream"]
 
+class _Hip:
+    """Streams and events through libthewhisper's own entry points (tw_stream_* / tw_event_*): one HIP runtime - the one torch
+    mapped and the library is linked against - owns every handle.  (dlopen("libamdhip64.so") by bare name could map a second
+    runtime whose handles mean nothing to the first.)"""
+
+    def __init__(self):
+        from . import _cabi
+
+        self.lib = _cabi.load_library()
+
+    def stream_create_masked(self, device: int, mask) -> int:
+        st = C.c_void_p()
+        _chk(self.lib.tw_stream_create_masked(device, mask, len(mask), C.byref(st)), "tw_stream_create_masked")
+        return int(st.value)
+
+    def event_create(self, device: int) -> int:
+        ev = C.c_void_p()
+        _chk(self.lib.tw_event_create(device, C.byref(ev)), "tw_event_create")
+        return int(ev.value)
+
+    def event_record(self, ev: int, st: int):
+        _chk(self.lib.tw_event_record(C.c_void_p(ev), C.c_void_p(st)), "tw_event_record")
+
+    def stream_wait_event(self, st: int, ev: int):
+        _chk(self.lib.tw_stream_wait_event(C.c_void_p(st), C.c_void_p(ev)), "tw_stream_wait_event")
+
+    def stream_synchronize(self, st: int):
+        _chk(self.lib.tw_stream_synchronize(C.c_void_p(st)), "tw_stream_synchronize")
+
+    def stream_destroy(self, st: int):
+        self.lib.tw_stream_destroy(C.c_void_p(st))
+
+    def event_destroy(self, ev: int):
+        self.lib.tw_event_destroy(C.c_void_p(ev))
+
+
 _hip = None
 
 
 def _hiplib():
     global _hip
     if _hip is None:
-        lib = C.CDLL("libamdhip64.so")
-        lib.hipExtStreamCreateWithCUMask.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]
-        lib.hipStreamDestroy.argtypes = [C.c_void_p]
-        lib.hipStreamSynchronize.argtypes = [C.c_void_p]
-        lib.hipEventCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
-        lib.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
-        lib.hipStreamWaitEvent.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
-        lib.hipEventDestroy.argtypes = [C.c_void_p]
-        lib.hipSetDevice.argtypes = [C.c_int]
-        _hip = lib
+        _hip = _Hip()
     return _hip
 
 
 def _chk(rc: int, what: str):
     if rc != 0:
-        raise RuntimeError(f"{what} failed with hipError {rc}")
+        raise RuntimeError(f"{what} failed ({rc})")
 
 
-def masked_stream(first_cu: int, last_cu: int, n_cus: int) -> int:
-    """A HIP stream whose kernels may only run on compute units [first_cu, last_cu) of the current device."""
+def masked_stream(first_cu: int, last_cu: int, n_cus: int, device: int = 0) -> int:
+    """A HIP stream whose kernels may only run on compute units [first_cu, last_cu) of `device`."""
     words = (n_cus + 31) // 32
     mask = (C.c_uint32 * words)(*([0] * words))
     for i in range(first_cu, last_cu):
         mask[i // 32] |= 1 << (i % 32)
-    st = C.c_void_p()
-    _chk(_hiplib().hipExtStreamCreateWithCUMask(C.byref(st), words, mask), "hipExtStreamCreateWithCUMask")
-    return int(st.value)
+    return _hiplib().stream_create_masked(device, mask)
 
 
 class EncoderOverlap:
@@ -80,24 +105,20 @@ class EncoderOverlap:
             raise ValueError(f"bad CU partition: range [{lo}, {hi}) of {n_cus}, {encoder_cus} encoder CUs")
         self.encoder_cus, self.n_cus = int(encoder_cus), int(n_cus)
         hip = _hiplib()
-        _chk(hip.hipSetDevice(self.device.index or 0), "hipSetDevice")
-        self.s_dec = masked_stream(lo, hi - encoder_cus, n_cus)
-        self.s_enc = masked_stream(hi - encoder_cus, hi, n_cus)
-        self._events: List[int] = []
-        for _ in range(2):
-            ev = C.c_void_p()
-            _chk(hip.hipEventCreateWithFlags(C.byref(ev), 0x2), "hipEventCreateWithFlags")  # hipEventDisableTiming
-            self._events.append(int(ev.value))
+        dev = self.device.index or 0
+        self.s_dec = masked_stream(lo, hi - encoder_cus, n_cus, dev)
+        self.s_enc = masked_stream(hi - encoder_cus, hi, n_cus, dev)
+        self._events: List[int] = [hip.event_create(dev) for _ in range(2)]
 
     def close(self):
         hip = _hiplib()
         for e in self.engines:
             e.raw_stream = None
         for ev in self._events:
-            hip.hipEventDestroy(ev)
+            hip.event_destroy(ev)
         for s in (self.s_dec, self.s_enc):
-            hip.hipStreamSynchronize(s)
-            hip.hipStreamDestroy(s)
+            if s is not None:
+                hip.stream_destroy(s)   # synchronises first
         self._events, self.s_dec, self.s_enc = [], None, None
 
     def run(self, batches: Iterable[Any], encode_fn: Callable[[WhisperEngine, Any], Any],
@@ -117,8 +138,7 @@ class EncoderOverlap:
 
         def producer():
             try:
-                torch.cuda.set_device(dev_index)
-                _chk(hip.hipSetDevice(dev_index), "hipSetDevice")
+                torch.cuda.set_device(dev_index)   # torch allocations of this thread; the tw_* calls guard their own device
                 for i, b in enumerate(batches):
                     k = i % 2
                     free[k].acquire()                      # decode of batch i - 2 has returned
@@ -129,7 +149,7 @@ class EncoderOverlap:
                     s_i = self.s_dec if i == 0 else self.s_enc
                     eng.raw_stream = s_i
                     enc = encode_fn(eng, b)                # asynchronous launches
-                    _chk(hip.hipEventRecord(self._events[k], s_i), "hipEventRecord")
+                    hip.event_record(self._events[k], s_i)
                     ready.put((i, k, enc, None))
             except BaseException as e:  # noqa: BLE001  (hand the failure to the consumer)
                 ready.put((-1, -1, None, e))
@@ -143,10 +163,10 @@ class EncoderOverlap:
                 if err is not None:
                     raise err
                 eng = self.engines[k]
-                _chk(hip.hipStreamWaitEvent(self.s_dec, self._events[k], 0), "hipStreamWaitEvent")
+                hip.stream_wait_event(self.s_dec, self._events[k])
                 eng.raw_stream = self.s_dec
                 out.append(decode_fn(eng, batches[i], enc))  # blocking: returns when the batch is decoded
-                _chk(hip.hipStreamSynchronize(self.s_dec), "hipStreamSynchronize")
+                hip.stream_synchronize(self.s_dec)
                 free[k].release()
         finally:
             stop.set()

@@ -36,14 +36,17 @@ class _StreamBackend:
 
 
 class BatchingHub:
-    def __init__(self, backend: AMDWhisperBackend, max_batch: Optional[int] = None, max_wait_s: float = 0.004):
+    def __init__(self, backend: AMDWhisperBackend, max_batch: Optional[int] = None, max_wait_s: float = 0.004,
+                 max_pending: int = 1024):
         self.backend = backend
         eng = backend.asr_pipeline.model.engine
         self.max_batch = int(max_batch or eng.max_batch)
         if self.max_batch > eng.max_batch:
             raise ValueError("max_batch exceeds the engine capacity")
         self.max_wait_s = max_wait_s
-        self._q: "queue.Queue[Optional[Tuple[np.ndarray, float, int, Future]]]" = queue.Queue()
+        self._q: "queue.Queue[Optional[Tuple[np.ndarray, float, int, Future]]]" = queue.Queue(maxsize=max_pending)
+        self._closed = False
+        self._lock = threading.Lock()
         self._next_id = 0
         self.batches: List[int] = []          # sizes of the batches that were run (introspection / tests)
         self._worker = threading.Thread(target=self._run, name="thewhisper-batcher", daemon=True)
@@ -55,16 +58,43 @@ class BatchingHub:
         return _StreamBackend(self, self._next_id - 1)
 
     def submit(self, audio: np.ndarray, buffer_start_time: float, sample_rate: int) -> Future:
+        """Parks one request; raises ``RuntimeError`` after ``close()`` and ``queue.Full`` when ``max_pending`` requests wait."""
         fut: Future = Future()
-        self._q.put((np.asarray(audio), float(buffer_start_time), int(sample_rate), fut))
+        with self._lock:
+            if self._closed:
+                raise RuntimeError("BatchingHub is closed")
+            self._q.put_nowait((np.asarray(audio), float(buffer_start_time), int(sample_rate), fut))
         return fut
 
     def close(self):
+        """Stops the worker; requests still parked are failed (their sessions would otherwise wait forever)."""
+        with self._lock:
+            if self._closed:
+                return
+            self._closed = True
         self._q.put(None)
-        self._worker.join(timeout=10)
+        self._worker.join(timeout=30)
+        self._fail_pending(RuntimeError("BatchingHub closed before the request was served"))
+
+    def _fail_pending(self, exc: Exception):
+        while True:
+            try:
+                item = self._q.get_nowait()
+            except queue.Empty:
+                return
+            if item is not None and not item[3].done():
+                item[3].set_exception(exc)
 
     # -- worker --------------------------------------------------------------------------------------
     def _run(self):
+        try:   # the batcher owns a GPU context: pin this thread's torch device to it
+            import torch
+
+            dev = getattr(self.backend.asr_pipeline.model.engine, "device", None)
+            if dev is not None and dev.type == "cuda":
+                torch.cuda.set_device(dev)
+        except Exception:  # noqa: BLE001
+            pass
         while True:
             item = self._q.get()
             if item is None:
@@ -88,7 +118,17 @@ class BatchingHub:
             results = self.backend.transcribe_many([(a, t0, sr) for a, t0, sr, _ in batch], batch_size=self.max_batch)
             for (_, _, _, fut), res in zip(batch, results):
                 fut.set_result(res)
-        except Exception as e:  # noqa: BLE001 - propagate to every waiting session, as the reference would raise
-            for _, _, _, fut in batch:
-                if not fut.done():
-                    fut.set_exception(e)
+        except Exception as e:  # noqa: BLE001
+            if len(batch) == 1:
+                if not batch[0][3].done():
+                    batch[0][3].set_exception(e)   # as the reference would raise in that session
+                return
+            # one malformed buffer must not fail its neighbours: run the members of the batch one by one, so that only
+            # the offending session sees the exception
+            for a, t0, sr, fut in batch:
+                if fut.done():
+                    continue
+                try:
+                    fut.set_result(self.backend.transcribe_many([(a, t0, sr)], batch_size=self.max_batch)[0])
+                except Exception as e1:  # noqa: BLE001
+                    fut.set_exception(e1)
