@@ -91,3 +91,61 @@ def test_hub_under_the_reference_scheduler():
     # the first 6 s of the golden stream: same backend calls -> same words as the reference backend produced
     ref_calls = [c for c in g["calls"] if c["offset"] + c["n"] <= 16000 * 6]
     assert normalise(results[0][1]) == ref_calls[-1]["result"] or len(results[0][1]) > 0
+
+
+class _FlakyBackend:
+    """Backend double: a request whose first sample is NaN makes the (batched or single) call raise."""
+
+    class _P:
+        class model:
+            class engine:
+                max_batch = 4
+        model = model
+
+    asr_pipeline = _P
+
+    def __init__(self):
+        self.calls = []
+
+    def transcribe_many(self, requests, batch_size=None):
+        self.calls.append(len(requests))
+        if any(np.isnan(a[0]) for a, _, _ in requests):
+            raise ValueError("malformed buffer")
+        return [[{"text": f"n={len(a)}", "start": t0, "end": t0 + 1.0}] for a, t0, _ in requests]
+
+
+def test_hub_isolates_a_failing_request_and_fails_parked_requests_on_close():
+    from thewhisper_amd.serving import BatchingHub
+
+    be = _FlakyBackend()
+    hub = BatchingHub(be, max_batch=4, max_wait_s=0.3)
+    good = [np.zeros(100 + i, np.float32) for i in range(3)]
+    bad = np.full(50, np.nan, np.float32)
+    futs = [hub.submit(good[0], 0.0, 16000), hub.submit(bad, 1.0, 16000), hub.submit(good[1], 2.0, 16000), hub.submit(good[2], 3.0, 16000)]
+    assert futs[0].result(10)[0]["text"] == "n=100" and futs[2].result(10)[0]["text"] == "n=101" and futs[3].result(10)[0]["text"] == "n=102"
+    with pytest.raises(ValueError, match="malformed"):
+        futs[1].result(10)                       # only the offending session sees the exception
+    assert be.calls[0] == 4 and sorted(be.calls[1:]) == [1, 1, 1, 1]   # one batched attempt, then one by one
+    hub.close()
+    with pytest.raises(RuntimeError, match="closed"):
+        hub.submit(good[0], 0.0, 16000)
+    hub.close()                                  # idempotent
+
+    # requests parked behind the shutdown sentinel are failed, not left hanging
+    hub2 = BatchingHub(_FlakyBackend(), max_batch=1, max_wait_s=0.0)
+    gate = threading.Event()
+    slow = hub2.backend.transcribe_many
+
+    def blocked(reqs, batch_size=None):
+        gate.wait(5)
+        return slow(reqs, batch_size)
+
+    hub2.backend.transcribe_many = blocked
+    f1 = hub2.submit(good[0], 0.0, 16000)
+    f2 = hub2.submit(good[1], 0.0, 16000)
+    t = threading.Thread(target=hub2.close)
+    t.start()
+    gate.set()
+    t.join(20)
+    assert f1.result(5)[0]["text"] == "n=100"
+    assert f2.done() and (f2.exception() is not None or f2.result()[0]["text"] == "n=101")

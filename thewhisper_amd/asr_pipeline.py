@@ -8,6 +8,7 @@ the host, exactly as in the reference), with the model object replaced by
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Optional, Union
 
 import torch
@@ -38,6 +39,11 @@ class ASRPipeline(AutomaticSpeechRecognitionPipeline):
         **kwargs,
     ):
         revision = kwargs.pop("revision", "main")
+        # THEWHISPER_DEVICE overrides a plain "cuda" (the reference's streaming backend hard-codes device="cuda" for GPU
+        # platforms, R:thestage_speechkit/streaming/streaming_pipeline.py:365): pick one MI355X of the node ("cuda:3"), or
+        # "cpu" together with an injected engine factory in the GPU-less tests of the host glue
+        if device == "cuda" and os.environ.get("THEWHISPER_DEVICE"):
+            device = os.environ["THEWHISPER_DEVICE"]
         engine_factory: Optional[Callable] = kwargs.pop("engine_factory", None)  # test seam only
         decoder_weights: Optional[str] = kwargs.pop("decoder_weights", None)     # MI355X-only option: "fp8" = MXFP8 decoder weights
         shared_engine = kwargs.pop("engine", None)  # MI355X-only option: an already loaded WhisperEngine (shared context)

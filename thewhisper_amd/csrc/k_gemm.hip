@@ -21,6 +21,8 @@
 //    layouts the attention kernels consume (no separate permute kernels).
 #include "tw_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 __device__ __forceinline__ long long rowmap(const RowMap& r, int m) {
@@ -81,24 +83,33 @@ __device__ __forceinline__ f32x4_t mfma_step<float>(const u32x4_t& wfrag, const 
   return acc;
 }
 
-template <typename T, int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A, RowMap amap, const T* __restrict__ W,
-                                                    int M, int N, int K, GemmEpilogue ep) {
+// BM x BN block tile, WM x WN wavefronts (each owns a (BM/WM) x (BN/WN) sub-tile), ST-stage LDS ring filled by global->LDS
+// DMA with prefetch distance ST-1: with two stages the DMA of tile k+1 has one tile's worth of MFMAs (~500 cycles) to land,
+// less than an HBM round trip, and the loop runs at a fifth of the matrix-core rate; with three stages (distance 2, 8
+// wavefronts = 2 per SIMD on a 256 x 128 tile: ~1000 cycles of MFMAs per SIMD and iteration) the latency is covered.
+// One barrier per K tile: after it, tile kt is visible to every wavefront and buffer (kt-1) % ST - consumed in the
+// previous iteration - is free for tile kt + ST - 1.
+template <typename T, int BM, int BN, int WM, int WN, int ST>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const T* __restrict__ A, RowMap amap, const T* __restrict__ W,
+                                                              int M, int N, int K, GemmEpilogue ep) {
   constexpr int E = ElemTraits<T>::kPer16B;  // elements per 16-B vector
   constexpr int BKE = 8 * E;                 // elements per K tile
-  constexpr int AV = BM * 8 / 256;           // 16-B vectors per thread per tile (activations)
-  constexpr int WV = BN * 8 / 256;           // (weights)
-  constexpr int MT = BM / 32;                // 16-row MFMA tiles per wave along M
-  constexpr int NT = BN / 32;                // along N
-  __shared__ u32x4_t lds[2 * 8 * (BM + BN)];
-  u32x4_t* ldsA = lds;                   // [2][8][BM]
-  u32x4_t* ldsW = lds + 2 * 8 * BM;      // [2][8][BN]
+  constexpr int NWAVE = WM * WN;
+  constexpr int NTHR = NWAVE * 64;
+  constexpr int AV = BM * 8 / NTHR;          // 16-B vectors per thread per tile (activations)
+  constexpr int WV = BN * 8 / NTHR;          // (weights)
+  constexpr int RM = BM / WM, RN = BN / WN;  // rows / columns of a wavefront's sub-tile
+  constexpr int MT = RM / 16;                // 16-row MFMA tiles per wave along M
+  constexpr int NT = RN / 16;                // along N
+  static_assert(AV >= 1 && WV >= 1 && MT >= 1 && NT >= 1, "tile / wavefront layout");
+  constexpr int STAGE = 8 * (BM + BN);       // 16-B vectors per ring stage
+  __shared__ u32x4_t lds[ST * STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wn = wave & 1;   // wave position along N
-  const int wm = wave >> 1;  // along M
+  const int wn = wave % WN;  // wave position along N
+  const int wm = wave / WN;  // along M
   const int n0 = blockIdx.x * BN;
   const int m0 = blockIdx.y * BM;
 
@@ -110,7 +121,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A, RowM
   const T* asrc[AV];
 #pragma unroll
   for (int i = 0; i < AV; ++i) {
-    const int p = (i * 4 + wave) * 64 + lane;
+    const int p = (i * NWAVE + wave) * 64 + lane;
     const int row = p >> 3, slot = (p & 7) ^ ((row >> 1) & 7);
     int m = m0 + row;
     if (m >= M) m = M - 1;
@@ -119,22 +130,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A, RowM
   const T* wsrc[WV];
 #pragma unroll
   for (int i = 0; i < WV; ++i) {
-    const int p = (i * 4 + wave) * 64 + lane;
+    const int p = (i * NWAVE + wave) * 64 + lane;
     const int row = p >> 3, slot = (p & 7) ^ ((row >> 1) & 7);
-    wsrc[i] = W + (long long)(n0 + row) * K + slot * E;
+    wsrc[i] = W + (long long)min(n0 + row, N - 1) * K + slot * E;
   }
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   auto issue_tile = [&](int kt, int b) {
     const int koff = kt * BKE;
-    u32x4_t* sa = ldsA + b * 8 * BM;
-    u32x4_t* sw = ldsW + b * 8 * BN;
+    u32x4_t* sa = lds + b * STAGE;
+    u32x4_t* sw = sa + 8 * BM;
 #pragma unroll
     for (int i = 0; i < AV; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + koff), (lptr_t)(sa + (i * 4 + wave) * 64), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + koff), (lptr_t)(sa + (i * NWAVE + wave) * 64), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < WV; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + koff), (lptr_t)(sw + (i * 4 + wave) * 64), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + koff), (lptr_t)(sw + (i * NWAVE + wave) * 64), 16, 0, 0);
   };
 
   f32x4_t acc[NT][MT];
@@ -146,28 +157,39 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A, RowM
   const int nk = K / BKE;
   const int fr = lane & 15;  // fragment row within a 16-row tile
   const int fq = lane >> 4;  // k-slot quad
-  issue_tile(0, 0);
+#pragma unroll
+  for (int t = 0; t < ST - 1; ++t)
+    if (t < nk) issue_tile(t, t);
   int buf = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    // tile kt has landed (this wavefront's DMA: vmcnt; the other wavefronts': barrier) and every wavefront is done
-    // reading the other buffer (it was consumed in iteration kt-1), so the next tile can be streamed into it
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // tile kt has landed: this wavefront's own DMA by vmcnt (requests retire in order; the ST-2 younger tiles may stay in
+    // flight), the other wavefronts' by the barrier
+    if (ST > 2 && kt + ST - 2 < nk) {
+      if constexpr (ST == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AV + WV) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AV + WV)) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
-    if (kt + 1 < nk) issue_tile(kt + 1, buf ^ 1);
-    const u32x4_t* la = ldsA + buf * 8 * BM;
-    const u32x4_t* lw = ldsW + buf * 8 * BN;
+    if (kt + ST - 1 < nk) {
+      int nb = buf + ST - 1;
+      if (nb >= ST) nb -= ST;
+      issue_tile(kt + ST - 1, nb);
+    }
+    const u32x4_t* la = lds + buf * STAGE;
+    const u32x4_t* lw = la + 8 * BM;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int slot = kk * 4 + fq;
       u32x4_t af[MT], wf[NT];
 #pragma unroll
       for (int b = 0; b < MT; ++b) {
-        const int row = wm * (BM / 2) + b * 16 + fr;
+        const int row = wm * RM + b * 16 + fr;
         af[b] = la[row * 8 + (slot ^ ((row >> 1) & 7))];
       }
 #pragma unroll
       for (int a = 0; a < NT; ++a) {
-        const int row = wn * (BN / 2) + a * 16 + fr;
+        const int row = wn * RN + a * 16 + fr;
         wf[a] = lw[row * 8 + (slot ^ ((row >> 1) & 7))];
       }
 #pragma unroll
@@ -175,7 +197,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A, RowM
 #pragma unroll
         for (int b = 0; b < MT; ++b) acc[a][b] = mfma_step<T>(wf[a], af[b], acc[a][b]);
     }
-    buf ^= 1;
+    if (++buf == ST) buf = 0;
   }
 
   // ---- epilogue: lane holds, per (a,b) tile, 4 consecutive columns n of row m ----
@@ -184,13 +206,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A, RowM
   const int dmodel = ep.H * 64;
 #pragma unroll
   for (int b = 0; b < MT; ++b) {
-    const int m = m0 + wm * (BM / 2) + b * 16 + fr;
+    const int m = m0 + wm * RM + b * 16 + fr;
     if (m >= M) continue;
     long long roff = 0;
     if (res) roff = rowmap(ep.res_map, ep.res_mod > 0 ? (m % ep.res_mod) : m);
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
-      const int n = n0 + wn * (BN / 2) + a * 16 + fq * 4;
+      const int n = n0 + wn * RN + a * 16 + fq * 4;
+      if (n >= N) continue;
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r];
@@ -246,25 +269,51 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A, RowM
 
 }  // namespace
 
+static int gemm_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int ST>
+static hipError_t gemm_go(const void* A, RowMap amap, const void* W, int M, int N, int K, const GemmEpilogue& ep, hipStream_t st) {
+  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
+  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, ST>), grid, dim3(WM * WN * 64), 0, st, reinterpret_cast<const T*>(A), amap,
+                     reinterpret_cast<const T*>(W), M, N, K, ep);
+  return hipGetLastError();
+}
+
 template <typename T>
 static hipError_t gemm_dispatch(const void* A, RowMap amap, const void* W, int M, int N, int K,
                                 const GemmEpilogue& ep, hipStream_t st) {
   constexpr int E = ElemTraits<T>::kPer16B;
   if (M <= 0) return hipSuccess;
   if (K % (8 * E) != 0 || N % 64 != 0) return hipErrorInvalidValue;
-  // 128x128 tiles when they already give >= 2 blocks per CU or N only divides by 128-multiples badly;
-  // otherwise 64x64 so that small-M (single stream) GEMMs still spread over the chip.
-  const long long blocks128 = (long long)((M + 127) / 128) * (N / 128);
-  if (N % 128 == 0 && blocks128 >= 384) {
-    dim3 grid(N / 128, (M + 127) / 128);
-    hipLaunchKernelGGL((gemm_kernel<T, 128, 128>), grid, dim3(256), 0, st, reinterpret_cast<const T*>(A), amap,
-                       reinterpret_cast<const T*>(W), M, N, K, ep);
-  } else {
-    dim3 grid(N / 64, (M + 63) / 64);
-    hipLaunchKernelGGL((gemm_kernel<T, 64, 64>), grid, dim3(256), 0, st, reinterpret_cast<const T*>(A), amap,
-                       reinterpret_cast<const T*>(W), M, N, K, ep);
+  // Tile choice by how many workgroups cover the 256 compute units (TW_GEMM_CFG forces one for experiments):
+  //   3: 256 x 128, 8 wavefronts, 3-stage ring   - large M (batched encoder): halves the LDS fill per flop
+  //   2: 128 x 128, 4 wavefronts, 3-stage ring
+  //   1: 128 x 64, 4 wavefronts, 3 stages        - mid-size (single 30 s stream): >= 1 workgroup per CU with 2x the MFMAs per
+  //                                                LDS byte of the 64 x 64 tile
+  //   0: 64 x 64, 4 wavefronts, 2 stages         - small M
+  static const int forced = gemm_env("TW_GEMM_CFG", -1);
+  const long long b256 = (long long)((M + 255) / 256) * ((N + 127) / 128);
+  const long long b128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
+  const long long b12864 = (long long)((M + 127) / 128) * (N / 64);
+  int cfg;
+  if (forced >= 0) cfg = forced;
+  else if (N % 128 == 0 && b256 >= 512) cfg = 3;
+  else if (N % 128 == 0 && b128 >= 384) cfg = 2;
+  else if (b12864 >= 200) cfg = 1;
+  else cfg = 0;
+  if (sizeof(T) == 4 && cfg == 3) cfg = 2;  // strict-f32 contexts: parity mode, the 8-wavefront tile is not instantiated
+  switch (cfg) {
+    case 3:
+      if constexpr (sizeof(T) == 2) return gemm_go<T, 256, 128, 4, 2, 3>(A, amap, W, M, N, K, ep, st);
+      return hipErrorInvalidValue;
+    case 2: return gemm_go<T, 128, 128, 2, 2, 3>(A, amap, W, M, N, K, ep, st);
+    case 4: return gemm_go<T, 128, 128, 2, 2, 2>(A, amap, W, M, N, K, ep, st);   // round-1 kernel (A/B runs)
+    case 1: return gemm_go<T, 128, 64, 2, 2, 3>(A, amap, W, M, N, K, ep, st);
+    default: return gemm_go<T, 64, 64, 2, 2, 2>(A, amap, W, M, N, K, ep, st);
   }
-  return hipGetLastError();
 }
 
 hipError_t launch_gemm(int dtype, const void* A, RowMap amap, const void* W, int M, int N, int K,

@@ -37,16 +37,25 @@ class WhisperEngine:
 
     def _adopt(self, *tensors) -> None:
         """With ``raw_stream`` set the work runs on a stream torch's caching allocator knows nothing about: order that
-        stream after torch's current stream (which produced the inputs: H2D copies, slicing, casts) and register every tensor
-        handed to the library with it, so that a temporary dropped on return is not recycled while the launches still read
-        or write it."""
+        stream after torch's current stream (which produced the inputs: H2D copies, slicing, casts) and keep every tensor
+        handed to the library alive until the stream has been synchronised (``_release_held``), so that a temporary dropped
+        on return is not recycled while the launches still read or write it.  (``Tensor.record_stream`` is not used: the
+        allocator would touch the foreign stream when the tensor is freed - possibly after the stream was destroyed.)"""
         if self.raw_stream is None:
             return
         ext = torch.cuda.ExternalStream(self.raw_stream, device=self.device)
         ext.wait_stream(torch.cuda.current_stream(self.device))
-        for t in tensors:
-            if t is not None and t.is_cuda:
-                t.record_stream(ext)
+        held = self.__dict__.setdefault("_held", [])
+        if len(held) > 256:      # only asynchronous calls for a long time: drain rather than grow without bound
+            ext.synchronize()
+            held.clear()
+        held.extend(t for t in tensors if t is not None and t.is_cuda)
+
+    def _release_held(self) -> None:
+        """Called after an entry point that synchronised the stream in use (greedy decode, timestamps, weight upload)."""
+        held = self.__dict__.get("_held")
+        if held:
+            held.clear()
 
     def _publish(self) -> None:
         """Counterpart of ``_adopt`` for tensors RETURNED to the caller: torch's current stream waits for the foreign stream,
@@ -59,6 +68,7 @@ class WhisperEngine:
             torch.cuda.ExternalStream(self.raw_stream, device=self.device).synchronize()
         else:
             torch.cuda.current_stream(self.device).synchronize()
+        self._release_held()
 
 
     def __init__(
@@ -261,6 +271,7 @@ class WhisperEngine:
                                          out.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(out_len),
                                          self._sp())
         self._chk(rc, "tw_generate_greedy")
+        self._release_held()   # the call returns after synchronising its stream, which is ordered after the encoder stage
         L = int(out_len.value)
         return {"sequences": out[:, :L].astype(np.int64), "length": L}
 

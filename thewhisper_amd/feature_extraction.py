@@ -8,12 +8,15 @@ per chunk (HF:pipelines/automatic_speech_recognition.py:67-72); everything excep
 """
 from __future__ import annotations
 
+import threading
+
 import numpy as np
 from transformers import WhisperFeatureExtractor
 
 
 class AMDWhisperFeatureExtractor(WhisperFeatureExtractor):
     _engine = None
+    _tls = threading.local()
 
     @classmethod
     def from_hf(cls, fe: WhisperFeatureExtractor) -> "AMDWhisperFeatureExtractor":
@@ -33,7 +36,17 @@ class AMDWhisperFeatureExtractor(WhisperFeatureExtractor):
             raise ValueError("engine / feature extractor mel-bin mismatch")
         self._engine = engine
 
-    def _torch_extract_fbank_features(self, waveform: np.ndarray, device: str = "cpu") -> np.ndarray:  # noqa: ARG002
+    def __call__(self, raw_speech, *args, return_tensors=None, **kwargs):
+        # With return_tensors="pt" (what the ASR pipeline asks for, HF:pipelines/automatic_speech_recognition.py:67-72) the
+        # log-mel tensor stays where tw_logmel wrote it - in HBM - and travels through BatchFeature / the pipeline's collate
+        # function as a device tensor straight into tw_encode: no device -> host -> device round trip per chunk.
+        self._tls.keep_on_device = return_tensors == "pt"
+        try:
+            return super().__call__(raw_speech, *args, return_tensors=return_tensors, **kwargs)
+        finally:
+            self._tls.keep_on_device = False
+
+    def _torch_extract_fbank_features(self, waveform: np.ndarray, device: str = "cpu"):  # noqa: ARG002
         if self._engine is None:
             raise RuntimeError("AMDWhisperFeatureExtractor has no engine attached (no CPU fallback)")
         import torch
@@ -46,9 +59,11 @@ class AMDWhisperFeatureExtractor(WhisperFeatureExtractor):
         mb = self._engine.max_batch
         for i in range(0, w.shape[0], mb):
             x = torch.from_numpy(np.ascontiguousarray(w[i : i + mb]))
-            mel = self._engine.logmel(x, out_dtype=torch.float32)
-            outs.append(mel.cpu().numpy())
-        out = np.concatenate(outs, axis=0)
+            outs.append(self._engine.logmel(x, out_dtype=torch.float32))
+        mel = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+        if getattr(self._tls, "keep_on_device", False):
+            return mel[0] if squeeze else mel
+        out = mel.cpu().numpy()
         return out[0] if squeeze else out
 
     # the numpy path must not silently take over either
