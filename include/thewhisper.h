@@ -163,6 +163,15 @@ int tw_get_alignment(tw_ctx* ctx, int32_t B, int32_t n_rows, float* out_host, vo
  * number of decode steps of the last greedy call in steps_out.  Used by bench.py for the roofline. */
 int tw_last_timings(tw_ctx* ctx, float* ms_out5, int32_t* steps_out);
 
+/* SURVEY 8f-2.  Stands where the reference calls silero-vad: `prob = vad_model(frame_512, 16000).item()` on consecutive
+ * 512-sample frames with state kept between calls (R:thestage_speechkit/streaming/streaming_pipeline.py:533-538, :589-622).
+ * NOT silero (its weights are not obtainable offline): an adaptive-noise-floor energy detector with the same contract, rule in
+ * thewhisper_amd/csrc/k_vad.hip.  pcm_dev: float32 [B, stream_stride] (16-byte aligned), the first n_frames*512 samples of
+ * every row are processed in order; state_dev: float32 [B, 2] (noise floor dB, started flag; zero-initialise to reset a
+ * stream); prob_dev: float32 [B, n_frames].  Asynchronous on `stream`. */
+int tw_vad_energy(int32_t device, const float* pcm_dev, int64_t stream_stride, int32_t B, int32_t n_frames, float* state_dev,
+                  float* prob_dev, void* stream);
+
 /* Host-side schedule helpers (no reference counterpart: the reference processes one request at a time,
  * R:examples/server.py:22-115).  Streams and events created by the SAME HIP runtime the library and torch use, for the
  * encoder / decoder stage overlap (thewhisper_amd/overlap.py): a stream whose kernels may only run on the compute units

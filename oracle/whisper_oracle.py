@@ -829,6 +829,30 @@ def token_timestamps(
 # --------------------------------------------------------------------------------------
 
 
+def energy_vad(pcm: np.ndarray, state: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """Restatement of thewhisper_amd/csrc/k_vad.hip (the stand-in for the reference's silero-vad gate,
+    R:thestage_speechkit/streaming/streaming_pipeline.py:533-538, :589-622; NOT silero - see the kernel header).
+    pcm [B, k*512] float32, state [B, 2] (noise floor dB, started flag) or None -> (probabilities [B, k], new state)."""
+    x = np.asarray(pcm, dtype=np.float32)
+    if x.ndim == 1:
+        x = x[None]
+    B, k = x.shape[0], x.shape[1] // 512
+    st = np.zeros((B, 2), np.float32) if state is None else np.array(state, dtype=np.float32)
+    out = np.zeros((B, k), np.float32)
+    for b in range(B):
+        nf, started = np.float32(st[b, 0]), st[b, 1] != 0
+        for f in range(k):
+            fr = x[b, f * 512 : (f + 1) * 512].astype(np.float64)
+            e = np.float32(10.0) * np.log10(np.float32((fr * fr).sum() * (1.0 / 512.0)) + np.float32(1e-10)).astype(np.float32)
+            nf = np.float32(min(e, nf + np.float32(0.02))) if started else np.float32(min(e, np.float32(-40.0)))
+            started = True
+            p = np.float32(1.0) / (np.float32(1.0) + np.exp(-((e - nf) - np.float32(9.0)) * np.float32(0.5), dtype=np.float32)) \
+                if e > np.float32(-60.0) else np.float32(0.0)
+            out[b, f] = p
+        st[b] = (nf, 1.0 if started else 0.0)
+    return out, st
+
+
 def synth_audio(n: int, seed: int = 0, kind: str = "noise") -> np.ndarray:
     """Seeded float32 mono 16 kHz test clips: gaussian noise (sigma 0.1, clipped), zeros, 440 Hz sine."""
     if kind == "noise":

@@ -57,6 +57,7 @@ SYMBOLS = [
                                       C.POINTER(C.c_float), _P]),
     ("tw_get_alignment", C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_float), _P]),
     ("tw_last_timings", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+    ("tw_vad_energy", C.c_int, [C.c_int32, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, _P]),
     ("tw_stream_create_masked", C.c_int, [C.c_int32, C.POINTER(C.c_uint32), C.c_int32, C.POINTER(_P)]),
     ("tw_stream_destroy", C.c_int, [_P]),
     ("tw_stream_synchronize", C.c_int, [_P]),

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBNAME = "libthewhisper_gfx950.so"
-SOURCES = ["api.hip", "k_gemm.hip", "k_misc.hip", "k_logmel.hip", "k_attn.hip", "k_decode.hip", "k_dtw.hip"]
+SOURCES = ["api.hip", "k_gemm.hip", "k_misc.hip", "k_logmel.hip", "k_attn.hip", "k_decode.hip", "k_dtw.hip", "k_vad.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 
 

@@ -985,6 +985,16 @@ int tw_last_timings(tw_ctx* c, float* ms_out5, int32_t* steps_out) {
 // ---------------------------------------------------------------------------------------------
 extern "C" {
 
+int tw_vad_energy(int32_t device, const float* pcm_dev, int64_t stream_stride, int32_t B, int32_t n_frames, float* state_dev,
+                  float* prob_dev, void* stream) {
+  if (!pcm_dev || !state_dev || !prob_dev || B < 1 || n_frames < 1 || stream_stride < (int64_t)n_frames * 512) return TW_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(pcm_dev) & 15) || (stream_stride & 3)) return TW_EINVAL;   // 16-byte frame loads
+  DeviceGuard guard(device);
+  hipError_t e = launch_vad_energy(pcm_dev, stream_stride, B, n_frames, state_dev, prob_dev, reinterpret_cast<hipStream_t>(stream));
+  if (e != hipSuccess) { g_create_error = std::string("vad_energy_kernel: ") + hipGetErrorString(e); return TW_EHIP; }
+  return TW_OK;
+}
+
 int tw_stream_create_masked(int32_t device, const uint32_t* cu_mask, int32_t n_words, void** out_stream) {
   if (!cu_mask || n_words < 1 || !out_stream) return TW_EINVAL;
   DeviceGuard guard(device);

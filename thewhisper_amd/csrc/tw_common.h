@@ -217,3 +217,7 @@ struct DtwArgs {
   double time_precision;
 };
 hipError_t launch_token_timestamps(const DtwArgs& a, hipStream_t st);
+
+// 8f-2: energy voice-activity gate, one wavefront per stream, `n_frames` consecutive 512-sample frames each (k_vad.hip)
+hipError_t launch_vad_energy(const float* pcm, long long stream_stride, int B, int n_frames, float* state, float* prob,
+                             hipStream_t st);
