@@ -133,3 +133,53 @@ def test_reference_remote_backend_against_the_gateway(served, monkeypatch):
     want = backend.transcribe(q.copy(), 12.5, 16000)          # what LocalWhisperBackend-equivalent code returns for this buffer
     got = remote.transcribe(audio, 12.5, 16000)
     assert normalise(got) == normalise(want)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference checkout not present")
+def test_session_routes_mirror_the_reference_server(served):
+    """R:examples/server.py:118-163: create / add_chunk (base64 float32 as a query parameter) / process / clear / end.  Two
+    sessions stream the golden clip in lock step through their own scheduler state and the shared hub; the words each one
+    gets equal the reference's single-stream run."""
+    import base64
+    import json
+
+    from oracle.make_golden import _import_reference
+
+    _import_reference()      # makes thestage_speechkit importable: the per-session scheduler is the reference's StreamingPipeline
+    backend, hub, client = served
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "pipeline_golden.json")))["streaming_micro_c10"]
+    audio = wo.synth_audio(16000 * g["seconds"], g["seed"], g["kind"])[: 16000 * 6]
+    H = {"Authorization": "Bearer s3cret"}
+    assert client.post("/session/create/").status_code == 401
+    sids = [client.post("/session/create/", headers=H).json()["session_id"] for _ in range(2)]
+    assert len(set(sids)) == 2 and client.get("/health").json()["sessions"] == 2
+    committed = {s: [] for s in sids}
+    last = {s: [] for s in sids}
+    step = g["step_samples"] * 10      # 0.5 s per request keeps the test short; the scheduler state machine is the same
+    for i in range(0, len(audio), step):
+        chunk = base64.b64encode(audio[i : i + step].astype(np.float32).tobytes()).decode("ascii")
+        for s in sids:
+            assert client.post(f"/session/{s}/add_chunk", params={"audio_data": chunk}, headers=H).json() == {"status": "success"}
+        res = {}
+
+        def proc(s):
+            res[s] = client.post(f"/session/{s}/process", headers=H)
+
+        th = [threading.Thread(target=proc, args=(s,)) for s in sids]
+        [t.start() for t in th]
+        [t.join(120) for t in th]
+        for s in sids:
+            assert res[s].status_code == 200, res[s].text
+            body = res[s].json()
+            assert set(body) == {"words", "uncommited_words"}
+            committed[s] += body["words"]
+            last[s] = body["uncommited_words"]
+    assert committed[sids[0]] == committed[sids[1]] and last[sids[0]] == last[sids[1]]
+    assert len(last[sids[0]]) + len(committed[sids[0]]) > 0
+    assert all({"text", "start", "end"} <= set(w) for w in last[sids[0]])
+    assert client.post(f"/session/{sids[0]}/clear", headers=H).json() == {"status": "success"}
+    assert client.post(f"/session/{sids[0]}/end", headers=H).json() == {"status": "success"}
+    assert client.post(f"/session/{sids[0]}/process", headers=H).status_code == 404
+    assert client.post("/session/nope/add_chunk", params={"audio_data": ""}, headers=H).status_code == 404
+    client.post(f"/session/{sids[1]}/end", headers=H)
+    assert client.get("/health").json()["sessions"] == 0

@@ -75,17 +75,118 @@ def words_to_response(words: List[Dict[str, Any]], model_name: str = "") -> Dict
     return out
 
 
+def _default_scheduler_factory(session_backend, chunk_length_s):
+    """The per-session scheduler is the reference's own, unmodified ``StreamingPipeline`` (rolling buffer, truncation,
+    committed / uncommitted words: R:thestage_speechkit/streaming/streaming_pipeline.py:443-988), fed through its backend
+    injection seam (:460, :561-562).  It lives in the reference package, so session routes need ``thestage_speechkit``
+    importable (the gateway then runs inside the reference's environment) or an explicit ``scheduler_factory``."""
+    try:
+        from thestage_speechkit.streaming import StreamingPipeline
+    except Exception as e:  # noqa: BLE001
+        raise RuntimeError("session routes need the reference package `thestage_speechkit` (its StreamingPipeline is the "
+                           "per-session scheduler) or create_app(scheduler_factory=...)") from e
+    return StreamingPipeline(backend=session_backend, chunk_length_s=chunk_length_s, min_process_chunk_s=0.5, use_vad=False)
+
+
 def create_app(backend: Union[BatchingHub, AMDWhisperBackend], auth_token: str = "", model_name: str = "",
-               lang_id: Optional[str] = None, path: str = "/transcribe"):
+               lang_id: Optional[str] = None, path: str = "/transcribe", scheduler_factory=None, max_sessions: int = 1024):
     """FastAPI application.  ``backend``: a ``BatchingHub`` (concurrent requests share batches) or a bare
     ``AMDWhisperBackend``.  ``auth_token``: when set, requests must carry ``Authorization: Bearer <token>``.
-    ``lang_id``: when set, a request's ``X-Lang-Id`` must equal it (the engine is built for one language prompt)."""
+    ``lang_id``: when set, a request's ``X-Lang-Id`` must equal it (the engine is built for one language prompt).
+
+    Two surfaces:
+      * ``POST /transcribe`` - stateless, the wire format of the reference's remote backend (module docstring);
+      * ``POST /session/create/``, ``/session/{id}/add_chunk``, ``/process``, ``/clear``, ``/end`` - the routes of the
+        reference's demo server (R:examples/server.py:118-163) with the same request / response shapes, except that every
+        session owns its scheduler state (the reference shares ONE StreamingPipeline across sessions, :25, :90, :98, and
+        cannot batch) and all sessions of the process share the hub, i.e. one batched engine call per tick.
+        ``scheduler_factory(session_backend, chunk_length_s)`` builds the per-session scheduler (default: the reference's
+        StreamingPipeline)."""
+    import base64
+    import os
+    import threading
+
     from fastapi import FastAPI, Header, HTTPException, Request
     from fastapi.concurrency import run_in_threadpool
 
     app = FastAPI(title="thewhisper-amd gateway")
     hub = backend if isinstance(backend, BatchingHub) else None
-    sample_rate = (backend.backend if hub is not None else backend).sample_rate
+    base_backend = backend.backend if hub is not None else backend
+    sample_rate = base_backend.sample_rate
+    sessions: Dict[str, Any] = {}
+    sessions_lock = threading.Lock()
+    make_scheduler = scheduler_factory or _default_scheduler_factory
+
+    def check_auth(authorization: Optional[str]):
+        if auth_token and not hmac.compare_digest((authorization or "").encode(), f"Bearer {auth_token}".encode()):
+            raise HTTPException(status_code=401, detail="invalid or missing bearer token")
+
+    def get_session(session_id: str):
+        with sessions_lock:
+            s = sessions.get(session_id)
+        if s is None:
+            raise HTTPException(status_code=404, detail=f"Session {session_id} not found")   # R:examples/server.py:86-89
+        return s
+
+    @app.post("/session/create/")
+    async def session_create(authorization: Optional[str] = Header(default=None)):
+        check_auth(authorization)
+        session_id = base64.urlsafe_b64encode(os.urandom(16)).decode("ascii")     # as R:examples/server.py:122
+        try:
+            sched = make_scheduler(hub.stream_backend() if hub is not None else base_backend, base_backend.chunk_length_s)
+        except RuntimeError as e:
+            raise HTTPException(status_code=500, detail=f"Failed to initialize model: {e}") from e
+        with sessions_lock:
+            if len(sessions) >= max_sessions:
+                raise HTTPException(status_code=503, detail="too many sessions")
+            sessions[session_id] = {"scheduler": sched, "lock": threading.Lock()}
+        return {"session_id": session_id}
+
+    @app.post("/session/{session_id}/end")
+    async def session_end(session_id: str, authorization: Optional[str] = Header(default=None)):
+        check_auth(authorization)
+        with sessions_lock:
+            sessions.pop(session_id, None)
+        return {"status": "success"}
+
+    @app.post("/session/{session_id}/add_chunk")
+    async def session_add_chunk(session_id: str, audio_data: str, authorization: Optional[str] = Header(default=None)):
+        """``audio_data``: base64 of float32 PCM, a query parameter exactly as in the reference (R:examples/server.py:135-144)."""
+        check_auth(authorization)
+        s = get_session(session_id)
+        try:
+            audio_np = np.frombuffer(base64.b64decode(audio_data), dtype=np.float32)
+            with s["lock"]:
+                s["scheduler"].add_new_chunk(audio_np)
+            return {"status": "success"}
+        except HTTPException:
+            raise
+        except Exception as e:  # noqa: BLE001
+            raise HTTPException(status_code=500, detail=str(e)) from e
+
+    @app.post("/session/{session_id}/process")
+    async def session_process(session_id: str, authorization: Optional[str] = Header(default=None)):
+        check_auth(authorization)
+        s = get_session(session_id)
+
+        def work():
+            with s["lock"]:
+                return s["scheduler"].process_new_chunk()    # blocks in the hub while the shared batch is decoded
+
+        try:
+            words, uncommited_words = await run_in_threadpool(work)
+            return {"words": words, "uncommited_words": uncommited_words}   # key spelling as in the reference (:153)
+        except Exception as e:  # noqa: BLE001
+            raise HTTPException(status_code=500, detail=str(e)) from e
+
+    @app.post("/session/{session_id}/clear")
+    async def session_clear(session_id: str, authorization: Optional[str] = Header(default=None)):
+        check_auth(authorization)
+        s = get_session(session_id)
+        with s["lock"]:
+            if hasattr(s["scheduler"], "clear"):
+                s["scheduler"].clear()   # per-session state: clearing is safe here (the reference's shared pipeline leaves it commented out)
+        return {"status": "success"}
 
     def transcribe(audio: np.ndarray, sr: int) -> List[Dict[str, Any]]:
         if hub is not None:
@@ -95,8 +196,7 @@ def create_app(backend: Union[BatchingHub, AMDWhisperBackend], auth_token: str =
     @app.post(path)
     async def post_transcribe(request: Request, authorization: Optional[str] = Header(default=None),
                               x_lang_id: Optional[str] = Header(default=None), x_model_name: Optional[str] = Header(default=None)):
-        if auth_token and not hmac.compare_digest((authorization or "").encode(), f"Bearer {auth_token}".encode()):
-            raise HTTPException(status_code=401, detail="invalid or missing bearer token")
+        check_auth(authorization)
         if lang_id and x_lang_id and x_lang_id != lang_id:
             raise HTTPException(status_code=400, detail=f"this gateway serves language '{lang_id}'")
         if model_name and x_model_name and x_model_name != model_name:
@@ -117,7 +217,8 @@ def create_app(backend: Union[BatchingHub, AMDWhisperBackend], auth_token: str =
 
     @app.get("/health")
     async def health():
-        return {"status": "ready", "model": model_name, "batches": (len(hub.batches) if hub is not None else None)}
+        return {"status": "ready", "model": model_name, "batches": (len(hub.batches) if hub is not None else None),
+                "sessions": len(sessions)}
 
     return app
 
