@@ -517,6 +517,7 @@ int tw_finalize_weights(tw_ctx* c, void* stream) {
     size_t mx = Vp * c->d;
     if ((size_t)3 * c->d * c->d > mx) mx = (size_t)3 * c->d * c->d;
     if ((size_t)c->ffn * c->d > mx) mx = (size_t)c->ffn * c->d;
+    if ((size_t)3 * c->C * c->d > mx) mx = (size_t)3 * c->C * c->d;
     void* scratch = nullptr;
     HIPCHK(c, hipMalloc(&scratch, mx * e));
     // narrow projections (N <= 2048: the three d x d matrices and fc2) are laid out for 8-row tiles so that their launches
@@ -551,6 +552,23 @@ int tw_finalize_weights(tw_ctx* c, void* stream) {
       if ((r = retile(L.w2, c->d, c->ffn, &L.s_2, &L.tr_2)) != TW_OK) break;
     }
     if (r == TW_OK) r = retile(c->logit_w, c->V, c->d, &c->logit_ws, nullptr);
+    // the MFMA GEMMs (k_gemm.hip) read their weight operand fragment-major too (16-row tiles, never quantised): encoder
+    // projections, the conv stem as GEMMs over [co][3*C] / [co][3*d] rows, and the decoder's cross K|V projection
+    auto retile_gemm = [&](void* w, int N, int K) -> int {
+      HIPCHK(c, launch_tile_weights(c->dtype, w, scratch, N, K, 16, st));
+      HIPCHK(c, hipMemcpyAsync(w, scratch, (size_t)N * K * e, hipMemcpyDeviceToDevice, st));
+      return TW_OK;
+    };
+    if (r == TW_OK) r = retile_gemm(c->conv1_w, c->d, 3 * c->C);
+    if (r == TW_OK) r = retile_gemm(c->conv2_w, c->d, 3 * c->d);
+    for (int l = 0; l < c->Le && r == TW_OK; ++l) {
+      LayerW& L = c->enc[l];
+      if ((r = retile_gemm(L.wqkv, 3 * c->d, c->d)) != TW_OK) break;
+      if ((r = retile_gemm(L.wo, c->d, c->d)) != TW_OK) break;
+      if ((r = retile_gemm(L.w1, c->ffn, c->d)) != TW_OK) break;
+      if ((r = retile_gemm(L.w2, c->d, c->ffn)) != TW_OK) break;
+    }
+    for (int l = 0; l < c->Ld && r == TW_OK; ++l) r = retile_gemm(c->dec[l].wkv_c, 2 * c->d, c->d);
     hipError_t he = hipStreamSynchronize(st);
     hipFree(scratch);
     if (r != TW_OK) return r;

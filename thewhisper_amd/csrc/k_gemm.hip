@@ -21,7 +21,9 @@
 //    layouts the attention kernels consume (no separate permute kernels).
 #include "tw_common.h"
 
+#include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -44,6 +46,45 @@ __device__ __forceinline__ float gelu_exact(float x) {
   p = fmaf(t, p, 0.254829592f);
   const float e = 1.0f - p * t * __expf(-az * az);
   return 0.5f * x * (1.0f + copysignf(e, z));
+}
+
+// s_barrier WITHOUT the workgroup-scope fence of __syncthreads(): the fence makes hipcc wait for every outstanding VMEM
+// operation (vmcnt(0)) before the barrier, which drains the global->LDS DMA ring and the weight-fragment loads that are
+// meant to stay in flight across it.  What the K loops need is ordered by hand: the s_waitcnt vmcnt(n) before the barrier
+// covers the DMA data of the tile about to be read, and the LDS reads of the previous tile have been consumed by MFMAs that
+// were issued before the barrier.
+__device__ __forceinline__ void tw_barrier_only() { asm volatile("s_barrier" ::: "memory"); }
+
+// LDS fragment reads through inline asm.  hipcc cannot tell a ds_read from a preceding global->LDS DMA apart (not even for
+// distinct __shared__ arrays): in front of the first consumer of ANY ds_read that follows a DMA in program order it emits
+// s_waitcnt vmcnt(0), i.e. it waits for the tile that was requested a moment ago for a LATER iteration - and for the weight
+// fragments requested with it.  With compiler-visible reads the K loop therefore has no prefetching at all (measured: 22-25 %
+// of the matrix-core peak whatever the tile shape or ring depth).  The asm reads are invisible to that analysis; their
+// ordering is done by hand: volatile asm statements keep their program order (barrier, waits, reads), and a fragment becomes
+// usable through tw_lds_ready, which waits on lgkmcnt and carries the fragment as an in/out operand so that no consumer can
+// be scheduled above it.
+typedef __attribute__((address_space(3))) const void* tw_lds_cptr_t;
+__device__ __forceinline__ unsigned tw_lds_addr(const void* p) { return (unsigned)(uintptr_t)(tw_lds_cptr_t)p; }
+template <int OFF>
+__device__ __forceinline__ void tw_lds_read(u32x4_t& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int PENDING>
+__device__ __forceinline__ void tw_lds_ready(u32x4_t& x) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(PENDING)); }
+__device__ __forceinline__ void tw_tie(u32x4_t& x) { asm volatile("" : "+v"(x)); }
+// 16-B global load invisible to hipcc's wait-count pass (same reason: with compiler-visible loads in flight next to LDS DMA
+// it falls back to vmcnt(0) in front of their first consumer); readiness = the manual s_waitcnt vmcnt + tw_tie
+template <int OFF>
+__device__ __forceinline__ void tw_gload(u32x4_t& dst, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(OFF));
+}
+
+// compile-time loops (asm immediates must be constants)
+template <int I, int N, typename F> __device__ __forceinline__ void tw_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    tw_static_for<I + 1, N>(f);
+  }
 }
 
 template <typename T> struct Vec4;  // 4 consecutive elements
@@ -83,136 +124,22 @@ __device__ __forceinline__ f32x4_t mfma_step<float>(const u32x4_t& wfrag, const 
   return acc;
 }
 
-// BM x BN block tile, WM x WN wavefronts (each owns a (BM/WM) x (BN/WN) sub-tile), ST-stage LDS ring filled by global->LDS
-// DMA with prefetch distance ST-1: with two stages the DMA of tile k+1 has one tile's worth of MFMAs (~500 cycles) to land,
-// less than an HBM round trip, and the loop runs at a fifth of the matrix-core rate; with three stages (distance 2, 8
-// wavefronts = 2 per SIMD on a 256 x 128 tile: ~1000 cycles of MFMAs per SIMD and iteration) the latency is covered.
-// One barrier per K tile: after it, tile kt is visible to every wavefront and buffer (kt-1) % ST - consumed in the
-// previous iteration - is free for tile kt + ST - 1.
-template <typename T, int BM, int BN, int WM, int WN, int ST>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const T* __restrict__ A, RowMap amap, const T* __restrict__ W,
-                                                              int M, int N, int K, GemmEpilogue ep) {
-  constexpr int E = ElemTraits<T>::kPer16B;  // elements per 16-B vector
-  constexpr int BKE = 8 * E;                 // elements per K tile
-  constexpr int NWAVE = WM * WN;
-  constexpr int NTHR = NWAVE * 64;
-  constexpr int AV = BM * 8 / NTHR;          // 16-B vectors per thread per tile (activations)
-  constexpr int WV = BN * 8 / NTHR;          // (weights)
-  constexpr int RM = BM / WM, RN = BN / WN;  // rows / columns of a wavefront's sub-tile
-  constexpr int MT = RM / 16;                // 16-row MFMA tiles per wave along M
-  constexpr int NT = RN / 16;                // along N
-  static_assert(AV >= 1 && WV >= 1 && MT >= 1 && NT >= 1, "tile / wavefront layout");
-  constexpr int STAGE = 8 * (BM + BN);       // 16-B vectors per ring stage
-  __shared__ u32x4_t lds[ST * STAGE];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wn = wave % WN;  // wave position along N
-  const int wm = wave / WN;  // along M
-  const int n0 = blockIdx.x * BN;
-  const int m0 = blockIdx.y * BM;
-
-  // Global -> LDS by direct DMA (global_load_lds_dwordx4): no staging registers, no ds_write pass.  The DMA writes the 64
-  // lanes of a wavefront to 64 consecutive 16-B LDS slots, so the swizzle is applied on the SOURCE side: linear LDS
-  // position p (16-B units) of a tile holds row p>>3, k-slot (p&7) ^ ((row>>1)&7); 8 consecutive lanes still cover one
-  // 128-B row segment of global memory (coalesced), and the fragment read - 16 lanes = 16 consecutive rows of one k-slot,
-  // ds_read_b128 - touches every bank exactly once.
-  const T* asrc[AV];
-#pragma unroll
-  for (int i = 0; i < AV; ++i) {
-    const int p = (i * NWAVE + wave) * 64 + lane;
-    const int row = p >> 3, slot = (p & 7) ^ ((row >> 1) & 7);
-    int m = m0 + row;
-    if (m >= M) m = M - 1;
-    asrc[i] = A + rowmap(amap, m) + slot * E;
-  }
-  const T* wsrc[WV];
-#pragma unroll
-  for (int i = 0; i < WV; ++i) {
-    const int p = (i * NWAVE + wave) * 64 + lane;
-    const int row = p >> 3, slot = (p & 7) ^ ((row >> 1) & 7);
-    wsrc[i] = W + (long long)min(n0 + row, N - 1) * K + slot * E;
-  }
-  typedef __attribute__((address_space(1))) const void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  auto issue_tile = [&](int kt, int b) {
-    const int koff = kt * BKE;
-    u32x4_t* sa = lds + b * STAGE;
-    u32x4_t* sw = sa + 8 * BM;
-#pragma unroll
-    for (int i = 0; i < AV; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + koff), (lptr_t)(sa + (i * NWAVE + wave) * 64), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < WV; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + koff), (lptr_t)(sw + (i * NWAVE + wave) * 64), 16, 0, 0);
-  };
-
-  f32x4_t acc[NT][MT];
-#pragma unroll
-  for (int a = 0; a < NT; ++a)
-#pragma unroll
-    for (int b = 0; b < MT; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = K / BKE;
-  const int fr = lane & 15;  // fragment row within a 16-row tile
-  const int fq = lane >> 4;  // k-slot quad
-#pragma unroll
-  for (int t = 0; t < ST - 1; ++t)
-    if (t < nk) issue_tile(t, t);
-  int buf = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    // tile kt has landed: this wavefront's own DMA by vmcnt (requests retire in order; the ST-2 younger tiles may stay in
-    // flight), the other wavefronts' by the barrier
-    if (ST > 2 && kt + ST - 2 < nk) {
-      if constexpr (ST == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AV + WV) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AV + WV)) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    if (kt + ST - 1 < nk) {
-      int nb = buf + ST - 1;
-      if (nb >= ST) nb -= ST;
-      issue_tile(kt + ST - 1, nb);
-    }
-    const u32x4_t* la = lds + buf * STAGE;
-    const u32x4_t* lw = la + 8 * BM;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int slot = kk * 4 + fq;
-      u32x4_t af[MT], wf[NT];
-#pragma unroll
-      for (int b = 0; b < MT; ++b) {
-        const int row = wm * RM + b * 16 + fr;
-        af[b] = la[row * 8 + (slot ^ ((row >> 1) & 7))];
-      }
-#pragma unroll
-      for (int a = 0; a < NT; ++a) {
-        const int row = wn * RN + a * 16 + fr;
-        wf[a] = lw[row * 8 + (slot ^ ((row >> 1) & 7))];
-      }
-#pragma unroll
-      for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int b = 0; b < MT; ++b) acc[a][b] = mfma_step<T>(wf[a], af[b], acc[a][b]);
-    }
-    if (++buf == ST) buf = 0;
-  }
-
-  // ---- epilogue: lane holds, per (a,b) tile, 4 consecutive columns n of row m ----
+// ---- epilogue shared by the kernels below: a lane holds, per (a,b) MFMA tile, 4 consecutive columns n of row m ----
+template <typename T, int NT, int MT>
+__device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[NT][MT], int m_base, int n_base, int M, int N,
+                                              const GemmEpilogue& ep, int fr, int fq) {
   const T* bias = reinterpret_cast<const T*>(ep.bias);
   const T* res = reinterpret_cast<const T*>(ep.res);
   const int dmodel = ep.H * 64;
 #pragma unroll
   for (int b = 0; b < MT; ++b) {
-    const int m = m0 + wm * RM + b * 16 + fr;
+    const int m = m_base + b * 16 + fr;
     if (m >= M) continue;
     long long roff = 0;
     if (res) roff = rowmap(ep.res_map, ep.res_mod > 0 ? (m % ep.res_mod) : m);
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
-      const int n = n0 + wn * RN + a * 16 + fq * 4;
+      const int n = n_base + a * 16 + fq * 4;
       if (n >= N) continue;
       float v[4];
 #pragma unroll
@@ -267,6 +194,248 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const T* __restrict_
   }
 }
 
+// The weight operand W[N,K] of every GEMM is stored FRAGMENT-MAJOR (launch_tile_weights with 16-row tiles, done once at
+// tw_finalize_weights): for n-tile t = n/16 and k-step s = k/(4E) one contiguous 1-KiB block holds the MFMA A operand exactly
+// as the 64 lanes consume it (lane = kq*16 + n%16 holds W[n][s*4E + kq*E .. +E]); element offset ((t*S + s)*64 + lane)*E with
+// S = K/(4E).  Either kernel moves whole 1-KiB fragments: kernel 1 by DMA into LDS (fragment reads are then linear and
+// conflict-free), kernel 2 straight into registers.
+
+// Kernel 1.  BM x BN block tile, WM x WN wavefronts (each owns a (BM/WM) x (BN/WN) sub-tile), both operands through an
+// ST-stage LDS ring filled by global->LDS DMA with prefetch distance ST-1.  One barrier per K tile: after it, tile kt is
+// visible to every wavefront and buffer (kt-1) % ST - consumed in the previous iteration - is free for tile kt + ST - 1.
+// Used for small M (single stream) where the grid needs small tiles.
+template <typename T, int BM, int BN, int WM, int WN, int ST>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const T* __restrict__ A, RowMap amap, const T* __restrict__ W,
+                                                              int M, int N, int K, GemmEpilogue ep) {
+  constexpr int E = ElemTraits<T>::kPer16B;  // elements per 16-B vector
+  constexpr int BKE = 8 * E;                 // elements per K tile (two MFMA k-steps)
+  constexpr int NWAVE = WM * WN;
+  constexpr int NTHR = NWAVE * 64;
+  constexpr int AV = BM * 8 / NTHR;          // 16-B vectors per thread per tile (activations)
+  constexpr int WV = BN * 8 / NTHR;          // (weights): BN/8 fragments of 64 vectors per K tile
+  constexpr int RM = BM / WM, RN = BN / WN;  // rows / columns of a wavefront's sub-tile
+  constexpr int MT = RM / 16;                // 16-row MFMA tiles per wave along M
+  constexpr int NT = RN / 16;                // along N
+  static_assert(AV >= 1 && WV >= 1 && MT >= 1 && NT >= 1, "tile / wavefront layout");
+  constexpr int STAGE = 8 * (BM + BN);       // 16-B vectors per ring stage
+  __shared__ u32x4_t lds[ST * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wn = wave % WN;  // wave position along N
+  const int wm = wave / WN;  // along M
+  const int n0 = blockIdx.x * BN;
+  const int m0 = blockIdx.y * BM;
+  const int S = K / (4 * E);
+
+  // Activations: the DMA writes the 64 lanes of a wavefront to 64 consecutive 16-B LDS slots, so the swizzle is applied on
+  // the SOURCE side: linear LDS position p (16-B units) of a tile holds row p>>3, k-slot (p&7) ^ ((row>>1)&7); 8 consecutive
+  // lanes still cover one 128-B row segment of global memory (coalesced), and the fragment read - 16 lanes = 16 consecutive
+  // rows of one k-slot, ds_read_b128 - touches every bank exactly once.
+  const T* asrc[AV];
+#pragma unroll
+  for (int i = 0; i < AV; ++i) {
+    const int p = (i * NWAVE + wave) * 64 + lane;
+    const int row = p >> 3, slot = (p & 7) ^ ((row >> 1) & 7);
+    int m = m0 + row;
+    if (m >= M) m = M - 1;
+    asrc[i] = A + rowmap(amap, m) + slot * E;
+  }
+  // Weights: DMA piece q = i*NWAVE + wave is fragment (n-tile q>>1, k-step q&1) of this K tile
+  const T* wsrc[WV];
+#pragma unroll
+  for (int i = 0; i < WV; ++i) {
+    const int q = i * NWAVE + wave;
+    const int tile = min(n0 / 16 + (q >> 1), N / 16 - 1);
+    wsrc[i] = W + (((long long)tile * S + (q & 1)) * 64 + lane) * E;
+  }
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto issue_tile = [&](int kt, int b) {
+    u32x4_t* sa = lds + b * STAGE;
+    u32x4_t* sw = sa + 8 * BM;
+#pragma unroll
+    for (int i = 0; i < AV; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + kt * BKE), (lptr_t)(sa + (i * NWAVE + wave) * 64), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < WV; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + (long long)kt * (2 * 64 * E)), (lptr_t)(sw + (i * NWAVE + wave) * 64), 16, 0, 0);
+  };
+
+  f32x4_t acc[NT][MT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / BKE;
+  const int fr = lane & 15;  // fragment row within a 16-row tile
+  const int fq = lane >> 4;  // k-slot quad
+  unsigned a_addr[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int row = wm * RM + fr;
+    a_addr[kk] = tw_lds_addr(lds) + (unsigned)(row * 8 + ((kk * 4 + fq) ^ ((row >> 1) & 7))) * 16;
+  }
+  const unsigned w_addr = tw_lds_addr(lds) + (unsigned)(8 * BM + ((wn * RN) / 16) * 2 * 64 + lane) * 16;
+#pragma unroll
+  for (int t = 0; t < ST - 1; ++t)
+    if (t < nk) issue_tile(t, t);
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed: this wavefront's own DMA by vmcnt (requests retire in order; the ST-2 younger tiles may stay in
+    // flight), the other wavefronts' by the barrier
+    if (ST > 2 && kt + ST - 2 < nk) {
+      if constexpr (ST == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AV + WV) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AV + WV)) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    tw_barrier_only();
+    if (kt + ST - 1 < nk) {
+      int nb = buf + ST - 1;
+      if (nb >= ST) nb -= ST;
+      issue_tile(kt + ST - 1, nb);
+    }
+    const unsigned stage_off = (unsigned)buf * (STAGE * 16);
+    tw_static_for<0, 2>([&](auto kkc) {
+      constexpr int kk = decltype(kkc)::value;
+      u32x4_t af[MT], wf[NT];
+      // activation fragment b: row wm*RM + b*16 + fr (the swizzle term (row>>1)&7 does not depend on b), k-slot kk*4 + fq
+      tw_static_for<0, MT>([&](auto bc) { tw_lds_read<decltype(bc)::value * 2048>(af[decltype(bc)::value], a_addr[kk] + stage_off); });
+      // weight fragment a of this wavefront: linear, 1 KiB per (n-tile, k-step)
+      tw_static_for<0, NT>([&](auto ac) { tw_lds_read<(decltype(ac)::value * 2 + kk) * 1024>(wf[decltype(ac)::value], w_addr + stage_off); });
+      tw_lds_ready<0>(af[0]);
+#pragma unroll
+      for (int b = 1; b < MT; ++b) tw_tie(af[b]);
+#pragma unroll
+      for (int a = 0; a < NT; ++a) tw_tie(wf[a]);
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc[a][b] = mfma_step<T>(wf[a], af[b], acc[a][b]);
+    });
+    if (++buf == ST) buf = 0;
+  }
+  gemm_epilogue<T, NT, MT>(acc, m0 + wm * RM, n0 + wn * RN, M, N, ep, fr, fq);
+}
+
+// Kernel 2 (large M: the batched encoder, the cross-K/V projection).  The round-1 kernel staged both operands through LDS in
+// 128 x 128 tiles and ran at 22 % of the matrix-core peak: per K tile the LDS pipe had to take 32 KB of DMA writes and serve
+// 64 fragment reads for 128 MFMAs, about as many LDS cycles as MFMA cycles, and 32 KB per 2.1 MFLOP is also right at what a CU
+// can pull from L2 (64 B/clk).  Here only the ACTIVATION tile goes through LDS; every wavefront owns a BM x 64 slab of the
+// block tile (all NW wavefronts side by side along N, none stacked along M) and takes its weight fragments - which nobody
+// else in the workgroup needs - straight from global memory into registers, 1 KiB contiguous per request, one K tile ahead.
+// Per K tile and CU: 16 KB of DMA + 32 fragment reads per wavefront for 64 MFMAs each, and (16 + 32) KB for 4.2 MFLOP.
+template <typename T, int BM, int NW, int ST>
+__global__ __launch_bounds__(NW * 64, 2) void gemm_wreg_kernel(const T* __restrict__ A, RowMap amap, const T* __restrict__ W,
+                                                             int M, int N, int K, GemmEpilogue ep) {
+  constexpr int E = ElemTraits<T>::kPer16B;
+  constexpr int BKE = 8 * E;
+  constexpr int BN = NW * 64;
+  constexpr int NTHR = NW * 64;
+  constexpr int AV = BM * 8 / NTHR;
+  constexpr int MT = BM / 16, NT = 4;
+  static_assert(AV >= 1 && (ST == 2 || ST == 3), "tile layout");
+  constexpr int STAGE = 8 * BM;
+  __shared__ u32x4_t lds[ST * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int n0 = blockIdx.x * BN + wave * 64;
+  const int m0 = blockIdx.y * BM;
+  const int S = K / (4 * E);
+  const int fr = lane & 15, fq = lane >> 4;
+
+  const T* asrc[AV];
+#pragma unroll
+  for (int i = 0; i < AV; ++i) {
+    const int p = (i * NW + wave) * 64 + lane;
+    const int row = p >> 3, slot = (p & 7) ^ ((row >> 1) & 7);
+    int m = m0 + row;
+    if (m >= M) m = M - 1;
+    asrc[i] = A + rowmap(amap, m) + slot * E;
+  }
+  const T* wsrc[NT];   // this wavefront's 4 n-tiles, k-step 0
+#pragma unroll
+  for (int a = 0; a < NT; ++a) wsrc[a] = W + ((long long)min(n0 / 16 + a, N / 16 - 1) * S * 64 + lane) * E;
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto issue_a = [&](int kt, int b) {
+    u32x4_t* sa = lds + b * STAGE;
+#pragma unroll
+    for (int i = 0; i < AV; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + kt * BKE), (lptr_t)(sa + (i * NW + wave) * 64), 16, 0, 0);
+  };
+  // two register sets for the weight fragments, used alternately (the K loop is unrolled by two): a copy "current <- next"
+  // would let the compiler sink the copy - and with it the wait for the freshly issued loads - into the MFMA block
+  u32x4_t w0[NT][2], w1[NT][2];
+  auto load_w = [&](u32x4_t (&w)[NT][2], int kt) {
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+      const T* p = wsrc[a] + (long long)kt * (2 * 64 * E);
+      tw_gload<0>(w[a][0], p);
+      tw_gload<1024>(w[a][1], p);
+    }
+  };
+
+  f32x4_t acc[NT][MT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / BKE;
+  int buf = 0;
+  unsigned a_addr[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) a_addr[kk] = tw_lds_addr(lds) + (unsigned)(fr * 8 + ((kk * 4 + fq) ^ ((fr >> 1) & 7))) * 16;
+  // one K tile: A(kt) and `cur` = W(kt) have landed (vmcnt retires in order: with three stages the younger A(kt+1) may stay
+  // in flight); then W(kt+1) -> `nxt` and A(kt+ST-1) are requested, in that order, and tile kt is multiplied
+  auto step = [&](int kt, u32x4_t (&cur)[NT][2], u32x4_t (&nxt)[NT][2]) {
+    // (requests are unconditional - past the last tile they re-fetch tile nk-1 into a free stage / the idle register set -
+    // so that the loop body is straight-line code: with requests inside branches hipcc's wait-count bookkeeping gives up
+    // at the join and drains everything, vmcnt(0), in front of the first MFMA)
+    if (ST == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AV) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int a = 0; a < NT; ++a) { tw_tie(cur[a][0]); tw_tie(cur[a][1]); }
+    tw_barrier_only();
+    load_w(nxt, min(kt + 1, nk - 1));
+    {
+      int nb = buf + ST - 1;
+      if (nb >= ST) nb -= ST;
+      issue_a(min(kt + ST - 1, nk - 1), nb);
+    }
+    const unsigned stage_off = (unsigned)buf * (STAGE * 16);
+    tw_static_for<0, 2>([&](auto kkc) {
+      constexpr int kk = decltype(kkc)::value;
+      u32x4_t af[MT];
+      tw_static_for<0, MT>([&](auto bc) { tw_lds_read<decltype(bc)::value * 2048>(af[decltype(bc)::value], a_addr[kk] + stage_off); });
+      // fragments are consumed in arrival order: MFMAs on af[b] start while af[b+1..] are still on their way
+      tw_static_for<0, MT>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        tw_lds_ready<MT - 1 - b>(af[b]);
+#pragma unroll
+        for (int a = 0; a < NT; ++a) acc[a][b] = mfma_step<T>(cur[a][kk], af[b], acc[a][b]);
+      });
+    });
+    if (++buf == ST) buf = 0;
+  };
+  // request order: A(0), W(0), A(1) | per tile: W(kt+1), A(kt+ST-1)
+  issue_a(0, 0);
+  load_w(w0, 0);
+  if (ST == 3) issue_a(min(1, nk - 1), 1);
+  for (int kt = 0; kt < nk; kt += 2) {
+    step(kt, w0, w1);
+    if (kt + 1 < nk) step(kt + 1, w1, w0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant tail requests must not outlive the LDS allocation
+  gemm_epilogue<T, NT, MT>(acc, m0, n0, M, N, ep, fr, fq);
+}
+
 }  // namespace
 
 static int gemm_env(const char* name, int dflt) {
@@ -282,35 +451,38 @@ static hipError_t gemm_go(const void* A, RowMap amap, const void* W, int M, int 
   return hipGetLastError();
 }
 
+template <typename T, int BM, int NW, int ST>
+static hipError_t gemm_wreg_go(const void* A, RowMap amap, const void* W, int M, int N, int K, const GemmEpilogue& ep, hipStream_t st) {
+  dim3 grid((N + NW * 64 - 1) / (NW * 64), (M + BM - 1) / BM);
+  hipLaunchKernelGGL((gemm_wreg_kernel<T, BM, NW, ST>), grid, dim3(NW * 64), 0, st, reinterpret_cast<const T*>(A), amap,
+                     reinterpret_cast<const T*>(W), M, N, K, ep);
+  return hipGetLastError();
+}
+
 template <typename T>
 static hipError_t gemm_dispatch(const void* A, RowMap amap, const void* W, int M, int N, int K,
                                 const GemmEpilogue& ep, hipStream_t st) {
   constexpr int E = ElemTraits<T>::kPer16B;
   if (M <= 0) return hipSuccess;
   if (K % (8 * E) != 0 || N % 64 != 0) return hipErrorInvalidValue;
-  // Tile choice by how many workgroups cover the 256 compute units (TW_GEMM_CFG forces one for experiments):
-  //   3: 256 x 128, 8 wavefronts, 3-stage ring   - large M (batched encoder): halves the LDS fill per flop
-  //   2: 128 x 128, 4 wavefronts, 3-stage ring
-  //   1: 128 x 64, 4 wavefronts, 3 stages        - mid-size (single 30 s stream): >= 1 workgroup per CU with 2x the MFMAs per
-  //                                                LDS byte of the 64 x 64 tile
-  //   0: 64 x 64, 4 wavefronts, 2 stages         - small M
+  // Tile choice (TW_GEMM_CFG forces one for experiments):
+  //   5: 128 x 256, 4 wavefronts side by side, weights straight to registers, 3-stage activation ring (kernel 2)  - large M
+  //   6: same, 2 stages;   8: 64 x 256 (narrow N at large M: twice the workgroups)
+  //   4: 128 x 128, 4 wavefronts, both operands through a 2-stage LDS ring (the round-1 shape)
+  //   1: 128 x 64;  0: 64 x 64  - small M (single stream): enough workgroups to cover the chip
   static const int forced = gemm_env("TW_GEMM_CFG", -1);
-  const long long b256 = (long long)((M + 255) / 256) * ((N + 127) / 128);
+  static const int narrow = gemm_env("TW_GEMM_NARROW", 8);   // tile config for N <= 2048 at large M (experiments)
   const long long b128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
-  const long long b12864 = (long long)((M + 127) / 128) * (N / 64);
   int cfg;
   if (forced >= 0) cfg = forced;
-  else if (N % 128 == 0 && b256 >= 512) cfg = 3;
-  else if (N % 128 == 0 && b128 >= 384) cfg = 2;
-  else if (b12864 >= 200) cfg = 1;
+  else if (N % 256 == 0 && b128 >= 384) cfg = (N <= 2048) ? narrow : 5;
+  else if (M > 64) cfg = 1;
   else cfg = 0;
-  if (sizeof(T) == 4 && cfg == 3) cfg = 2;  // strict-f32 contexts: parity mode, the 8-wavefront tile is not instantiated
   switch (cfg) {
-    case 3:
-      if constexpr (sizeof(T) == 2) return gemm_go<T, 256, 128, 4, 2, 3>(A, amap, W, M, N, K, ep, st);
-      return hipErrorInvalidValue;
-    case 2: return gemm_go<T, 128, 128, 2, 2, 3>(A, amap, W, M, N, K, ep, st);
-    case 4: return gemm_go<T, 128, 128, 2, 2, 2>(A, amap, W, M, N, K, ep, st);   // round-1 kernel (A/B runs)
+    case 5: return gemm_wreg_go<T, 128, 4, 3>(A, amap, W, M, N, K, ep, st);
+    case 6: return gemm_wreg_go<T, 128, 4, 2>(A, amap, W, M, N, K, ep, st);
+    case 8: return gemm_wreg_go<T, 64, 4, 3>(A, amap, W, M, N, K, ep, st);     // narrow N: twice the workgroups
+    case 4: return gemm_go<T, 128, 128, 2, 2, 2>(A, amap, W, M, N, K, ep, st);
     case 1: return gemm_go<T, 128, 64, 2, 2, 3>(A, amap, W, M, N, K, ep, st);
     default: return gemm_go<T, 64, 64, 2, 2, 2>(A, amap, W, M, N, K, ep, st);
   }

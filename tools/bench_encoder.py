@@ -34,3 +34,15 @@ for case in args.cases.split(","):
     eng.close()
     del eng
     torch.cuda.empty_cache()
+if os.environ.get("TW_TORCH_REF"):
+    # comparison only (never on the product path): what the vendor library reaches on the encoder's GEMM shapes
+    for (M, N, K) in [(8000, 5120, 1280), (8000, 1280, 5120), (8000, 3840, 1280), (8000, 1280, 1280), (1500, 5120, 1280), (500, 5120, 1280)]:
+        a = torch.randn((M, K), device=dev, dtype=torch.bfloat16); w = torch.randn((N, K), device=dev, dtype=torch.bfloat16)
+        for _ in range(3): torch.matmul(a, w.t())
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): torch.matmul(a, w.t())
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        print(f"torch.matmul (hipBLASLt, comparison only) M={M} N={N} K={K}: {ms*1e3:.1f} us = {2*M*N*K/ms/1e9:.0f} TF/s", flush=True)
