@@ -499,6 +499,18 @@ def mx8_quant_dequant(x: np.ndarray) -> np.ndarray:
     return (q * X).astype(np.float32).reshape(x.shape)
 
 
+def kv8_quant_dequant(x: np.ndarray) -> np.ndarray:
+    """fp8 cross-attention K / V^T caches of the TW_BF16_MXFP8 engine (thewhisper_amd/csrc/k_gemm.hip: gemm_epilogue_kv8):
+    per (stream, head, key) the 64 head dims share one power-of-two scale 2^(sb-127), sb = max(E - 7, 1) with E the biased
+    exponent of the largest bf16 magnitude (the rule of mx8_quant_dequant), elements RNE to e4m3.  Last axis = head dim."""
+    xb = bf16_round(x)
+    amax = np.abs(xb).max(axis=-1, keepdims=True)
+    Eb = np.floor(np.log2(np.maximum(amax, 2.0**-126))).astype(np.int64) + 127
+    sb = np.maximum(Eb - 7, 1)
+    X = np.ldexp(1.0, sb - 127)
+    return (e4m3_rne(xb.astype(np.float64) / X) * X).astype(np.float32)
+
+
 class OracleWhisperMXFP8(OracleWhisper):
     """bf16 activations, decoder projection weights in MXFP8 with the pre-LayerNorm folded into the weights, as the
     TW_BF16_MXFP8 engine computes:  y = rstd * (Q(x) . Q(W')^T - mean * gW) + cb,  W' = bf16(g * W)."""
@@ -544,14 +556,15 @@ class OracleWhisperMXFP8(OracleWhisper):
         return self._folded_apply(x, d + ".layer_norm", d + ".embed_tokens.weight", None)
 
     def new_cache(self, enc):
-        """Cross K/V as the engine's bf16 GEMM produces them: bf16 encoder states x bf16 weights, fp32 accumulation, bf16 store."""
+        """Cross K/V as the engine's GEMM produces them: bf16 encoder states x bf16 weights, fp32 accumulation, rounded to bf16
+        and stored as e4m3 with one power-of-two scale per (key, head) (kv8_quant_dequant)."""
         r = bf16_round
         e = r(enc)
         ck, cv = [], []
         for i in range(self.dims.dec_layers):
             p = f"model.decoder.layers.{i}.encoder_attn"
-            ck.append(self._heads(r(e @ r(self.w[p + ".k_proj.weight"]).T)))
-            cv.append(self._heads(r(e @ r(self.w[p + ".v_proj.weight"]).T + r(self.w[p + ".v_proj.bias"]))))
+            ck.append(kv8_quant_dequant(self._heads(r(e @ r(self.w[p + ".k_proj.weight"]).T))))
+            cv.append(kv8_quant_dequant(self._heads(r(e @ r(self.w[p + ".v_proj.weight"]).T + r(self.w[p + ".v_proj.bias"])))))
         b = enc.shape[0]
         empty = lambda: np.zeros((b, self.dims.heads, 0, self.dims.head_dim), dtype=np.float32)  # noqa: E731
         L = self.dims.dec_layers

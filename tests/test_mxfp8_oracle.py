@@ -64,3 +64,22 @@ def test_mxfp8_oracle_close_to_exact_oracle():
     la, lb = a.decode(ids, ca)[0], b.decode(ids, cb)[0]
     err = np.linalg.norm(la - lb) / np.linalg.norm(la)
     assert 1e-3 < err < 1e-1
+
+
+def test_kv8_per_key_scales():
+    """fp8 cross-K/V restatement: one power-of-two scale per (key, head) row of 64 dims, e4m3 elements."""
+    rng = np.random.default_rng(2)
+    x = wo.bf16_round(rng.standard_normal((2, 3, 5, 64)).astype(np.float32) * rng.uniform(1e-3, 50.0, (2, 3, 5, 1)).astype(np.float32))
+    q = wo.kv8_quant_dequant(x)
+    amax = np.abs(x).max(axis=-1, keepdims=True)
+    big = np.abs(x) > amax * 2.0**-6
+    assert (np.abs(q - x)[big] / np.abs(x)[big]).max() <= 2.0**-4 + 1e-6
+    assert np.array_equal(wo.kv8_quant_dequant(q), q)                                  # idempotent
+    assert np.array_equal(wo.kv8_quant_dequant(x * 4.0), q * 4.0)                      # power-of-two scaling commutes
+    y = x.copy()
+    y[0, 1, 2] *= 1024.0                                                               # another key's scale is untouched
+    q2 = wo.kv8_quant_dequant(y)
+    mask = np.ones(x.shape[:3], bool)
+    mask[0, 1, 2] = False
+    assert np.array_equal(q2[mask], q[mask])
+    assert np.array_equal(wo.kv8_quant_dequant(np.zeros((1, 1, 2, 64), np.float32)), np.zeros((1, 1, 2, 64), np.float32))

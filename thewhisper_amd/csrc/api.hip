@@ -69,6 +69,7 @@ struct tw_ctx {
 
   // decoder state
   void *self_k = nullptr, *self_v = nullptr, *cross_k = nullptr, *cross_v = nullptr;
+  unsigned char *cross_ksc = nullptr, *cross_vsc = nullptr;  // MXFP8 contexts: per-key scale bytes of the fp8 cross K / V^T caches [Ld][B][H][Tp]
   void *dx0 = nullptr, *dx1 = nullptr, *dq = nullptr, *datt = nullptr, *dh = nullptr;
   float* logits = nullptr;
   float* align = nullptr;
@@ -347,8 +348,14 @@ int tw_create(const tw_config* cfg, tw_ctx** out) {
   const size_t Pp = (P + 63) / 64 * 64;
   CALLOC(c->self_k, Ld * B * Pp * d * e, true);
   CALLOC(c->self_v, Ld * B * Pp * d * e, true);
-  CALLOC(c->cross_k, Ld * B * Tp * d * e, true);
-  CALLOC(c->cross_v, Ld * B * Tp * d * e, true);
+  // cross K / V^T: bf16 (f32) fragment-major, or - MXFP8 contexts - e4m3 with one scale byte per (key, head) (tw_common.h)
+  const size_t ckv_e = c->w8 ? 1 : e;
+  CALLOC(c->cross_k, Ld * B * Tp * d * ckv_e, true);
+  CALLOC(c->cross_v, Ld * B * Tp * d * ckv_e, true);
+  if (c->w8) {
+    CALLOC(c->cross_ksc, Ld * B * H * Tp, true);
+    CALLOC(c->cross_vsc, Ld * B * H * Tp, true);
+  }
   // per-token decoder activations that feed a projection are fragment-major in groups of 16 streams (tw_xt_index)
   const size_t Bg = (B + 15) / 16 * 16;  // whole groups of 16 streams
   CALLOC(c->dx0, Bg * d * e, true); CALLOC(c->dx1, Bg * d * e, true); CALLOC(c->dq, B * d * e, true);
@@ -681,9 +688,13 @@ int tw_cross_kv(tw_ctx* c, int32_t B, void* stream) {
   for (int l = 0; l < c->Ld; ++l) {
     const LayerW& L = c->dec[l];
     GemmEpilogue ep{};
-    ep.bias = L.bkv_c; ep.mode = EPI_KV_CROSS; ep.T = T; ep.Tp = c->Tp; ep.H = c->H;
-    ep.out = at(c->cross_k, per_layer * l, c->esz);
-    ep.out2 = at(c->cross_v, per_layer * l, c->esz);
+    ep.bias = L.bkv_c; ep.mode = c->w8 ? EPI_KV_CROSS8 : EPI_KV_CROSS; ep.T = T; ep.Tp = c->Tp; ep.H = c->H;
+    ep.out = at(c->cross_k, per_layer * l, c->w8 ? 1 : c->esz);
+    ep.out2 = at(c->cross_v, per_layer * l, c->w8 ? 1 : c->esz);
+    if (c->w8) {
+      ep.out3 = c->cross_ksc + (size_t)c->Bmax * c->H * c->Tp * l;
+      ep.out4 = c->cross_vsc + (size_t)c->Bmax * c->H * c->Tp * l;
+    }
     HIPCHK(c, launch_gemm(c->dtype, c->enc_out, plain_rows(d), L.wkv_c, B * T, 2 * d, d, ep, st));
   }
   toc(c, 2, st);
@@ -731,9 +742,10 @@ int decode_core(tw_ctx* c, int B, hipStream_t st) {
       a.y = c->dq; a.ldy = d;
       HIPCHK(c, launch_gemv(dt, a, st));
     }
-    HIPCHK(c, launch_dec_cross_attn(dt, c->dq, at(c->cross_k, cross_layer * l, e), at(c->cross_v, cross_layer * l, e),
+    HIPCHK(c, launch_dec_cross_attn(dt, c->dq, at(c->cross_k, cross_layer * l, c->w8 ? 1 : e), at(c->cross_v, cross_layer * l, c->w8 ? 1 : e),
                                     c->datt, B, H, T, c->Tp, c->Ha > 0 ? c->align_slot + (size_t)l * H : nullptr, c->align, c->Ha,
-                                    P, c->stt, st));
+                                    P, c->stt, c->w8 ? c->cross_ksc + (size_t)c->Bmax * H * c->Tp * l : nullptr,
+                                    c->w8 ? c->cross_vsc + (size_t)c->Bmax * H * c->Tp * l : nullptr, st));
     {
       GemvArgs a{};
       a.x = c->datt; a.ldx = d; a.W = L.wo_c; a.wscale = L.s_oc; a.tr = L.tr_oc; a.bias = L.bo_c; a.N = d; a.K = d; a.B = B; a.res = xmid; a.ldres = d;

@@ -671,6 +671,142 @@ __device__ __forceinline__ float attn_mfma_block(const T* __restrict__ q, const 
   return inv;
 }
 
+// fp8 variant of attn_mfma_block for the cross attention of TW_BF16_MXFP8 contexts (bf16 activations): K and V^T are stored as
+// e4m3 with one power-of-two scale byte per (key, head) (layouts: tw_kf8_index / tw_vtf8_index, written by gemm_epilogue_kv8),
+// which halves the bytes the step has to stream - at 16 streams the cross-attention K/V are as many bytes as all weights.
+// The products stay bf16 MFMAs: fragments are widened in registers (v_cvt_scalef32_pk_bf16_fp8; the K scale is applied by
+// that instruction, lane = key; the V scale multiplies the probability of its key before the P.V operand is packed), so q and
+// the probabilities are NOT quantised.  A 16-B fp8 vector holds 16 dims (K) / 16 keys (V^T), i.e. two bf16 MFMA operands:
+// the contraction index of an MFMA is order-free, so the q / probability operands are simply gathered in the same order.
+__device__ __forceinline__ void kv8_widen(const u32x4_t& raw, float X, u32x4_t& lo, u32x4_t& hi) {
+  lo[0] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)raw[0], X, false));
+  lo[1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)raw[0], X, true));
+  lo[2] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)raw[1], X, false));
+  lo[3] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)raw[1], X, true));
+  hi[0] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)raw[2], X, false));
+  hi[1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)raw[2], X, true));
+  hi[2] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)raw[3], X, false));
+  hi[3] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)raw[3], X, true));
+}
+
+template <int NW, bool SINGLE>
+__device__ __forceinline__ float attn_mfma_block_kv8(const bf16_t* __restrict__ q, const unsigned char* __restrict__ kf8,
+                                                     const unsigned char* __restrict__ vtf8, const unsigned char* __restrict__ ksc,
+                                                     const unsigned char* __restrict__ vsc, int n_keys, int n_bound, float* sc,
+                                                     float* scv, float* red, bf16_t* __restrict__ out_base, int out_j, int out_k0) {
+  typedef bf16_t T;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, kq = lane >> 4;
+  const int n_chunks = SINGLE ? 1 : (n_bound + NW * 64 - 1) / (NW * 64);
+  const int last64 = n_bound / 64 - 1;
+  u32x4_t qf[2], kraw[4], vraw[4];
+  unsigned ksb[4];
+  unsigned vsb = 0;
+  auto load_k = [&](int g64) {  // 64 keys = 4 tiles of 1 KiB + their 64 scale bytes
+    const int g = min(g64, last64);
+    const unsigned char* p = kf8 + ((long long)g * 4 * 64 + lane) * 16;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) kraw[a] = *reinterpret_cast<const u32x4_t*>(p + a * 1024);
+    const unsigned s4 = *reinterpret_cast<const unsigned*>(ksc + g * 64 + fr * 4);   // [group][key % 16][tile]: one load
+#pragma unroll
+    for (int a = 0; a < 4; ++a) ksb[a] = (s4 >> (8 * a)) & 0xffu;
+  };
+  auto load_v = [&](int g64) {  // 64 keys x 64 dims = 4 dim tiles of 1 KiB; lane `lane` also fetches the scale of ITS key
+    const int g = min(g64, last64);
+    const unsigned char* p = vtf8 + ((long long)g * 4 * 64 + lane) * 16;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vraw[dt] = *reinterpret_cast<const u32x4_t*>(p + dt * 1024);
+    vsb = vsc[g * 64 + lane];
+  };
+  qf[0] = *reinterpret_cast<const u32x4_t*>(q + kq * 16);
+  qf[1] = *reinterpret_cast<const u32x4_t*>(q + kq * 16 + 8);
+  load_k(wave);
+  if (SINGLE) load_v(wave);
+  __builtin_amdgcn_sched_barrier(0);
+
+  float m = -1.0e30f;
+  for (int c = 0; c < n_chunks; ++c) {
+    const int g64 = c * NW + wave;
+    if (c > 0) load_k(g64);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      u32x4_t k0, k1;
+      kv8_widen(kraw[a], __builtin_bit_cast(float, ksb[a] << 23), k0, k1);
+      f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      acc = sk_mfma<T>(k0, qf[0], acc);
+      acc = sk_mfma<T>(k1, qf[1], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = g64 * 64 + a * 16 + kq * 4 + r;
+        const float sv = (t < n_keys) ? acc[r] : -1.0e30f;
+        m = fmaxf(m, sv);
+        if (fr == 0 && t < n_bound) sc[t] = sv;
+      }
+    }
+  }
+  m = tw_xor32_max(tw_xor16_max(m));
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  float M = red[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) M = fmaxf(M, red[w]);
+
+  f32x4_t o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float ls = 0.f;
+  for (int c = 0; c < n_chunks; ++c) {
+    const int g64 = c * NW + wave;
+    if (!SINGLE) load_v(g64);
+    const int t0 = g64 * 64 + lane;  // one key per lane
+    float pr = 0.f;
+    if (t0 < n_bound) {
+      pr = (t0 < n_keys) ? expf(sc[t0] - M) : 0.f;
+      sc[t0] = pr;                                               // plain probability: alignment rows, normaliser
+      scv[t0] = pr * __builtin_bit_cast(float, vsb << 23);       // probability x the key's V scale: the P.V operand
+    }
+    ls += pr;
+    u32x4_t v0[4], v1[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) kv8_widen(vraw[dt], 1.0f, v0[dt], v1[dt]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {   // operand j of lane (kq, .): keys kq*16 + j*8 .. +7 of this 64-key group
+      float pv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int t = g64 * 64 + kq * 16 + j * 8 + e;
+        pv[e] = (t < n_bound) ? scv[t] : 0.f;   // same wavefront wrote these: LDS operations of a wavefront stay in order
+      }
+      const u32x4_t pf = pack16<T>(pv);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt] = sk_mfma<T>(j == 0 ? v0[dt] : v1[dt], pf, o[dt]);
+    }
+  }
+  ls = tw_wave_sum(ls);
+  float* wl = red + NW;
+  float* wo = red + 2 * NW;
+  if (lane == 0) wl[wave] = ls;
+  if (fr == 0) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wo[wave * 64 + dt * 16 + kq * 4 + r] = o[dt][r];
+  }
+  __syncthreads();
+  float L = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) L += wl[w];
+  const float inv = 1.0f / L;
+  if (tid < 64) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += wo[w * 64 + tid];
+    out_base[tw_xt_index<T>(out_j, out_k0 + tid)] = (T)(v * inv);
+  }
+  return inv;
+}
+
 // q [B, H*64] row-major; kc / vc per (stream, head): `rows` (multiple of 64) keys of K fragment-major / V^T fragment-major
 template <typename T, bool SINGLE>
 __global__ __launch_bounds__(256) void dec_self_attn_kernel(const T* __restrict__ q, const T* __restrict__ kc,
@@ -702,6 +838,32 @@ __global__ __launch_bounds__(512) void dec_cross_attn_kernel(const T* __restrict
   const long long base = ((long long)b * H + h) * Tp * 64;
   const float inv = attn_mfma_block<T, 8, SINGLE>(q + ((long long)b * H + h) * 64, ck + base, cv + base, Tlen, Tp, sc, red,
                                                   out + (long long)(b >> 4) * 16 * H * 64, b & 15, h * 64);
+  const int slot = align_slot ? align_slot[h] : -1;
+  if (slot >= 0) {  // A11 side output: softmax row of an alignment head
+    __syncthreads();
+    float* row = align + (((long long)b * Ha + slot) * P + stt->pos) * Tlen;
+    for (int t = threadIdx.x; t < Tlen; t += 512) row[t] = sc[t] * inv;
+  }
+}
+
+template <bool SINGLE>
+__global__ __launch_bounds__(512) void dec_cross_attn_kv8_kernel(const bf16_t* __restrict__ q, const unsigned char* __restrict__ ck,
+                                                                  const unsigned char* __restrict__ cv,
+                                                                  const unsigned char* __restrict__ ksc,
+                                                                  const unsigned char* __restrict__ vsc, bf16_t* __restrict__ out,
+                                                                  int H, int Tlen, int Tp, const int* __restrict__ align_slot,
+                                                                  float* __restrict__ align, int Ha, int P,
+                                                                  const DecState* __restrict__ stt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* sc = reinterpret_cast<float*>(smem);  // [Tp] scores -> unnormalised probabilities
+  float* scv = sc + Tp;                        // [Tp] probabilities x V scale
+  __shared__ float red[2 * 8 + 8 * 64];
+  asm volatile("" ::"s"(q), "s"(ck), "s"(cv), "s"(ksc), "s"(vsc), "s"(out), "s"(H), "s"(Tlen), "s"(Tp), "s"(align_slot), "s"(align),
+               "s"(Ha), "s"(P), "s"(stt));
+  const int h = blockIdx.x, b = blockIdx.y;
+  const long long hb = ((long long)b * H + h) * Tp;
+  const float inv = attn_mfma_block_kv8<8, SINGLE>(q + ((long long)b * H + h) * 64, ck + hb * 64, cv + hb * 64, ksc + hb, vsc + hb,
+                                                   Tlen, Tp, sc, scv, red, out + (long long)(b >> 4) * 16 * H * 64, b & 15, h * 64);
   const int slot = align_slot ? align_slot[h] : -1;
   if (slot >= 0) {  // A11 side output: softmax row of an alignment head
     __syncthreads();
@@ -1079,10 +1241,20 @@ hipError_t launch_dec_self_attn(int dtype, const void* q, const void* kc, const 
 
 hipError_t launch_dec_cross_attn(int dtype, const void* q, const void* ck, const void* cv, void* out, int B, int H,
                                  int T, int Tp, const int* align_slot_for_head, float* align, int Ha, int P,
-                                 const DecState* stt, hipStream_t st) {
+                                 const DecState* stt, const unsigned char* ksc, const unsigned char* vsc, hipStream_t st) {
   if (Tp % 64 != 0 || Tp < T) return hipErrorInvalidValue;
-  const size_t lds = (size_t)Tp * sizeof(float);
   const bool single = Tp <= 512;
+  if (ksc || vsc) {  // fp8 K / V^T caches with per-key scales (TW_BF16_MXFP8 contexts)
+    if (!ksc || !vsc || dtype != 1) return hipErrorInvalidValue;
+    const size_t lds8 = (size_t)Tp * sizeof(float) * 2;
+#define CA8_GO(SV) hipLaunchKernelGGL((dec_cross_attn_kv8_kernel<SV>), dim3(H, B), dim3(512), lds8, st, (const bf16_t*)q, \
+                                      (const unsigned char*)ck, (const unsigned char*)cv, ksc, vsc, (bf16_t*)out, H, T, Tp,      \
+                                      align_slot_for_head, align, Ha, P, stt)
+    if (single) CA8_GO(true); else CA8_GO(false);
+#undef CA8_GO
+    return hipGetLastError();
+  }
+  const size_t lds = (size_t)Tp * sizeof(float);
 #define CA_GO(TT, SV) hipLaunchKernelGGL((dec_cross_attn_kernel<TT, SV>), dim3(H, B), dim3(512), lds, st, (const TT*)q, (const TT*)ck, \
                                          (const TT*)cv, (TT*)out, H, T, Tp, align_slot_for_head, align, Ha, P, stt)
   if (dtype == 1) { if (single) CA_GO(bf16_t, true); else CA_GO(bf16_t, false); }

@@ -194,6 +194,80 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[NT][MT], int 
   }
 }
 
+// Epilogue of the cross-K/V projection in TW_BF16_MXFP8 contexts: the wavefront's 64 columns are exactly one head of K or of
+// V, so the per-key maximum over the head is 16 in-lane values and two lane swaps; every key gets one power-of-two scale
+// byte (sb = max(E - 7, 1), E = biased exponent of the maximum: the rule of sk_quant_mx8 in k_decode.hip) and its 64 values
+// are stored as e4m3(bf16(v) / 2^(sb-127)) in the fp8 fragment layouts of tw_common.h.
+typedef short tw_s16x2 __attribute__((ext_vector_type(2)));
+template <typename T, int NT, int MT>
+__device__ __forceinline__ void gemm_epilogue_kv8(const f32x4_t (&acc)[NT][MT], int m_base, int n_base, int M, int N,
+                                                  const GemmEpilogue& ep, int fr, int fq) {
+  static_assert(NT == 4, "one 64-column head per wavefront");
+  if constexpr (sizeof(T) == 2) {
+    const T* bias = reinterpret_cast<const T*>(ep.bias);
+    const int dmodel = ep.H * 64;
+    if (n_base >= N) return;
+    const int seg = n_base / dmodel;                 // 0: K, 1: V
+    const int h = (n_base - seg * dmodel) >> 6;
+    float bv[NT][4];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+      Vec4<T> b4;
+      if (bias) b4.load(bias + n_base + a * 16 + fq * 4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[a][r] = bias ? b4.get(r) : 0.f;
+    }
+#pragma unroll
+    for (int b = 0; b < MT; ++b) {
+      const int m = m_base + b * 16 + fr;
+      const int mc = min(m, M - 1);
+      const int bidx = mc / ep.T, t = mc % ep.T;
+      bf16x2_t pk[NT][2];
+      unsigned amax = 0;
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        pk[a][0] = bf16x2_t{(bf16_t)(acc[a][b][0] + bv[a][0]), (bf16_t)(acc[a][b][1] + bv[a][1])};
+        pk[a][1] = bf16x2_t{(bf16_t)(acc[a][b][2] + bv[a][2]), (bf16_t)(acc[a][b][3] + bv[a][3])};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const unsigned u = __builtin_bit_cast(unsigned, pk[a][j]) & 0x7fff7fffu;
+          amax = max(amax, max(u & 0xffffu, u >> 16));
+        }
+      }
+      // the 64 columns of row m live in the 4 lanes fr, fr+16, fr+32, fr+48
+      float am = __builtin_bit_cast(float, amax << 16);   // the bf16 pattern as the float32 it denotes (a normal number)
+      am = tw_xor32_max(tw_xor16_max(am));
+      amax = __builtin_bit_cast(unsigned, am) >> 16;
+      const int sb = max((int)(amax >> 7) - 7, 1);
+      const float X = __builtin_bit_cast(float, (unsigned)sb << 23);
+      if (m < M) {
+        const long long hb = (long long)(bidx * ep.H + h) * ep.Tp;       // (stream, head) slab: Tp*64 bytes, Tp scale bytes
+        unsigned char* dst = reinterpret_cast<unsigned char*>(seg == 0 ? ep.out : ep.out2) + hb * 64;
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+          tw_s16x2 q = {0, 0};
+          q = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(q, pk[a][0], X, false);
+          q = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(q, pk[a][1], X, true);
+          const unsigned w = __builtin_bit_cast(unsigned, q);
+          const int c = a * 16 + fq * 4;
+          if (seg == 0) {
+            *reinterpret_cast<unsigned*>(dst + tw_kf8_index(t, c)) = w;     // 4 dims of one key: 4 consecutive bytes
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[tw_vtf8_index(t, c + r)] = (unsigned char)(w >> (8 * r));
+          }
+        }
+        // K scales are stored [64-key group][key % 16][key tile] so that a lane of the attention kernel (one key row of each
+        // of the 4 tiles) fetches its four scale bytes with ONE 32-bit load; V scales in key order (lane = key there)
+        if (fq == 0) {
+          if (seg == 0) reinterpret_cast<unsigned char*>(ep.out3)[hb + (t & ~63) + (t & 15) * 4 + ((t >> 4) & 3)] = (unsigned char)sb;
+          else reinterpret_cast<unsigned char*>(ep.out4)[hb + t] = (unsigned char)sb;
+        }
+      }
+    }
+  }
+}
+
 // The weight operand W[N,K] of every GEMM is stored FRAGMENT-MAJOR (launch_tile_weights with 16-row tiles, done once at
 // tw_finalize_weights): for n-tile t = n/16 and k-step s = k/(4E) one contiguous 1-KiB block holds the MFMA A operand exactly
 // as the 64 lanes consume it (lane = kq*16 + n%16 holds W[n][s*4E + kq*E .. +E]); element offset ((t*S + s)*64 + lane)*E with
@@ -433,7 +507,8 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_wreg_kernel(const T* __restri
     if (kt + 1 < nk) step(kt + 1, w1, w0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant tail requests must not outlive the LDS allocation
-  gemm_epilogue<T, NT, MT>(acc, m0, n0, M, N, ep, fr, fq);
+  if (ep.mode == EPI_KV_CROSS8) gemm_epilogue_kv8<T, NT, MT>(acc, m0, n0, M, N, ep, fr, fq);
+  else gemm_epilogue<T, NT, MT>(acc, m0, n0, M, N, ep, fr, fq);
 }
 
 }  // namespace
@@ -471,9 +546,13 @@ static hipError_t gemm_dispatch(const void* A, RowMap amap, const void* W, int M
   //   4: 128 x 128, 4 wavefronts, both operands through a 2-stage LDS ring (the round-1 shape)
   //   1: 128 x 64;  0: 64 x 64  - small M (single stream): enough workgroups to cover the chip
   static const int forced = gemm_env("TW_GEMM_CFG", -1);
-  static const int narrow = gemm_env("TW_GEMM_NARROW", 8);   // tile config for N <= 2048 at large M (experiments)
+  static const int narrow = gemm_env("TW_GEMM_NARROW", 5);   // tile config for N <= 2048 at large M (experiments)
   const long long b128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
   int cfg;
+  if (ep.mode == EPI_KV_CROSS8) {   // fp8 cross-K/V epilogue: one head per wavefront, i.e. kernel 2 whatever the shape
+    if (sizeof(T) != 2 || N % 64 != 0) return hipErrorInvalidValue;
+    return gemm_wreg_go<T, 128, 4, 3>(A, amap, W, M, N, K, ep, st);
+  }
   if (forced >= 0) cfg = forced;
   else if (N % 256 == 0 && b128 >= 384) cfg = (N <= 2048) ? narrow : 5;
   else if (M > 64) cfg = 1;

@@ -72,6 +72,17 @@ __device__ __forceinline__ long long tw_vtf_index(int t, int c) {
   return ((long long)((t / (4 * E)) * 4 + (c >> 4)) * 64 + ((t / E) & 3) * 16 + (c & 15)) * E + (t % E);
 }
 
+// fp8 (e4m3) variants of the cross-attention caches (TW_BF16_MXFP8 contexts), byte offsets inside one (stream, head) slab of
+// Tp*64 bytes; every key carries one power-of-two scale byte per head (value = fp8 * 2^(sb - 127), the rule of sk_quant_mx8):
+//  K  : 16-key tile t/16 = 1 KiB, lane = (c/16)*16 + t%16 holds dims 16*(c/16) .. +15 of key t          (A operand of Q.K^T)
+//  V^T: 64-key group, dim tile c/16 = 1 KiB, lane = ((t%64)/16)*16 + c%16 holds 16 consecutive keys of dim c   (A of P.V)
+__device__ __forceinline__ long long tw_kf8_index(int t, int c) {
+  return ((long long)(t >> 4) * 64 + (c >> 4) * 16 + (t & 15)) * 16 + (c & 15);
+}
+__device__ __forceinline__ long long tw_vtf8_index(int t, int c) {
+  return (((long long)(t >> 6) * 4 + (c >> 4)) * 64 + ((t & 63) >> 4) * 16 + (c & 15)) * 16 + (t & 15);
+}
+
 // Affine map from a logical GEMM row m to an element offset:  (m / rpb) * bstride + (m % rpb) * rstride.
 // Lets one GEMM read convolution windows as overlapping rows of a padded token-major buffer and
 // write into padded / per-batch layouts without im2col copies.
@@ -83,7 +94,7 @@ struct RowMap {
 static inline RowMap plain_rows(long long ld) { return RowMap{1 << 30, 0, ld}; }
 
 // GEMM epilogue descriptor: v = acc + bias[n]; GELU?; + res[rmap(m % res_mod) + n]; store by mode.
-enum { EPI_ROWMAJOR = 0, EPI_HEADSPLIT = 1, EPI_QKV_ENC = 2, EPI_KV_CROSS = 3 };
+enum { EPI_ROWMAJOR = 0, EPI_HEADSPLIT = 1, EPI_QKV_ENC = 2, EPI_KV_CROSS = 3, EPI_KV_CROSS8 = 4 };
 struct GemmEpilogue {
   const void* bias;   // [N] in T, may be null
   int gelu;           // exact erf GELU
@@ -99,7 +110,8 @@ struct GemmEpilogue {
   int H;
   void* out;          // primary output (q / k of cross)
   void* out2;         // k (QKV_ENC) or v (KV_CROSS)
-  void* out3;         // v transposed (QKV_ENC)
+  void* out3;         // v transposed (QKV_ENC); KV_CROSS8: per-key scale bytes of K [B][H][Tp]
+  void* out4;         // KV_CROSS8: per-key scale bytes of V^T [B][H][Tp]
 };
 
 // ---- launchers (one per kernel family); all enqueue on `st` and return hipGetLastError() ----
@@ -183,9 +195,10 @@ hipError_t launch_dec_self_attn(int dtype, const void* q, const void* kc, const 
                                 int key_bound, const DecState* stt, hipStream_t st);
 // cross attention over cached encoder K/V: ck/cv per (stream, head) Tp keys fragment-major; out fragment-major; align rows:
 // for head h with align_slot[h] >= 0 write the softmax row to align[((b*Ha + slot)*P + pos)*T + t]
+// ksc / vsc non-null: ck / cv are the fp8 caches above (bf16 contexts only), these their per-key scale bytes [B][H][Tp]
 hipError_t launch_dec_cross_attn(int dtype, const void* q, const void* ck, const void* cv, void* out, int B, int H,
                                  int T, int Tp, const int* align_slot_for_head, float* align, int Ha, int P,
-                                 const DecState* stt, hipStream_t st);
+                                 const DecState* stt, const unsigned char* ksc, const unsigned char* vsc, hipStream_t st);
 
 struct SamplerPartial { float bt_v; int bt_i; float bs_v; int bs_i; float sum; int pad_[3]; };  // per vocabulary slice
 struct SamplerArgs {   // A10 + argmax + bookkeeping
