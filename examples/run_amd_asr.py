@@ -23,14 +23,22 @@ generate_kwargs = {"num_beams": 1, "do_sample": False, "use_cache": True, "langu
 chunk_length_s = 10
 
 if args.synthetic:
-    from oracle import hf_reference as hr  # test infrastructure, used here only to fabricate a model offline
-    from oracle import whisper_oracle as wo
+    import numpy as np
+    from transformers import WhisperFeatureExtractor
 
-    dims = wo.PRESETS["micro"]
-    pipe = ASRPipeline(hr.build_hf_model(dims, wo.make_weights(dims, 0)),
-                       feature_extractor=hr.build_feature_extractor(dims, chunk_length_s), tokenizer=hr.build_tokenizer(dims),
-                       chunk_length_s=chunk_length_s, batch_size=4, device="cuda", torch_dtype=torch.bfloat16)
-    audio = wo.synth_audio(16000 * 25, 5, "speechlike")
+    from thewhisper_amd import synthetic
+    from thewhisper_amd.engine import WhisperEngine
+
+    # no checkpoint, no tokenizer files: a model of the tiny.en SHAPE with random weights generated on the device
+    dims = synthetic.DIMS["tiny.en"]
+    heads = [tuple(h) for h in synthetic.default_alignment_heads(dims["dec_layers"], dims["heads"])]
+    eng = WhisperEngine(dims, 50 * chunk_length_s, max_batch=4, dtype="bf16", alignment_heads=heads)
+    eng.load_state_dict(synthetic.random_state_dict(dims, torch.device("cuda", 0), seed=0))
+    pipe = ASRPipeline(synthetic.skeleton_model(dims, device="cuda:0", dtype=torch.bfloat16, alignment_heads=heads),
+                       feature_extractor=WhisperFeatureExtractor(feature_size=dims["n_mels"], chunk_length=chunk_length_s),
+                       tokenizer=synthetic.build_tokenizer(dims["vocab"]), chunk_length_s=chunk_length_s, batch_size=4,
+                       device="cuda:0", torch_dtype=torch.bfloat16, engine=eng)
+    audio = (np.random.default_rng(5).standard_normal(16000 * 25) * 0.1).astype(np.float32)
     generate_kwargs["max_new_tokens"] = 32
 else:
     from librosa import load, resample
