@@ -3,10 +3,12 @@
 #include "../../include/thewhisper.h"
 #include "tw_common.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <set>
 #include <string>
 #include <vector>
@@ -91,7 +93,9 @@ struct tw_ctx {
   int* n_cols = nullptr;
 
   // graph replay of one decode step
-  hipGraphExec_t step_graph = nullptr;
+  // one captured step per 64-key bucket of the self-attention length (the step at position s only has to read keys
+  // [0, roundup(s + 1, 64)), and the host knows s): fewer bytes per step than one graph sized for the longest sequence
+  std::map<std::string, hipGraphExec_t> step_graphs;
   std::string step_graph_key;
 
   // timing
@@ -210,7 +214,7 @@ int tw_destroy(tw_ctx* c) {
   if (!c) return TW_OK;
   TW_ON_DEVICE(c);
   (void)hipDeviceSynchronize();
-  if (c->step_graph) (void)hipGraphExecDestroy(c->step_graph);
+  for (auto& kv : c->step_graphs) (void)hipGraphExecDestroy(kv.second);
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
   for (int i = 0; i < 5; ++i) {
@@ -825,7 +829,7 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
   if (max_len > c->P) max_len = c->P;
   if (max_len <= n_prompt) return fail(c, TW_EINVAL, "nothing to generate (max_len %d <= n_prompt %d)", max_len, n_prompt);
   const int out_ld = o->max_length > 0 ? o->max_length : max_len;
-  c->dec_key_bound = max_len;
+  c->dec_key_bound = max_len;   // per step: the 64-key bucket of the position (below)
   hipStream_t st = pick_stream(c, stream);
   const int P = c->P;
 
@@ -860,14 +864,22 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
   sa.begin_suppress = c->begin_suppress_dev; sa.n_begin_suppress = o->n_begin_suppress;
   sa.suppress_bits = c->suppress_bits; sa.partials = c->sampler_partials;
 
-  // ---- optional graph capture of one full step ----
+  // ---- graph replay: one captured step per self-attention length bucket, captured on first use ----
   char keybuf[256];
-  snprintf(keybuf, sizeof keybuf, "%d|%d|%d|%d|%d|%d|%d|%d|%d|%d", B, o->eos_id, o->pad_id, o->min_new_tokens, o->timestamps,
-           o->no_timestamps_id, o->max_initial_timestamp_index, o->n_begin_suppress, o->n_suppress, (max_len + 63) / 64);
+  snprintf(keybuf, sizeof keybuf, "%d|%d|%d|%d|%d|%d|%d|%d|%d", B, o->eos_id, o->pad_id, o->min_new_tokens, o->timestamps,
+           o->no_timestamps_id, o->max_initial_timestamp_index, o->n_begin_suppress, o->n_suppress);
   const bool use_graph = c->cfg.use_graph != 0;
-  if (use_graph && (c->step_graph == nullptr || c->step_graph_key != keybuf)) {
-    if (c->step_graph) { (void)hipGraphExecDestroy(c->step_graph); c->step_graph = nullptr; }
+  if (use_graph && c->step_graph_key != keybuf) {   // other options: the captured sampler arguments are stale
+    for (auto& kv : c->step_graphs) (void)hipGraphExecDestroy(kv.second);
+    c->step_graphs.clear();
+    c->step_graph_key = keybuf;
+  }
+  auto graph_for = [&](int kb, hipGraphExec_t* out) -> int {
+    const std::string k = std::to_string(kb);
+    auto it = c->step_graphs.find(k);
+    if (it != c->step_graphs.end()) { *out = it->second; return TW_OK; }
     hipGraph_t g = nullptr;
+    c->dec_key_bound = kb;
     HIPCHK(c, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     int r = decode_core(c, B, st);
     hipError_t es = (r == TW_OK) ? launch_sampler(sa, st) : hipSuccess;
@@ -877,11 +889,14 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
       if (g) (void)hipGraphDestroy(g);
       return fail(c, TW_EHIP, "decode-step graph capture failed: %s", hipGetErrorString(es != hipSuccess ? es : ee));
     }
-    hipError_t ei = hipGraphInstantiate(&c->step_graph, g, nullptr, nullptr, 0);
+    hipGraphExec_t ex = nullptr;
+    hipError_t ei = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
-    if (ei != hipSuccess) { c->step_graph = nullptr; return fail(c, TW_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ei)); }
-    c->step_graph_key = keybuf;
-  }
+    if (ei != hipSuccess) return fail(c, TW_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ei));
+    c->step_graphs[k] = ex;
+    *out = ex;
+    return TW_OK;
+  };
 
   // ---- the loop: step s consumes position s and produces the token at position s+1 ----
   tic(c, 3, st);
@@ -889,9 +904,14 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
   int steps = 0;
   bool all_done = false;
   for (int s = 0; s < max_len - 1 && !all_done; ++s) {
+    const int kb = std::min(((s + 64) / 64) * 64, ((max_len + 63) / 64) * 64);   // keys [0, kb) cover position s
     if (use_graph) {
-      HIPCHK(c, hipGraphLaunch(c->step_graph, st));
+      hipGraphExec_t ex = nullptr;
+      int r = graph_for(kb, &ex);
+      if (r != TW_OK) return r;
+      HIPCHK(c, hipGraphLaunch(ex, st));
     } else {
+      c->dec_key_bound = kb;
       int r = decode_core(c, B, st);
       if (r != TW_OK) return r;
       HIPCHK(c, launch_sampler(sa, st));
