@@ -154,8 +154,9 @@ def test_full_depth(name, dtype):
 
 
 def test_full_depth_fp8_vs_bf16_statement():
-    """BASELINE config 5 (large-v3, 15 s chunks, MXFP8 decoder weights): full-depth logit error of the fp8 context against the
-    fp32 reference, beside bf16's (no reference exists for fp8 results; this states the quantisation error at depth).
+    """BASELINE config 5 (large-v3, 15 s chunks, MXFP8 decoder weights + fp8 cross-K/V caches): full-depth logit error of the fp8
+    context against the fp32 reference, beside bf16's (no reference exists for fp8 results; this states the quantisation error
+    at depth: measured 8.5e-2 vs 1.5e-2 for bf16).
     Bounds: rel-L2 <= 0.25 and top-1 identical wherever the golden margin exceeds 1.5."""
     name = "full_large-v3_c15"
     z, dims, w, pcm, heads = load_case(name)

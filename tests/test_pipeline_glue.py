@@ -136,3 +136,18 @@ def test_shared_engine_and_skeleton_model_give_the_reference_result():
     with pytest.raises(ValueError, match="encoder frames"):
         ASRPipeline(model, feature_extractor=hr.build_feature_extractor(dims, 30), tokenizer=synthetic.build_tokenizer(dims.vocab),
                     chunk_length_s=30, device="cpu", torch_dtype=torch.float32, engine=eng)
+
+
+def test_special_id_cache_is_transparent():
+    from thewhisper_amd.tokenizer_cache import cache_special_ids
+
+    dims = wo.PRESETS["micro"]
+    plain, tok = hr.build_tokenizer(dims), cache_special_ids(hr.build_tokenizer(dims))
+    assert tok.all_special_ids == plain.all_special_ids and tok.all_special_ids is tok.all_special_ids   # cached object
+    ids = [50258, 50259, 50360, 50365, 300, 301, 50400, 50257]
+    assert tok._decode_with_timestamps(ids) == plain._decode_with_timestamps(ids)
+    assert tok.decode(ids, skip_special_tokens=True) == plain.decode(ids, skip_special_tokens=True)
+    tok.add_special_tokens({"additional_special_tokens": ["<|brandnew|>"]})      # table changes -> cache re-derived
+    plain.add_special_tokens({"additional_special_tokens": ["<|brandnew|>"]})
+    assert tok.all_special_ids == plain.all_special_ids
+    assert cache_special_ids(tok) is tok

@@ -24,6 +24,7 @@ from transformers import WhisperForConditionalGeneration as HFWhisperForConditio
 from . import lcs_patch  # noqa: F401  (installs the reference's chunk-merge fix, R:thestage_speechkit/__init__.py:137-139)
 from .feature_extraction import AMDWhisperFeatureExtractor
 from .model import AMDWhisperForConditionalGeneration
+from .tokenizer_cache import cache_special_ids
 
 
 class ASRPipeline(AutomaticSpeechRecognitionPipeline):
@@ -72,6 +73,7 @@ class ASRPipeline(AutomaticSpeechRecognitionPipeline):
             model = AMDWhisperForConditionalGeneration.from_hf(model)
 
         feature_extractor = AMDWhisperFeatureExtractor.from_hf(feature_extractor)
+        tokenizer = cache_special_ids(tokenizer)   # host-side post-processing cost only; values unchanged
         if feature_extractor.chunk_length != chunk_length_s:
             raise ValueError(
                 f"feature_extractor.chunk_length={feature_extractor.chunk_length} must equal chunk_length_s={chunk_length_s}: "
