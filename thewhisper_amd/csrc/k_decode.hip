@@ -808,10 +808,12 @@ __device__ __forceinline__ float attn_mfma_block_kv8(const bf16_t* __restrict__ 
 }
 
 // q [B, H*64] row-major; kc / vc per (stream, head): `rows` (multiple of 64) keys of K fragment-major / V^T fragment-major
-template <typename T, bool SINGLE>
-__global__ __launch_bounds__(256) void dec_self_attn_kernel(const T* __restrict__ q, const T* __restrict__ kc,
-                                                             const T* __restrict__ vc, int rows, T* __restrict__ out, int H,
-                                                             int key_bound, const DecState* __restrict__ stt) {
+// NW wavefronts of 64 keys each: 1 / 2 wavefronts while the sequence is shorter than 64 / 128 positions (the host picks the
+// 64-key bucket per step): no idle wavefronts to launch and to meet at the barriers of the cross-wavefront reductions
+template <typename T, bool SINGLE, int NW>
+__global__ __launch_bounds__(NW * 64) void dec_self_attn_kernel(const T* __restrict__ q, const T* __restrict__ kc,
+                                                                 const T* __restrict__ vc, int rows, T* __restrict__ out, int H,
+                                                                 int key_bound, const DecState* __restrict__ stt) {
   __shared__ float sc[512];
   __shared__ float red[2 * 4 + 4 * 64];
   asm volatile("" ::"s"(q), "s"(kc), "s"(vc), "s"(rows), "s"(out), "s"(H), "s"(key_bound), "s"(stt));
@@ -819,7 +821,7 @@ __global__ __launch_bounds__(256) void dec_self_attn_kernel(const T* __restrict_
   const int n_keys = stt->pos + 1;
   const long long base = ((long long)b * H + h) * rows * 64;
   // the host guarantees pos < key_bound (a multiple of 64, <= rows): the requests do not wait for `pos`
-  attn_mfma_block<T, 4, SINGLE>(q + ((long long)b * H + h) * 64, kc + base, vc + base, n_keys, key_bound, sc, red,
+  attn_mfma_block<T, NW, SINGLE>(q + ((long long)b * H + h) * 64, kc + base, vc + base, n_keys, key_bound, sc, red,
                                 out + (long long)(b >> 4) * 16 * H * 64, b & 15, h * 64);  // fragment-major, groups of 16 streams
 }
 
@@ -1231,10 +1233,13 @@ hipError_t launch_dec_self_attn(int dtype, const void* q, const void* kc, const 
   int kb = (key_bound + 63) / 64 * 64;
   if (rows % 64 != 0 || rows > 512 || kb > rows) return hipErrorInvalidValue;
   const bool single = kb <= 256;
-#define SA_GO(TT, SV) hipLaunchKernelGGL((dec_self_attn_kernel<TT, SV>), dim3(H, B), dim3(256), 0, st, (const TT*)q, (const TT*)kc, \
-                                         (const TT*)vc, rows, (TT*)out, H, kb, stt)
-  if (dtype == 1) { if (single) SA_GO(bf16_t, true); else SA_GO(bf16_t, false); }
-  else { if (single) SA_GO(float, true); else SA_GO(float, false); }
+  const int nw = kb <= 64 ? 1 : (kb <= 128 ? 2 : 4);
+#define SA_GO(TT, SV, NWV) hipLaunchKernelGGL((dec_self_attn_kernel<TT, SV, NWV>), dim3(H, B), dim3(NWV * 64), 0, st, (const TT*)q, \
+                                              (const TT*)kc, (const TT*)vc, rows, (TT*)out, H, kb, stt)
+#define SA_PICK(TT) do { if (nw == 1) SA_GO(TT, true, 1); else if (nw == 2) SA_GO(TT, true, 2); else if (single) SA_GO(TT, true, 4); \
+                         else SA_GO(TT, false, 4); } while (0)
+  if (dtype == 1) SA_PICK(bf16_t); else SA_PICK(float);
+#undef SA_PICK
 #undef SA_GO
   return hipGetLastError();
 }
