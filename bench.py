@@ -209,6 +209,17 @@ def pipeline_leg(eng, dims, args, device_index, heads, latency_calls, hub_rounds
             backend.transcribe(clips[i % B], 0.0, 16000)
             lat.append((time.perf_counter() - t0) * 1e3)
         lat.sort()
+        # the call pattern the reference scheduler produces for one stream (SURVEY.md section 3.2 probe: the rolling buffer grows
+        # 2.0, 2.5, ... 10.5 s, then oscillates between ~6.8 and ~8.9 s as committed audio is trimmed): ragged buffers, one call
+        # per 0.5 s of new audio - the p50 of THIS sequence is what a streaming session sees (R:...streaming_pipeline.py:740-822)
+        ragged = [2.0 + 0.5 * i for i in range(18)] + [6.8 + 0.5 * (i % 5) for i in range(40)]
+        rag = []
+        for i, secs in enumerate(ragged if latency_calls > 0 else []):
+            buf = clips[i % B][: min(len(clips[0]), int(secs * 16000))]
+            t0 = time.perf_counter()
+            backend.transcribe(buf, 0.0, 16000)
+            rag.append((time.perf_counter() - t0) * 1e3)
+        rag.sort()
         hub = BatchingHub(backend, max_batch=B, max_wait_s=0.05)
         gate = threading.Barrier(B)
 
@@ -236,9 +247,13 @@ def pipeline_leg(eng, dims, args, device_index, heads, latency_calls, hub_rounds
             "backend_transcribe_p50_ms": round(lat[len(lat) // 2], 2) if lat else None,
             "backend_transcribe_p90_ms": round(lat[min(len(lat) - 1, (len(lat) * 9) // 10)], 2) if lat else None,
             "backend_transcribe_calls": len(lat),
+            "scheduler_pattern_p50_ms": round(rag[len(rag) // 2], 2) if rag else None,
+            "scheduler_pattern_p90_ms": round(rag[min(len(rag) - 1, (len(rag) * 9) // 10)], 2) if rag else None,
+            "scheduler_pattern_calls": len(rag),
             "note": f"host float32 {args.chunk_s} s buffers through thewhisper_amd.AMDWhisperBackend.transcribe (reference contract "
                     f"R:thestage_speechkit/streaming/streaming_pipeline.py:388-435: word timestamps on, max_new_tokens=128, natural eos); "
-                    f"{B} session threads share one engine through BatchingHub",
+                    f"{B} session threads share one engine through BatchingHub; scheduler_pattern_* = the ragged 2-10.5 s rolling "
+                    f"buffers the reference scheduler sends for one stream (clips longer than the chunk are cut to it)",
         }
     finally:
         eng.generate_greedy = inner
