@@ -538,11 +538,11 @@ int tw_finalize_weights(tw_ctx* c, void* stream) {
     auto retile = [&](void* w, int N, int K, unsigned char** scales, int* tr_out) -> int {
       const size_t Np = (size_t)(N + 15) / 16 * 16;
       int tr = 16;
-      if (tr_out && !c->w8 && N <= 2048 && (tr_narrow == 8 || tr_narrow == 4) && N % tr_narrow == 0) tr = tr_narrow;
+      if (tr_out && N <= 2048 && (tr_narrow == 8 || (tr_narrow == 4 && !c->w8)) && N % 16 == 0) tr = tr_narrow;
       if (tr_out) *tr_out = tr;
       if (c->w8) {  // MXFP8 fragments + block scales replace the bf16 rows in the same buffer (half the bytes + 1/32)
         unsigned char* sc = reinterpret_cast<unsigned char*>(scratch);
-        HIPCHK(c, launch_quant_mx8(w, sc, sc + Np * K, N, K, st));
+        HIPCHK(c, launch_quant_mx8(w, sc, sc + Np * K, N, K, tr, st));
         HIPCHK(c, hipMemcpyAsync(w, scratch, Np * K + Np * K / 32, hipMemcpyDeviceToDevice, st));
         *scales = reinterpret_cast<unsigned char*>(w) + Np * K;
       } else {

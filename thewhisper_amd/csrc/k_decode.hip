@@ -226,7 +226,8 @@ template <typename T, int NW, int SK_MAXS, bool LN, int EPI, bool MULTI, bool W8
 __global__ __launch_bounds__(NW * 64, (CG > 1 ? (NW >= 16 ? 4 : 2) : (NW >= 16 ? 4 : (W8 ? (SK_MAXS <= 2 ? 4 : 2) : (SK_MAXS <= 5 ? 4 : 2)))))
 void skinny_mfma_kernel(GemvArgs a) {
   static_assert(!W8 || sizeof(T) == 2, "MXFP8 weights go with bf16 activations");
-  static_assert(TR == 16 || (!W8 && !MULTI && EPI != SK_KV && EPI != SK_F32), "narrow tiles: plain / residual / GELU projections only");
+  static_assert(TR == 16 || (!MULTI && EPI != SK_KV && EPI != SK_F32), "narrow tiles: plain / residual / GELU projections only");
+  static_assert(!W8 || TR == 16 || TR == 8, "MXFP8 weights: 16- or 8-row tiles");
   constexpr int E = ElemTraits<T>::kPer16B;
   constexpr int XPS = W8 ? 4 : 1;  // 32-wide activation fragments per MFMA step
   constexpr int WPS = W8 ? 2 : 1;  // 16-B weight requests per MFMA step
@@ -287,10 +288,12 @@ void skinny_mfma_kernel(GemvArgs a) {
     }
   };
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<T*>(W), 0, (TR == 16 || W8) ? 0 : (int)((long long)n_tiles * S * 4 * TR * 16), 0x00020000);
+      const_cast<T*>(W), 0, TR == 16 ? 0 : (int)((long long)n_tiles * S * 4 * TR * 16 * (W8 ? 2 : 1)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(wscale), 0, (W8 && TR != 16) ? (int)((long long)n_tiles * S * 4 * TR) : 0, 0x00020000);
   auto load_w = [&](int tile, int s0) {  // fragment-major weights: 1 KiB contiguous per wavefront request
     const int tl = min(tile, n_tiles - 1);
-    if (W8) {
+    if (W8 && TR == 16) {
       const unsigned char* wt = reinterpret_cast<const unsigned char*>(W) + ((long long)tl * S * 128 + lane) * 16;
       const unsigned char* ws = wscale + (long long)tl * S * 64 + lane;
 #pragma unroll
@@ -299,6 +302,20 @@ void skinny_mfma_kernel(GemvArgs a) {
         wq[2 * i] = sk_load_w<unsigned char>(wt + st * 2048);
         wq[2 * i + 1] = sk_load_w<unsigned char>(wt + st * 2048 + 1024);
         wsc[i] = ws[st * 64];
+      }
+    } else if (W8) {
+      // 8-row MXFP8 tiles (quant_mx8_kernel with tr = 8): per (tile, 128-k step) [half][kq*8 + row][16 B] + 32 scale bytes;
+      // the lanes of rows >= 8 are out of range of the descriptors (no request, zero data, zero scale)
+      const unsigned lane_off = (fr < TR) ? (unsigned)((kq * TR + fr) * 16) : 0x80000000u;
+      const unsigned sc_off = (fr < TR) ? (unsigned)(kq * TR + fr) : 0x80000000u;
+      const unsigned tile_off = (unsigned)tl * (unsigned)(S * 8 * TR * 16);   // S steps x 2 halves x 4*TR lanes x 16 B
+#pragma unroll
+      for (int i = 0; i < SK_MAXS; ++i) {
+        const unsigned st = (unsigned)min(s0 + i, S - 1);
+        const unsigned o = lane_off + tile_off + st * (unsigned)(8 * TR * 16);
+        wq[2 * i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wr, o, 0, 2 /* nt */));
+        wq[2 * i + 1] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wr, o + (unsigned)(4 * TR * 16), 0, 2));
+        wsc[i] = (int)__builtin_amdgcn_raw_buffer_load_b8(wsr, sc_off + ((unsigned)tl * S + st) * (unsigned)(4 * TR), 0, 0);
       }
     } else if (TR == 16) {
       const T* wt = W + ((long long)tl * S * 64 + lane) * E;
@@ -495,10 +512,10 @@ __global__ __launch_bounds__(256) void tile_weights_kernel(const T* __restrict__
 // one scale byte per lane (already placed in the lane the MFMA reads it from).  Quantisation = sk_quant_mx8, i.e. identical
 // to what the projection kernel does to the activations.
 __global__ __launch_bounds__(256) void quant_mx8_kernel(const bf16_t* __restrict__ src, unsigned char* __restrict__ dst,
-                                                        unsigned char* __restrict__ scales, int N, int K) {
+                                                        unsigned char* __restrict__ scales, int N, int K, int TR) {
   const int S = K / 128;
-  const long long v = (long long)blockIdx.x * 256 + threadIdx.x;  // (tile, step, lane)
-  const long long total = (long long)((N + 15) / 16) * S * 64;
+  const long long v = (long long)blockIdx.x * 256 + threadIdx.x;  // (16-row tile, step, lane): quantisation always works on
+  const long long total = (long long)((N + 15) / 16) * S * 64;    // whole wavefronts = 16 rows x 4 k-groups
   if (v >= total) return;
   const int l = (int)(v & 63);
   const long long ts = v >> 6;
@@ -513,10 +530,14 @@ __global__ __launch_bounds__(256) void quant_mx8_kernel(const bf16_t* __restrict
   }
   int sb;  // (whole wavefronts reach this point: `total` is a multiple of 64)
   const v8i_t q = sk_quant_mx8(xv, sb);
-  unsigned char* blk = dst + ts * 2048;
-  *reinterpret_cast<u32x4_t*>(blk + l * 16) = u32x4_t{(unsigned)q[0], (unsigned)q[1], (unsigned)q[2], (unsigned)q[3]};
-  *reinterpret_cast<u32x4_t*>(blk + 1024 + l * 16) = u32x4_t{(unsigned)q[4], (unsigned)q[5], (unsigned)q[6], (unsigned)q[7]};
-  scales[ts * 64 + l] = (unsigned char)sb;
+  // storage: tiles of TR rows (16, or 8 for the narrow projections): [tile][step][half][kq * TR + row % TR][16 B]
+  const int fr = l & 15;
+  const long long tile = t * (16 / TR) + fr / TR;
+  const int slot = kq * TR + fr % TR;
+  unsigned char* blk = dst + (tile * S + s) * (long long)(8 * TR * 16);
+  *reinterpret_cast<u32x4_t*>(blk + slot * 16) = u32x4_t{(unsigned)q[0], (unsigned)q[1], (unsigned)q[2], (unsigned)q[3]};
+  *reinterpret_cast<u32x4_t*>(blk + 4 * TR * 16 + slot * 16) = u32x4_t{(unsigned)q[4], (unsigned)q[5], (unsigned)q[6], (unsigned)q[7]};
+  scales[(tile * S + s) * (long long)(4 * TR) + slot] = (unsigned char)sb;
 }
 
 // W[n,:] *= g (in place, rounded to T); gw[n] = sum_k g[k] W[n,k]; cb[n] = sum_k beta[k] W[n,k] + bias[n]   (one wave per row)
@@ -689,7 +710,11 @@ __device__ __forceinline__ void kv8_widen(const u32x4_t& raw, float X, u32x4_t& 
   hi[3] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)raw[3], X, true));
 }
 
-template <int NW, bool SINGLE>
+// G = 64-key groups per wavefront (1, 2 or 3: up to 512 / 1024 / 1536 keys with 8 wavefronts, i.e. every chunk length up to
+// 30 s).  At 32 registers per group and operand the whole head fits the register file, so - unlike the bf16 kernel, which
+// falls back to two dependent passes above 512 keys - EVERY fragment of the head is requested before anything is waited for:
+// one memory round trip per head whatever the chunk length.
+template <int NW, int G>
 __device__ __forceinline__ float attn_mfma_block_kv8(const bf16_t* __restrict__ q, const unsigned char* __restrict__ kf8,
                                                      const unsigned char* __restrict__ vtf8, const unsigned char* __restrict__ ksc,
                                                      const unsigned char* __restrict__ vsc, int n_keys, int n_bound, float* sc,
@@ -698,41 +723,37 @@ __device__ __forceinline__ float attn_mfma_block_kv8(const bf16_t* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, kq = lane >> 4;
-  const int n_chunks = SINGLE ? 1 : (n_bound + NW * 64 - 1) / (NW * 64);
   const int last64 = n_bound / 64 - 1;
-  u32x4_t qf[2], kraw[4], vraw[4];
-  unsigned ksb[4];
-  unsigned vsb = 0;
-  auto load_k = [&](int g64) {  // 64 keys = 4 tiles of 1 KiB + their 64 scale bytes
-    const int g = min(g64, last64);
-    const unsigned char* p = kf8 + ((long long)g * 4 * 64 + lane) * 16;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) kraw[a] = *reinterpret_cast<const u32x4_t*>(p + a * 1024);
-    const unsigned s4 = *reinterpret_cast<const unsigned*>(ksc + g * 64 + fr * 4);   // [group][key % 16][tile]: one load
-#pragma unroll
-    for (int a = 0; a < 4; ++a) ksb[a] = (s4 >> (8 * a)) & 0xffu;
-  };
-  auto load_v = [&](int g64) {  // 64 keys x 64 dims = 4 dim tiles of 1 KiB; lane `lane` also fetches the scale of ITS key
-    const int g = min(g64, last64);
-    const unsigned char* p = vtf8 + ((long long)g * 4 * 64 + lane) * 16;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) vraw[dt] = *reinterpret_cast<const u32x4_t*>(p + dt * 1024);
-    vsb = vsc[g * 64 + lane];
-  };
+  u32x4_t qf[2], kraw[G][4], vraw[G][4];
+  unsigned ks4[G], vsb[G];
   qf[0] = *reinterpret_cast<const u32x4_t*>(q + kq * 16);
   qf[1] = *reinterpret_cast<const u32x4_t*>(q + kq * 16 + 8);
-  load_k(wave);
-  if (SINGLE) load_v(wave);
+#pragma unroll
+  for (int g = 0; g < G; ++g) {  // 64 keys = 4 tiles of 1 KiB + their 64 scale bytes ([group][key % 16][tile]: one 32-bit load)
+    const int gi = min(g * NW + wave, last64);
+    const unsigned char* p = kf8 + ((long long)gi * 4 * 64 + lane) * 16;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) kraw[g][a] = *reinterpret_cast<const u32x4_t*>(p + a * 1024);
+    ks4[g] = *reinterpret_cast<const unsigned*>(ksc + gi * 64 + fr * 4);
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) {  // 64 keys x 64 dims = 4 dim tiles of 1 KiB; lane `lane` also fetches the scale of ITS key
+    const int gi = min(g * NW + wave, last64);
+    const unsigned char* p = vtf8 + ((long long)gi * 4 * 64 + lane) * 16;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vraw[g][dt] = *reinterpret_cast<const u32x4_t*>(p + dt * 1024);
+    vsb[g] = vsc[gi * 64 + lane];
+  }
   __builtin_amdgcn_sched_barrier(0);
 
   float m = -1.0e30f;
-  for (int c = 0; c < n_chunks; ++c) {
-    const int g64 = c * NW + wave;
-    if (c > 0) load_k(g64);
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int g64 = g * NW + wave;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       u32x4_t k0, k1;
-      kv8_widen(kraw[a], __builtin_bit_cast(float, ksb[a] << 23), k0, k1);
+      kv8_widen(kraw[g][a], __builtin_bit_cast(float, ((ks4[g] >> (8 * a)) & 0xffu) << 23), k0, k1);
       f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
       acc = sk_mfma<T>(k0, qf[0], acc);
       acc = sk_mfma<T>(k1, qf[1], acc);
@@ -756,20 +777,20 @@ __device__ __forceinline__ float attn_mfma_block_kv8(const bf16_t* __restrict__ 
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   float ls = 0.f;
-  for (int c = 0; c < n_chunks; ++c) {
-    const int g64 = c * NW + wave;
-    if (!SINGLE) load_v(g64);
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int g64 = g * NW + wave;
     const int t0 = g64 * 64 + lane;  // one key per lane
     float pr = 0.f;
     if (t0 < n_bound) {
       pr = (t0 < n_keys) ? expf(sc[t0] - M) : 0.f;
-      sc[t0] = pr;                                               // plain probability: alignment rows, normaliser
-      scv[t0] = pr * __builtin_bit_cast(float, vsb << 23);       // probability x the key's V scale: the P.V operand
+      sc[t0] = pr;                                                  // plain probability: alignment rows, normaliser
+      scv[t0] = pr * __builtin_bit_cast(float, vsb[g] << 23);       // probability x the key's V scale: the P.V operand
     }
     ls += pr;
     u32x4_t v0[4], v1[4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) kv8_widen(vraw[dt], 1.0f, v0[dt], v1[dt]);
+    for (int dt = 0; dt < 4; ++dt) kv8_widen(vraw[g][dt], 1.0f, v0[dt], v1[dt]);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {   // operand j of lane (kq, .): keys kq*16 + j*8 .. +7 of this 64-key group
       float pv[8];
@@ -848,7 +869,7 @@ __global__ __launch_bounds__(512) void dec_cross_attn_kernel(const T* __restrict
   }
 }
 
-template <bool SINGLE>
+template <int G>
 __global__ __launch_bounds__(512) void dec_cross_attn_kv8_kernel(const bf16_t* __restrict__ q, const unsigned char* __restrict__ ck,
                                                                   const unsigned char* __restrict__ cv,
                                                                   const unsigned char* __restrict__ ksc,
@@ -864,7 +885,7 @@ __global__ __launch_bounds__(512) void dec_cross_attn_kv8_kernel(const bf16_t* _
                "s"(Ha), "s"(P), "s"(stt));
   const int h = blockIdx.x, b = blockIdx.y;
   const long long hb = ((long long)b * H + h) * Tp;
-  const float inv = attn_mfma_block_kv8<8, SINGLE>(q + ((long long)b * H + h) * 64, ck + hb * 64, cv + hb * 64, ksc + hb, vsc + hb,
+  const float inv = attn_mfma_block_kv8<8, G>(q + ((long long)b * H + h) * 64, ck + hb * 64, cv + hb * 64, ksc + hb, vsc + hb,
                                                    Tlen, Tp, sc, scv, red, out + (long long)(b >> 4) * 16 * H * 64, b & 15, h * 64);
   const int slot = align_slot ? align_slot[h] : -1;
   if (slot >= 0) {  // A11 side output: softmax row of an alignment head
@@ -1105,7 +1126,7 @@ static hipError_t skinny_launch_cg(const GemvArgs& a, dim3 grid, size_t lds1, hi
 #define SK_GO(LNV, EPIV) hipLaunchKernelGGL((skinny_mfma_kernel<T, NW, SK_MAXS, LNV, EPIV, MULTI, W8, CG, TR>), grid, dim3(NW * 64), lds, st, a)
   if constexpr (TR != 16) {  // narrow tiles: plain / residual / GELU projections, one tile per workgroup
     if (a.y_f32 || a.kcache) return hipErrorInvalidValue;
-    if constexpr (MULTI || W8) {
+    if constexpr (MULTI || (W8 && TR != 8)) {
       return hipErrorInvalidValue;
     } else if constexpr (NW >= 16) {
       if (ln || a.gelu) return hipErrorInvalidValue;
@@ -1184,23 +1205,29 @@ static hipError_t skinny_launch_nw(const GemvArgs& a0, hipStream_t st) {
 }
 
 // MXFP8 weights: 128-k steps; 2 steps per wavefront cover K = 1280 with 8 wavefronts, 3 cover K = 5120 with 16
-template <int NW>
+template <int NW, int TR>
 static hipError_t skinny_launch_w8(const GemvArgs& a0, hipStream_t st) {
   GemvArgs a = a0;
   if (a.K % 128 != 0 || a.B > 64) return hipErrorInvalidValue;
   const size_t lds = (size_t)NW * 256 * 4;
-  const int tiles = (a.N + 15) / 16;
+  const int tiles = (a.N + TR - 1) / TR;
   static const int max_blocks = env_int("TW_SK_MAX_BLOCKS", 512);
   const int steps_per_wave = (a.K / 128 + NW - 1) / NW;
   a.rg = (tiles + max_blocks - 1) / max_blocks;
   if (a.rg < 1 || steps_per_wave > 3) a.rg = 1;
   dim3 grid((tiles + a.rg - 1) / a.rg);
-  if (a.rg > 1) {
-    if (steps_per_wave <= 2) return skinny_launch_v<bf16_t, NW, 2, true, true, 16>(a, grid, lds, st);
-    return skinny_launch_v<bf16_t, NW, 3, true, true, 16>(a, grid, lds, st);
+  if constexpr (TR != 16) {
+    if (a.rg > 1) return hipErrorInvalidValue;
+    if (steps_per_wave <= 2) return skinny_launch_v<bf16_t, NW, 2, false, true, TR>(a, grid, lds, st);
+    return skinny_launch_v<bf16_t, NW, 3, false, true, TR>(a, grid, lds, st);
+  } else {
+    if (a.rg > 1) {
+      if (steps_per_wave <= 2) return skinny_launch_v<bf16_t, NW, 2, true, true, 16>(a, grid, lds, st);
+      return skinny_launch_v<bf16_t, NW, 3, true, true, 16>(a, grid, lds, st);
+    }
+    if (steps_per_wave <= 2) return skinny_launch_v<bf16_t, NW, 2, false, true, 16>(a, grid, lds, st);
+    return skinny_launch_v<bf16_t, NW, 3, false, true, 16>(a, grid, lds, st);
   }
-  if (steps_per_wave <= 2) return skinny_launch_v<bf16_t, NW, 2, false, true, 16>(a, grid, lds, st);
-  return skinny_launch_v<bf16_t, NW, 3, false, true, 16>(a, grid, lds, st);
 }
 
 template <typename T>
@@ -1209,7 +1236,9 @@ static hipError_t skinny_launch(const GemvArgs& a, hipStream_t st) {
   const bool big = a.K >= 4096 && nw_big == 16 && !a.ln_gw && !a.y_f32 && !a.kcache && !a.gelu && a.B <= 16;
   if (a.wscale) {
     if (sizeof(T) != 2) return hipErrorInvalidValue;
-    return big ? skinny_launch_w8<16>(a, st) : skinny_launch_w8<8>(a, st);
+    if (a.tr == 8) return big ? skinny_launch_w8<16, 8>(a, st) : skinny_launch_w8<8, 8>(a, st);
+    if (a.tr != 0 && a.tr != 16) return hipErrorInvalidValue;
+    return big ? skinny_launch_w8<16, 16>(a, st) : skinny_launch_w8<8, 16>(a, st);
   }
   if (a.tr == 8) return big ? skinny_launch_nw<T, 16, 8>(a, st) : skinny_launch_nw<T, 8, 8>(a, st);
   if (a.tr == 4) return big ? skinny_launch_nw<T, 16, 4>(a, st) : skinny_launch_nw<T, 8, 4>(a, st);
@@ -1252,10 +1281,10 @@ hipError_t launch_dec_cross_attn(int dtype, const void* q, const void* ck, const
   if (ksc || vsc) {  // fp8 K / V^T caches with per-key scales (TW_BF16_MXFP8 contexts)
     if (!ksc || !vsc || dtype != 1) return hipErrorInvalidValue;
     const size_t lds8 = (size_t)Tp * sizeof(float) * 2;
-#define CA8_GO(SV) hipLaunchKernelGGL((dec_cross_attn_kv8_kernel<SV>), dim3(H, B), dim3(512), lds8, st, (const bf16_t*)q, \
+#define CA8_GO(GV) hipLaunchKernelGGL((dec_cross_attn_kv8_kernel<GV>), dim3(H, B), dim3(512), lds8, st, (const bf16_t*)q, \
                                       (const unsigned char*)ck, (const unsigned char*)cv, ksc, vsc, (bf16_t*)out, H, T, Tp,      \
                                       align_slot_for_head, align, Ha, P, stt)
-    if (single) CA8_GO(true); else CA8_GO(false);
+    if (Tp <= 512) CA8_GO(1); else if (Tp <= 1024) CA8_GO(2); else if (Tp <= 1536) CA8_GO(3); else return hipErrorInvalidValue;
 #undef CA8_GO
     return hipGetLastError();
   }
@@ -1299,11 +1328,11 @@ hipError_t launch_tile_weights(int dtype, const void* src, void* dst, int N, int
   return hipGetLastError();
 }
 
-hipError_t launch_quant_mx8(const void* src_bf16, void* dst_fp8, void* dst_scales, int N, int K, hipStream_t st) {
-  if (K % 128 != 0) return hipErrorInvalidValue;
+hipError_t launch_quant_mx8(const void* src_bf16, void* dst_fp8, void* dst_scales, int N, int K, int tr, hipStream_t st) {
+  if (K % 128 != 0 || (tr != 16 && tr != 8) || (tr == 8 && N % 16 != 0)) return hipErrorInvalidValue;
   const long long total = (long long)((N + 15) / 16) * (K / 128) * 64;
   hipLaunchKernelGGL(quant_mx8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const bf16_t*)src_bf16,
-                     (unsigned char*)dst_fp8, (unsigned char*)dst_scales, N, K);
+                     (unsigned char*)dst_fp8, (unsigned char*)dst_scales, N, K, tr);
   return hipGetLastError();
 }
 

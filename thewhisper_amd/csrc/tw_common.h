@@ -184,7 +184,7 @@ hipError_t init_decode_kernels();
 // row-major [N][K] -> the fragment-major layout launch_gemv reads (k_decode.hip); dst holds ceil(N/16)*16 rows
 hipError_t launch_tile_weights(int dtype, const void* src, void* dst, int N, int K, int tr, hipStream_t st);
 // row-major bf16 [N][K] -> MXFP8 fragments (ceil(N/16)*16*K bytes) + block scales (ceil(N/16)*16*K/32 bytes); K % 128 == 0
-hipError_t launch_quant_mx8(const void* src_bf16, void* dst_fp8, void* dst_scales, int N, int K, hipStream_t st);
+hipError_t launch_quant_mx8(const void* src_bf16, void* dst_fp8, void* dst_scales, int N, int K, int tr, hipStream_t st);   // tr: 16 or 8 rows per tile
 // weight preparation for the folded pre-LayerNorm: W <- Wsrc * g (may alias), gw, cb as above
 hipError_t launch_fold_ln(int dtype, void* W, const void* Wsrc, const void* g, const void* beta, const void* bias, float* gw,
                           float* cb, int N, int K, hipStream_t st);  // once per process: dynamic-LDS caps of the gemv instantiations
