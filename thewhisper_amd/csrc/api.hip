@@ -381,7 +381,7 @@ int tw_create(const tw_config* cfg, tw_ctx** out) {
   CALLOC(c->last_ts, B * 4, true); CALLOC(c->stt, sizeof(DecState), true);
   CALLOC(c->begin_suppress_dev, 64 * 4, true); CALLOC(c->suppress_dev, 1024 * 4, true);
   CALLOC(c->suppress_bits, ((V + 31) / 32 + 2048) * 4, true);
-  CALLOC(c->sampler_partials, 64 * 8 * sizeof(SamplerPartial), true);
+  CALLOC(c->sampler_partials, 64 * 32 * sizeof(SamplerPartial), true);
   // ---- dtw workspace ----
   CALLOC(c->zbuf, B * Ha * P * T * 4, false);
   CALLOC(c->mat, B * P * T * 4, false);

@@ -932,8 +932,9 @@ __global__ void suppress_bitmap_kernel(const int* __restrict__ list, int n, unsi
 //    passes.  Output per slice: best text token, best timestamp token, sum of exp(x - slice max) over timestamp tokens.
 //  * sampler_finish_kernel: ONE workgroup, wavefront b merges the slices of stream b (log-sum-exp merge), applies the
 //    "timestamp mass beats every text token" rule, appends the token, and thread 0 advances the position afterwards.
-constexpr int SAMPLER_NS = 8;
-constexpr int SAMPLER_IT = 13;  // float2 requests per thread: 13 * 256 * 2 * 8 = 53248 >= vocab
+// 8 slices of <= 13 x 512 logits per stream when many streams decode (8 x B workgroups cover the chip); 32 slices of <= 4 x 512
+// for a few streams (one stream would otherwise put the whole vocabulary on 8 CUs: 10 us of a turbo step's 220)
+constexpr int SAMPLER_NS_MAX = 32;
 
 struct SamplerMask {  // dynamic part of the mask: uniform scalars derived from the decoding state
   int b_lo, b_hi, c_lo, c_hi, d_hi, e_lo, ts_begin;
@@ -977,6 +978,7 @@ __device__ __forceinline__ SamplerMask sampler_mask(const SamplerArgs& a, int b)
   return k;
 }
 
+template <int SAMPLER_NS, int SAMPLER_IT>
 __global__ __launch_bounds__(256) void sampler_part_kernel(SamplerArgs a) {
   __shared__ MaxIdx red_text[4], red_ts[4];
   __shared__ float red_sum[4];
@@ -1065,7 +1067,7 @@ __global__ __launch_bounds__(256) void sampler_part_kernel(SamplerArgs a) {
     SamplerPartial o;
     o.bt_v = bt.v; o.bt_i = bt.i; o.bs_v = bs.v; o.bs_i = bs.i;
     o.sum = red_sum[0] + red_sum[1] + red_sum[2] + red_sum[3];
-    a.partials[b * SAMPLER_NS + part] = o;
+    a.partials[b * SAMPLER_NS_MAX + part] = o;
   }
 }
 
@@ -1074,8 +1076,8 @@ __global__ __launch_bounds__(1024) void sampler_finish_kernel(SamplerArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   for (int b = tid >> 6; b < a.B; b += 16) {  // wavefront w <- streams w, w+16, ...
     const SamplerMask k = sampler_mask(a, b);
-    SamplerPartial p = a.partials[b * SAMPLER_NS + min(lane, SAMPLER_NS - 1)];
-    const bool on = lane < SAMPLER_NS;
+    SamplerPartial p = a.partials[b * SAMPLER_NS_MAX + min(lane, a.n_slices - 1)];
+    const bool on = lane < a.n_slices;
     MaxIdx bt{on ? p.bt_v : -INFINITY, on ? p.bt_i : 0x7fffffff}, bs{on ? p.bs_v : -INFINITY, on ? p.bs_i : 0x7fffffff};
     const float my_m = bs.v;
     bt = wave_best(bt);
@@ -1297,9 +1299,12 @@ hipError_t launch_dec_cross_attn(int dtype, const void* q, const void* ck, const
   return hipGetLastError();
 }
 
-hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st) {
-  if (a.B < 1 || a.B > 64 || !a.partials || !a.suppress_bits) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(sampler_part_kernel, dim3(SAMPLER_NS, a.B), dim3(256), 0, st, a);
+hipError_t launch_sampler(const SamplerArgs& a0, hipStream_t st) {
+  if (a0.B < 1 || a0.B > 64 || !a0.partials || !a0.suppress_bits) return hipErrorInvalidValue;
+  SamplerArgs a = a0;
+  a.n_slices = a.B >= 8 ? 8 : 32;
+  if (a.n_slices == 8) hipLaunchKernelGGL((sampler_part_kernel<8, 13>), dim3(8, a.B), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((sampler_part_kernel<32, 4>), dim3(32, a.B), dim3(256), 0, st, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(sampler_finish_kernel, dim3(1), dim3(1024), 0, st, a);  // also advances the position

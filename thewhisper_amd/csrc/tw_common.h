@@ -211,7 +211,8 @@ struct SamplerArgs {   // A10 + argmax + bookkeeping
   int eos, pad, min_new, timestamps, no_ts_id, max_initial_ts;  // max_initial_ts < 0: unset
   const int* begin_suppress; int n_begin_suppress;
   const unsigned* suppress_bits;  // static suppress list as a V-bit map (launch_suppress_bitmap)
-  SamplerPartial* partials;       // [B][8] workspace between the two sampler launches
+  SamplerPartial* partials;       // [B][32] workspace between the two sampler launches
+  int n_slices;                   // vocabulary slices per stream (set by launch_sampler)
 };
 hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st);   // sampler + pos advance
 hipError_t launch_suppress_bitmap(const int* list, int n, unsigned* bits, int V, hipStream_t st);  // zero + set bits
