@@ -211,7 +211,9 @@ def test_logits_golden_reference_topk():
 # ---------------------------------------------------------------- A9-A11
 GREEDY_CASES = [("micro", 100, 1, 24, False, 0), ("micro", 100, 3, 24, True, 0), ("micro", 500, 2, 40, True, 40),
                 ("micro80", 100, 2, 24, False, 0), ("micro", 100, 16, 20, True, 0), ("micro", 750, 2, 24, True, 0),
-                ("micro", 100, 33, 12, True, 0)]
+                ("micro", 100, 33, 12, True, 0),
+                # 200 positions: the step graphs of the 64 / 128 / 192 / 256-key self-attention buckets (1, 2 and 4 wavefronts)
+                ("micro", 100, 2, 200, True, 200), ("micro", 100, 3, 150, False, 150)]
 
 
 @pytest.mark.parametrize("preset,T,B,max_new,graph,min_new", GREEDY_CASES)
