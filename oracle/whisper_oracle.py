@@ -515,10 +515,15 @@ class OracleWhisperMXFP8(OracleWhisper):
     """bf16 activations, decoder projection weights in MXFP8 with the pre-LayerNorm folded into the weights, as the
     TW_BF16_MXFP8 engine computes:  y = rstd * (Q(x) . Q(W')^T - mean * gW) + cb,  W' = bf16(g * W)."""
 
-    def __init__(self, dims, weights, T=None):
+    def __init__(self, dims, weights, T=None, cross_q_ahead=True):
         super().__init__(dims, weights, T=T, dtype=np.float32)
         self._fold_cache: Dict[Tuple[str, str], Tuple[np.ndarray, np.ndarray, np.ndarray]] = {}
         self._wq_cache: Dict[str, np.ndarray] = {}
+        self._ahead_cache: Dict[int, Tuple[np.ndarray, np.ndarray]] = {}
+        # the engine accumulates the cross-attention query ahead of its LayerNorm (DESIGN.md section 4, "cross query ahead"):
+        # x1 W'^T = x0 W'^T + attn (W' Wo)^T + W' bo, with W' Wo composed once (fp32), rounded to bf16 and quantised like
+        # every other weight; False restates the plain sequence (LayerNorm'd x1 times the quantised W')
+        self.cross_q_ahead = cross_q_ahead
 
     def _folded(self, ln_name, w_name, b_name):
         key = (ln_name, w_name)
@@ -532,7 +537,27 @@ class OracleWhisperMXFP8(OracleWhisper):
             if b_name is not None:
                 cb = cb + bf16_round(self.w[b_name]).astype(np.float64)
             self._fold_cache[key] = (mx8_quant_dequant(Wf), gw, cb.astype(np.float32))
+            self._fold_cache[(ln_name, w_name, "bf16")] = Wf
         return self._fold_cache[key]
+
+    def _cross_q_ahead(self, i, x0, attn_b, x1):
+        """Pre-softmax cross-attention query of layer i the way the fused launches form it (api.hip: decode_core)."""
+        p = f"model.decoder.layers.{i}"
+        ln, wn = p + ".encoder_attn_layer_norm", p + ".encoder_attn.q_proj"
+        Wq, gw, cb = self._folded(ln, wn + ".weight", wn + ".bias")
+        if i not in self._ahead_cache:
+            Wf = self._fold_cache[(ln, wn + ".weight", "bf16")]
+            Wo = bf16_round(self.w[p + ".self_attn.out_proj.weight"])
+            bo = bf16_round(self.w[p + ".self_attn.out_proj.bias"])
+            Wc = bf16_round((Wf.astype(np.float32) @ Wo.astype(np.float32)).astype(np.float32))
+            self._ahead_cache[i] = (mx8_quant_dequant(Wc), (Wf.astype(np.float32) @ bo.astype(np.float32)).astype(np.float32))
+        Wc_q, c0 = self._ahead_cache[i]
+        u = (mx8_quant_dequant(bf16_round(x0)) @ Wq.T + c0) + mx8_quant_dequant(attn_b) @ Wc_q.T
+        xb = bf16_round(x1)
+        mean = xb.mean(axis=-1, keepdims=True)
+        var = np.maximum((xb.astype(np.float64) ** 2).mean(axis=-1, keepdims=True) - mean.astype(np.float64) ** 2, 0.0)
+        rstd = (1.0 / np.sqrt(var + 1e-5)).astype(np.float32)
+        return rstd * (u - mean * gw) + cb
 
     def _folded_apply(self, x, ln_name, w_name, b_name):
         xb = bf16_round(x)
@@ -607,8 +632,12 @@ class OracleWhisperMXFP8(OracleWhisper):
             cache.self_k[i] = np.concatenate([cache.self_k[i], k], axis=2)
             cache.self_v[i] = np.concatenate([cache.self_v[i], v], axis=2)
             a, _ = self._attend(q, cache.self_k[i], cache.self_v[i], causal[None, None])
-            x = r(x + self._dec_lin(r(self._merge(a)), p + ".self_attn.out_proj"))
-            q = self._heads(r(self._dec_proj(x, p + ".encoder_attn_layer_norm", p + ".encoder_attn.q_proj") * scale))
+            x0, attn_b = x, r(self._merge(a))
+            x = r(x0 + self._dec_lin(attn_b, p + ".self_attn.out_proj"))
+            if self.cross_q_ahead:
+                q = self._heads(r(self._cross_q_ahead(i, x0, attn_b, x) * scale))
+            else:
+                q = self._heads(r(self._dec_proj(x, p + ".encoder_attn_layer_norm", p + ".encoder_attn.q_proj") * scale))
             a, pr = self._attend(q, r(cache.cross_k[i]), r(cache.cross_v[i]))
             if i in want:
                 for j, hh in want[i]:

@@ -156,11 +156,19 @@ def test_decoder_mxfp8_teacher_forced(preset, T, B, layers):
         got = eng.decode_step(ids[:, s].tolist()).cpu().numpy()
         if preset == "micro" and layers <= 1 and s == 0:
             # layers = 0 (embedding + logits): bit-level agreement of layouts, scales, roundings.  With one decoder layer the
-            # fp8 cross-K/V come in: the engine's and the restatement's bf16 K/V differ by 1 ulp wherever the fp32 summation
-            # order of the projection differs, and such a value can land on the other side of an e4m3 rounding boundary
-            # (a 6 % step for that element) - measured 7e-3, which still pins layouts and scale placement (a wrong scale or
-            # a permuted fragment is an error of order 1)
-            assert rel_l2(got, refq) < (2e-3 if layers == 0 else 1.5e-2), rel_l2(got, refq)
+            # fp8 cross-K/V and the fp8 activation operands come in: the engine's and the restatement's bf16 values differ by
+            # 1 ulp wherever the fp32 summation order of a projection differs, and such a value can land on the other side of
+            # an e4m3 rounding boundary (a 6 % step for that element).  Perturbing 5 % of the attention outputs of the
+            # restatement by one bf16 ulp moves its logits by 1-2e-2 (tools/dbg/dbg_fuse_fp8.py); measured here 2.2e-2
+            # (7e-3 with TW_FUSE_CQ=0 against the plain order), which still pins layouts and scale placement (a wrong scale
+            # or a permuted fragment is an error of order 1) ...
+            assert rel_l2(got, refq) < (2e-3 if layers == 0 else 3e-2), rel_l2(got, refq)
+            if layers == 1:
+                # ... and the restatement of the engine's order of operations ("cross query ahead") is the closer one:
+                # against the plain order (LayerNorm, then the quantised query weight) the same logits are 4e-2 away
+                op = wo.OracleWhisperMXFP8(dims, w, T=T, cross_q_ahead=False)
+                refp = op.decode(ids[:, :1], op.new_cache(enc))[0][:, 0]
+                assert rel_l2(got, refq) < rel_l2(got, refp), (rel_l2(got, refq), rel_l2(got, refp))
         assert rel_l2(got, refq) < 6e-2, (s, rel_l2(got, refq))
         assert rel_l2(got, ref) < 1e-1, (s, rel_l2(got, ref))       # fp8 (W8A8) quantisation noise vs exact arithmetic
         assert rel_l2(refq, ref) > 1e-2                             # ... which the restatement does model

@@ -66,6 +66,27 @@ def test_mxfp8_oracle_close_to_exact_oracle():
     assert 1e-3 < err < 1e-1
 
 
+def test_cross_query_ahead_is_the_same_projection_up_to_quantisation_noise():
+    """The engine accumulates the cross-attention query before its LayerNorm (x0 W'^T + attn (W' Wo)^T + W' bo); the
+    restatement of that order and of the plain order (LayerNorm of x1, then W') differ by fp8 noise only, and WITHOUT the
+    quantisers the algebra is exact to fp32 rounding."""
+    dims = wo.PRESETS["micro"]
+    w = wo.make_weights(dims, 1)
+    a, b = wo.OracleWhisperMXFP8(dims, w, T=100, cross_q_ahead=True), wo.OracleWhisperMXFP8(dims, w, T=100, cross_q_ahead=False)
+    enc = wo.OracleWhisper(dims, w, T=100).encode(wo.log_mel(wo.synth_audio(16000 * 2, 1)[None], dims.n_mels))
+    ids = np.array([[50258, 50259, 50360, 23]])
+    la, lb = a.decode(ids, a.new_cache(enc))[0], b.decode(ids, b.new_cache(enc))[0]
+    err = np.linalg.norm(la - lb) / np.linalg.norm(lb)
+    assert 0 < err < 6e-2
+    # the identity itself, in float64 on one layer's tensors
+    rng = np.random.default_rng(0)
+    d = dims.d_model
+    x0, attn = rng.standard_normal((3, d)), rng.standard_normal((3, d))
+    Wq, Wo, bo = rng.standard_normal((d, d)) / 8, rng.standard_normal((d, d)) / 8, rng.standard_normal(d)
+    x1 = x0 + attn @ Wo.T + bo
+    assert np.allclose(x1 @ Wq.T, x0 @ Wq.T + attn @ (Wq @ Wo).T + Wq @ bo, rtol=1e-10, atol=1e-10)
+
+
 def test_kv8_per_key_scales():
     """fp8 cross-K/V restatement: one power-of-two scale per (key, head) row of 64 dims, e4m3 elements."""
     rng = np.random.default_rng(2)

@@ -41,6 +41,11 @@ struct tw_ctx {
   tw_config cfg{};
   int dtype = 1;
   bool w8 = false;   // decoder projection weights in MXFP8 (TW_BF16_MXFP8 contexts)
+  // "cross query ahead" (decode_core): the decoder's cross-attention query projection is folded into the two launches before
+  // it, which saves one dependent launch per layer and step.  du = float32 [Bmax][d] pre-activation of that projection.
+  bool fuse_cq = false;
+  float* du = nullptr;
+  float* dstats = nullptr;   // [Bmax][d / tile rows][2] partial LayerNorm statistics of the residual stream (see GemvArgs::stats)
   unsigned char* logit_ws = nullptr;  // block scales of logit_w
   size_t esz = 2;
   int d = 0, H = 0, ffn = 0, V = 0, T = 0, Tp = 0, P = 0, C = 0, Bmax = 0, Le = 0, Ld = 0, n_mels = 0, Ha = 0;
@@ -262,6 +267,10 @@ int tw_create(const tw_config* cfg, tw_ctx** out) {
   c->T = cfg->source_positions; c->Tp = (c->T + 63) / 64 * 64; c->P = cfg->target_positions;
   c->n_mels = cfg->n_mels; c->C = (cfg->n_mels + 63) / 64 * 64;
   c->Bmax = cfg->max_batch; c->Le = cfg->enc_layers; c->Ld = cfg->dec_layers; c->Ha = cfg->n_align_heads;
+  {
+    const char* fe = getenv("TW_FUSE_CQ_LAYOUT");   // 0: do not even lay the weights out for the fused sequence
+    c->fuse_cq = c->d == c->H * 64 && !(fe && atoi(fe) == 0);
+  }
   auto bail = [&](int r) { g_create_error = c->err; tw_destroy(c); return r; };
 #define CALLOC(ptr, bytes, zero) do { int _r = dalloc(c, &(ptr), (bytes), (zero)); if (_r != TW_OK) return bail(_r); } while (0)
 #define CHIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { fail(c, TW_EHIP, "%s: %s", #expr, hipGetErrorString(_e)); return bail(TW_EHIP); } } while (0)
@@ -294,11 +303,14 @@ int tw_create(const tw_config* cfg, tw_ctx** out) {
   auto alloc_layer = [&](LayerW& L, bool decoder) -> int {
     int r;
 #define LA(ptr, n) if ((r = dalloc(c, &(ptr), (n) * e, true)) != TW_OK) return r
-    LA(L.ln1_g, d); LA(L.ln1_b, d); LA(L.wqkv, 3 * d * d); LA(L.bqkv, 3 * d); LA(L.wo, d * d); LA(L.bo, d);
+    // decoder with "cross query ahead": a fourth block of rows behind q|k|v (the folded cross-query weight) and a second one
+    // behind the out-projection (cross-query weight . out-projection), see tw_finalize_weights
+    const size_t qkv_blocks = (decoder && c->fuse_cq) ? 4 : 3, o_blocks = (decoder && c->fuse_cq) ? 2 : 1;
+    LA(L.ln1_g, d); LA(L.ln1_b, d); LA(L.wqkv, qkv_blocks * d * d); LA(L.bqkv, 3 * d); LA(L.wo, o_blocks * d * d); LA(L.bo, d);
     LA(L.ln2_g, d); LA(L.ln2_b, d); LA(L.w1, F * d); LA(L.b1, F); LA(L.w2, d * F); LA(L.b2, d);
     if (decoder) {
-      if ((r = dalloc(c, &L.qkv_gw, 3 * d * 4, true)) != TW_OK) return r;
-      if ((r = dalloc(c, &L.qkv_cb, 3 * d * 4, true)) != TW_OK) return r;
+      if ((r = dalloc(c, &L.qkv_gw, 4 * d * 4, true)) != TW_OK) return r;
+      if ((r = dalloc(c, &L.qkv_cb, 4 * d * 4, true)) != TW_OK) return r;
       if ((r = dalloc(c, &L.qc_gw, d * 4, true)) != TW_OK) return r;
       if ((r = dalloc(c, &L.qc_cb, d * 4, true)) != TW_OK) return r;
       if ((r = dalloc(c, &L.fc1_gw, F * 4, true)) != TW_OK) return r;
@@ -364,6 +376,8 @@ int tw_create(const tw_config* cfg, tw_ctx** out) {
   const size_t Bg = (B + 15) / 16 * 16;  // whole groups of 16 streams
   CALLOC(c->dx0, Bg * d * e, true); CALLOC(c->dx1, Bg * d * e, true); CALLOC(c->dq, B * d * e, true);
   CALLOC(c->datt, Bg * d * e, true); CALLOC(c->dh, Bg * F * e, true);
+  CALLOC(c->du, B * d * 4, true);
+  CALLOC(c->dstats, B * (d / 4) * 2 * 4, true);
   CALLOC(c->logits, B * V * 4, true);
   const size_t Ha = c->Ha > 0 ? c->Ha : 1;
   CALLOC(c->align, B * Ha * P * T * 4, true);
@@ -518,6 +532,15 @@ int tw_finalize_weights(tw_ctx* c, void* stream) {
     HIPCHK(c, launch_fold_ln(c->dtype, L.wqkv, L.wqkv, L.ln1_g, L.ln1_b, L.bqkv, L.qkv_gw, L.qkv_cb, 3 * c->d, c->d, st));
     HIPCHK(c, launch_fold_ln(c->dtype, L.wq_c, L.wq_c, L.lnx_g, L.lnx_b, L.bq_c, L.qc_gw, L.qc_cb, c->d, c->d, st));
     HIPCHK(c, launch_fold_ln(c->dtype, L.w1, L.w1, L.ln2_g, L.ln2_b, L.b1, L.fc1_gw, L.fc1_cb, c->ffn, c->d, st));
+    if (c->fuse_cq) {
+      // cross query ahead.  With x1 = x0 + attn Wo^T + bo (self-attention block) and W' the folded cross-query weight,
+      //   x1 W'^T = x0 W'^T + attn (W' Wo)^T + W' bo:
+      // rows [3d,4d) of the QKV matrix = W' (same operand x0 as q|k|v; ln_cb carries c0 = W' bo, no LayerNorm of ITS input),
+      // rows [d,2d) of the out-projection = W' Wo (same operand attn).  The LayerNorm of x1 is applied by the consumer.
+      const size_t dd = (size_t)c->d * c->d;
+      HIPCHK(c, hipMemcpyAsync(at(L.wqkv, 3 * dd, c->esz), L.wq_c, dd * c->esz, hipMemcpyDeviceToDevice, st));
+      HIPCHK(c, launch_compose(c->dtype, L.wq_c, L.wo, L.bo, at(L.wo, dd, c->esz), L.qkv_cb + 3 * c->d, c->d, c->d, c->d, st));
+    }
   }
   HIPCHK(c, launch_fold_ln(c->dtype, c->logit_w, c->tok_emb, c->dec_ln_g, c->dec_ln_b, nullptr, c->logit_gw, c->logit_cb,
                            c->V, c->d, st));
@@ -526,7 +549,7 @@ int tw_finalize_weights(tw_ctx* c, void* stream) {
     const size_t e = c->esz;
     const size_t Vp = (size_t)(c->V + 15) / 16 * 16;
     size_t mx = Vp * c->d;
-    if ((size_t)3 * c->d * c->d > mx) mx = (size_t)3 * c->d * c->d;
+    if ((size_t)4 * c->d * c->d > mx) mx = (size_t)4 * c->d * c->d;
     if ((size_t)c->ffn * c->d > mx) mx = (size_t)c->ffn * c->d;
     if ((size_t)3 * c->C * c->d > mx) mx = (size_t)3 * c->C * c->d;
     void* scratch = nullptr;
@@ -535,10 +558,10 @@ int tw_finalize_weights(tw_ctx* c, void* stream) {
     // cover 160 instead of 80 compute units (k_decode.hip); TW_SK_TR overrides (16 / 8 / 4) for experiments
     const char* tr_env = getenv("TW_SK_TR");
     const int tr_narrow = tr_env ? atoi(tr_env) : 8;
-    auto retile = [&](void* w, int N, int K, unsigned char** scales, int* tr_out) -> int {
+    auto retile = [&](void* w, int N, int K, unsigned char** scales, int* tr_out, bool narrow = false) -> int {
       const size_t Np = (size_t)(N + 15) / 16 * 16;
       int tr = 16;
-      if (tr_out && N <= 2048 && (tr_narrow == 8 || (tr_narrow == 4 && !c->w8)) && N % 16 == 0) tr = tr_narrow;
+      if (tr_out && (N <= 2048 || narrow) && (tr_narrow == 8 || (tr_narrow == 4 && !c->w8)) && N % 16 == 0) tr = tr_narrow;
       if (tr_out) *tr_out = tr;
       if (c->w8) {  // MXFP8 fragments + block scales replace the bf16 rows in the same buffer (half the bytes + 1/32)
         unsigned char* sc = reinterpret_cast<unsigned char*>(scratch);
@@ -555,8 +578,9 @@ int tw_finalize_weights(tw_ctx* c, void* stream) {
     int r = TW_OK;
     for (int l = 0; l < c->Ld && r == TW_OK; ++l) {
       LayerW& L = c->dec[l];
-      if ((r = retile(L.wqkv, 3 * c->d, c->d, &L.s_qkv, nullptr)) != TW_OK) break;   // K/V scatter epilogue: 16-row tiles
-      if ((r = retile(L.wo, c->d, c->d, &L.s_o, &L.tr_o)) != TW_OK) break;
+      // (both layouts are tile-major, so the unfused launches simply read the leading 3d / d rows of the fused buffers)
+      if ((r = retile(L.wqkv, (c->fuse_cq ? 4 : 3) * c->d, c->d, &L.s_qkv, nullptr)) != TW_OK) break;   // K/V scatter epilogue: 16-row tiles
+      if ((r = retile(L.wo, (c->fuse_cq ? 2 : 1) * c->d, c->d, &L.s_o, &L.tr_o, true)) != TW_OK) break;
       if ((r = retile(L.wq_c, c->d, c->d, &L.s_qc, &L.tr_qc)) != TW_OK) break;
       if ((r = retile(L.wo_c, c->d, c->d, &L.s_oc, &L.tr_oc)) != TW_OK) break;
       if ((r = retile(L.w1, c->ffn, c->d, &L.s_1, &L.tr_1)) != TW_OK) break;
@@ -713,6 +737,12 @@ int tw_cross_kv(tw_ctx* c, int32_t B, void* stream) {
 // ---------------------------------------------------------------------------------------------
 namespace {
 
+// TW_FUSE_CQ=0 at run time: the unfused launch sequence on the same (fused-layout) weights, for A/B measurements
+bool getenv_off_fuse() {
+  static const bool off = []() { const char* e = getenv("TW_FUSE_CQ"); return e && atoi(e) == 0; }();
+  return off;
+}
+
 // one token for every stream: embed -> Ld layers -> final LN + tied logits (fp32)
 int decode_core(tw_ctx* c, int B, hipStream_t st) {
   const int d = c->d, H = c->H, F = c->ffn, T = c->T, P = c->P, dt = c->dtype;
@@ -727,26 +757,35 @@ int decode_core(tw_ctx* c, int B, hipStream_t st) {
     const LayerW& L = c->dec[l];
     void* sk = at(c->self_k, self_layer * l, e);
     void* sv = at(c->self_v, self_layer * l, e);
+    // "cross query ahead" (tw_ctx::fuse_cq): the cross-attention query u = x1 . W'^T is accumulated by the two projections
+    // before it - x0 . W'^T as a fourth segment of the QKV launch, attn . (W' Wo)^T as a second half of the out-projection
+    // launch - and the cross attention applies the folded LayerNorm of x1 itself: 7 instead of 8 dependent launches per layer
+    const bool fq_on = c->fuse_cq && !getenv_off_fuse() && d / (L.tr_o ? L.tr_o : 16) <= 192;
     {  // LN + fused QKV; k,v rows go straight into the cache at position pos
       GemvArgs a{};
-      a.x = xin; a.ldx = d; a.ln_gw = L.qkv_gw; a.ln_cb = L.qkv_cb; a.W = L.wqkv; a.wscale = L.s_qkv; a.N = 3 * d; a.K = d; a.B = B;
+      a.x = xin; a.ldx = d; a.ln_gw = L.qkv_gw; a.ln_cb = L.qkv_cb; a.W = L.wqkv; a.wscale = L.s_qkv; a.N = (fq_on ? 4 : 3) * d; a.K = d; a.B = B;
       a.y = c->dq; a.ldy = d; a.kcache = sk; a.vcache = sv; a.cache_bstride = (long long)Pp * d; a.d_model = d; a.stt = c->stt;
+      a.u = fq_on ? c->du : nullptr;
       HIPCHK(c, launch_gemv(dt, a, st));
     }
     HIPCHK(c, launch_dec_self_attn(dt, c->dq, sk, sv, Pp, c->datt, B, H, c->dec_key_bound > 0 ? c->dec_key_bound : P, c->stt, st));
     {
       GemvArgs a{};
-      a.x = c->datt; a.ldx = d; a.W = L.wo; a.wscale = L.s_o; a.tr = L.tr_o; a.bias = L.bo; a.N = d; a.K = d; a.B = B; a.res = xin; a.ldres = d;
-      a.y = xmid; a.ldy = d;
+      a.x = c->datt; a.ldx = d; a.W = L.wo; a.wscale = L.s_o; a.tr = L.tr_o; a.bias = L.bo; a.N = (fq_on ? 2 : 1) * d; a.K = d; a.B = B;
+      a.res = xin; a.ldres = d; a.y = xmid; a.ldy = d;
+      if (fq_on) { a.u = c->du; a.nsplit = d; a.stats = c->dstats; }
       HIPCHK(c, launch_gemv(dt, a, st));
     }
-    {
+    FusedQ fq{};
+    if (fq_on) {
+      fq.u = c->du; fq.stats = c->dstats; fq.n_part = d / (L.tr_o ? L.tr_o : 16); fq.gw = L.qc_gw; fq.cb = L.qc_cb; fq.d = d;
+    } else {
       GemvArgs a{};
       a.x = xmid; a.ldx = d; a.ln_gw = L.qc_gw; a.ln_cb = L.qc_cb; a.W = L.wq_c; a.wscale = L.s_qc; a.tr = L.tr_qc; a.N = d; a.K = d; a.B = B;
       a.y = c->dq; a.ldy = d;
       HIPCHK(c, launch_gemv(dt, a, st));
     }
-    HIPCHK(c, launch_dec_cross_attn(dt, c->dq, at(c->cross_k, cross_layer * l, c->w8 ? 1 : e), at(c->cross_v, cross_layer * l, c->w8 ? 1 : e),
+    HIPCHK(c, launch_dec_cross_attn(dt, c->dq, fq, at(c->cross_k, cross_layer * l, c->w8 ? 1 : e), at(c->cross_v, cross_layer * l, c->w8 ? 1 : e),
                                     c->datt, B, H, T, c->Tp, c->Ha > 0 ? c->align_slot + (size_t)l * H : nullptr, c->align, c->Ha,
                                     P, c->stt, c->w8 ? c->cross_ksc + (size_t)c->Bmax * H * c->Tp * l : nullptr,
                                     c->w8 ? c->cross_vsc + (size_t)c->Bmax * H * c->Tp * l : nullptr, st));
@@ -874,15 +913,21 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
     c->step_graphs.clear();
     c->step_graph_key = keybuf;
   }
-  auto graph_for = [&](int kb, hipGraphExec_t* out) -> int {
-    const std::string k = std::to_string(kb);
+  // `n` consecutive steps per graph (the step is position-independent: the position lives in device memory): fewer graph
+  // launches for the host to issue when a step is short (turbo, one stream: 0.2 ms)
+  auto graph_for = [&](int kb, int n, hipGraphExec_t* out) -> int {
+    const std::string k = std::to_string(kb) + "x" + std::to_string(n);
     auto it = c->step_graphs.find(k);
     if (it != c->step_graphs.end()) { *out = it->second; return TW_OK; }
     hipGraph_t g = nullptr;
     c->dec_key_bound = kb;
     HIPCHK(c, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    int r = decode_core(c, B, st);
-    hipError_t es = (r == TW_OK) ? launch_sampler(sa, st) : hipSuccess;
+    int r = TW_OK;
+    hipError_t es = hipSuccess;
+    for (int i = 0; i < n && r == TW_OK && es == hipSuccess; ++i) {
+      r = decode_core(c, B, st);
+      if (r == TW_OK) es = launch_sampler(sa, st);
+    }
     hipError_t ee = hipStreamEndCapture(st, &g);
     if (r != TW_OK) { if (g) (void)hipGraphDestroy(g); return r; }
     if (es != hipSuccess || ee != hipSuccess) {
@@ -900,14 +945,19 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
 
   // ---- the loop: step s consumes position s and produces the token at position s+1 ----
   tic(c, 3, st);
-  const int LAG = 4;
-  int steps = 0;
+  // two steps per graph launch: measured +2 % at one turbo stream, +0.3 % at 16 large-v3 streams (4 per launch: +3 % / +0.8 %, but
+  // up to 7 steps past the last <eos> instead of 5); the finished flags are read LAG launches behind so the host never waits
+  static const int group = []() { const char* e = getenv("TW_GRAPH_STEPS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
+  const int LAG = std::max(1, 4 / group);
+  int steps = 0, launches = 0;
   bool all_done = false;
-  for (int s = 0; s < max_len - 1 && !all_done; ++s) {
-    const int kb = std::min(((s + 64) / 64) * 64, ((max_len + 63) / 64) * 64);   // keys [0, kb) cover position s
+  for (int s = 0; s < max_len - 1 && !all_done;) {
+    const int n = (use_graph && s + group <= max_len - 1) ? group : 1;   // steps in this launch
+    const int last = s + n - 1;
+    const int kb = std::min(((last + 64) / 64) * 64, ((max_len + 63) / 64) * 64);   // keys [0, kb) cover positions s .. last
     if (use_graph) {
       hipGraphExec_t ex = nullptr;
-      int r = graph_for(kb, &ex);
+      int r = graph_for(kb, n, &ex);
       if (r != TW_OK) return r;
       HIPCHK(c, hipGraphLaunch(ex, st));
     } else {
@@ -916,17 +966,19 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
       if (r != TW_OK) return r;
       HIPCHK(c, launch_sampler(sa, st));
     }
-    ++steps;
-    const int slot = s % 8;
+    steps += n;
+    s += n;
+    const int slot = launches % 8;
     HIPCHK(c, hipMemcpyAsync(c->h_pinned + slot * 64, c->finished, sizeof(int) * B, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipEventRecord(c->ring_ev[slot], st));
-    if (s >= LAG) {
-      const int ps = (s - LAG) % 8;
+    if (launches >= LAG) {
+      const int ps = (launches - LAG) % 8;
       HIPCHK(c, hipEventSynchronize(c->ring_ev[ps]));
       bool done = true;
       for (int b = 0; b < B; ++b) done &= (c->h_pinned[ps * 64 + b] != 0);
       all_done = done;
     }
+    ++launches;
   }
   toc(c, 3, st);
   c->last_steps = steps;

@@ -247,8 +247,12 @@ void skinny_mfma_kernel(GemvArgs a) {
   T* kcache = reinterpret_cast<T*>(a.kcache);
   T* vcache = reinterpret_cast<T*>(a.vcache);
   const DecState* stt = a.stt;
+  float* u_p = a.u;              // "cross query ahead" (tw_common.h): float32 [B][d_model] pre-activation, null = off
+  float* stats_p = a.stats;
+  const int nsplit = a.nsplit;   // SK_RES: rows >= nsplit accumulate into u (the launcher sets N when there is no such half)
   asm volatile("" ::"s"(x), "s"(W), "s"(bias), "s"(res), "s"(gw_p), "s"(cb_p), "s"(K), "s"(N), "s"(B), "s"(a.gelu), "s"(ldy),
-               "s"(RG), "s"(d_model), "s"(cache_bstride), "s"(y), "s"(y_f32), "s"(kcache), "s"(vcache), "s"(stt), "s"(wscale));
+               "s"(RG), "s"(d_model), "s"(cache_bstride), "s"(y), "s"(y_f32), "s"(kcache), "s"(vcache), "s"(stt), "s"(wscale),
+               "s"(u_p), "s"(nsplit), "s"(stats_p));
   int cur_pos = 0;
 #ifdef TW_PROBE_TS
   cur_pos = stt->pos;
@@ -275,16 +279,25 @@ void skinny_mfma_kernel(GemvArgs a) {
   // --- request helpers: all unconditional, addresses clamped into the matrix ---
   auto load_epi = [&](int tile, float& c, float& gwv, float (&r)[CG]) {
     const int n = min(tile * TR + min(ei, TR - 1), N - 1);
+    const bool second = EPI == SK_RES && n >= nsplit;   // row of the composed half: its "residual" is u, it has no bias
     if (LN) {
       gwv = gw_p[n];
       c = cb_p[n];
     } else {
-      const float v = (float)(bias ? bias : W)[bias ? n : 0];
-      c = bias ? v : 0.f;
+      const float v = (float)(bias ? bias : W)[(bias && !second) ? n : 0];
+      c = (bias && !second) ? v : 0.f;
     }
     if (EPI == SK_RES) {
+      // both operands are requested unconditionally (clamped addresses) and selected afterwards: no load inside a branch
+      const float* up = u_p ? u_p : reinterpret_cast<const float*>(W);
+      const int usz = u_p ? N - nsplit : 0;
+      const int nu = (u_p && second) ? n - nsplit : 0;
 #pragma unroll
-      for (int g = 0; g < CG; ++g) r[g] = (float)res[(long long)g * 16 * N + tw_xt_index<T>(ej, n)];
+      for (int g = 0; g < CG; ++g) {
+        const float rb = (float)res[(long long)g * 16 * nsplit + tw_xt_index<T>(ej, second ? 0 : n)];
+        const float ru = up[(long long)min(g * 16 + ej, B - 1) * usz + nu];
+        r[g] = second ? ru : rb;
+      }
     }
   };
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(
@@ -442,6 +455,7 @@ void skinny_mfma_kernel(GemvArgs a) {
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) v += red[(w * CG + g) * 256 + i * 16 + j];
+        const float vraw = v;
         if (LN) {
           if (!MULTI || grp == 0) {
             float sx = 0.f, sxx = 0.f;
@@ -457,18 +471,34 @@ void skinny_mfma_kernel(GemvArgs a) {
         }
         if (EPI == SK_GELU) v = gelu_exact<T>(v);
         if (EPI == SK_RES) v += e_res[g];
+        if (EPI == SK_RES && u_p) {   // (kernel-uniform) LayerNorm statistics of the residual rows of this tile, as stored
+          const float xs = (tile < n_tiles && n < nsplit && jg < B && i < TR) ? (float)(T)v : 0.f;
+          const float s1 = tw_row16_sum(xs), s2 = tw_row16_sum(xs * xs);   // the 16 threads of one stream are one DPP row
+          if (i == 0 && jg < B && tile < n_tiles && tile * TR < nsplit) {
+            float* sp = stats_p + ((long long)jg * (nsplit / TR) + tile) * 2;
+            sp[0] = s1;
+            sp[1] = s2;
+          }
+        }
         if (tile < n_tiles && n < N && jg < B && i < TR) {
           if (EPI == SK_F32) {
             y_f32[(long long)jg * N + n] = v;
           } else if (EPI == SK_KV) {
             const int seg = n / d_model;  // 0: query -> y, 1: key -> K cache, 2: value -> V^T cache   (one predicated store)
             const int nn = n - seg * d_model, hh = nn >> 6, cc = nn & 63;
-            const long long hb = (long long)jg * cache_bstride + (long long)hh * (cache_bstride / (d_model >> 6));  // (stream, head)
-            T* dst = seg == 0 ? y + (long long)jg * ldy + n
-                              : (seg == 1 ? kcache + hb + tw_kf_index<T>(cur_pos, cc) : vcache + hb + tw_vtf_index<T>(cur_pos, cc));
-            *dst = (T)v;
+            if (seg == 3) {   // cross query ahead: x . W'^T + c0 WITHOUT this LayerNorm (its own is applied by the consumer)
+              u_p[(long long)jg * d_model + nn] = vraw + e_c;
+            } else {
+              const long long hb = (long long)jg * cache_bstride + (long long)hh * (cache_bstride / (d_model >> 6));  // (stream, head)
+              T* dst = seg == 0 ? y + (long long)jg * ldy + n
+                                : (seg == 1 ? kcache + hb + tw_kf_index<T>(cur_pos, cc) : vcache + hb + tw_vtf_index<T>(cur_pos, cc));
+              *dst = (T)v;
+            }
           } else if (EPI == SK_STORE) {
             y[(long long)jg * ldy + n] = (T)v;  // row-major [B][ldy] (the attention kernels' query operand)
+          } else if (EPI == SK_RES) {
+            if (n >= nsplit) u_p[(long long)jg * (N - nsplit) + (n - nsplit)] = v;   // composed half: u += attn . Wc^T
+            else y[(long long)g * 16 * nsplit + tw_xt_index<T>(j, n)] = (T)v;       // residual stream, fragment-major
           } else {
             y[(long long)g * 16 * N + tw_xt_index<T>(j, n)] = (T)v;    // feeds the next projection: fragment-major
           }
@@ -564,6 +594,30 @@ __global__ __launch_bounds__(256) void fold_ln_kernel(T* __restrict__ W, const T
   }
 }
 
+// Load-time composition for "cross query ahead": out = A . Bm (row-major [N][J] x [J][K], float32 accumulation, one rounding
+// to T), c0 = A . bvec.  Runs once per decoder layer in tw_finalize_weights: plain 16x16 LDS tiles, nothing to tune.
+template <typename T>
+__global__ __launch_bounds__(256) void compose_kernel(const T* __restrict__ A, const T* __restrict__ Bm, const T* __restrict__ bvec,
+                                                      T* __restrict__ out, float* __restrict__ c0, int N, int J, int K) {
+  __shared__ float ta[16][17], tb[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int n = blockIdx.y * 16 + ty, k = blockIdx.x * 16 + tx;
+  float acc = 0.f, accb = 0.f;
+  for (int j0 = 0; j0 < J; j0 += 16) {
+    ta[ty][tx] = (n < N && j0 + tx < J) ? (float)A[(long long)n * J + j0 + tx] : 0.f;
+    tb[ty][tx] = (j0 + ty < J && k < K) ? (float)Bm[(long long)(j0 + ty) * K + k] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc = fmaf(ta[ty][j], tb[j][tx], acc);
+    if (blockIdx.x == 0 && tx == 0 && bvec) {
+      for (int j = 0; j < 16 && j0 + j < J; ++j) accb = fmaf(ta[ty][j], (float)bvec[j0 + j], accb);
+    }
+    __syncthreads();
+  }
+  if (n < N && k < K) out[(long long)n * K + k] = (T)acc;
+  if (blockIdx.x == 0 && tx == 0 && n < N && c0) c0[n] = accb;
+}
+
 // ---------------------------------------------------------------------------------------------
 // single-query attention (decoder self-attention over the growing cache, cross-attention over the
 // cached encoder K/V).  One workgroup per (stream, head), NW wavefronts, each owning 64 consecutive
@@ -581,15 +635,57 @@ __global__ __launch_bounds__(256) void fold_ln_kernel(T* __restrict__ W, const T
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_max(float v) { return tw_wave_max(v); }
 
+// Fused query operand (FusedQ, tw_common.h): the query of the cross attention is the LayerNorm'd projection of the residual
+// stream, q = rstd (u - mean gw) + cb, with u = x . W'^T accumulated by the two projections that ran before (api.hip:
+// decode_core).  Every wavefront folds the partial row statistics the residual launch left behind (one coalesced 8-byte
+// request per lane and 64 partials; reading the fragment-major row itself costs 64 cache lines per request and made the
+// launch 3 us slower) and lane l forms element l of the head's query; the MFMA operand order is then read back from a 64-element LDS
+// row PRIVATE to the wavefront (LDS operations of one wavefront stay in order: no barrier).  All requests are issued before
+// the K / V^T requests of the caller and consumed after them, i.e. this arithmetic runs while the K fragments are in flight.
+template <typename T>
+struct QRaw {
+  static constexpr int MAXP = 3;   // partial statistics per lane: n_part <= 192 (d = 1280 in 8-row tiles: 160)
+  float u, gw, cb;
+  f32x2_t st[MAXP];
+};
+template <typename T>
+__device__ __forceinline__ void fq_request(QRaw<T>& r, const FusedQ& fq, int b, int h, int lane) {
+  r.u = fq.u[(long long)b * fq.d + h * 64 + lane];
+  r.gw = fq.gw[h * 64 + lane];
+  r.cb = fq.cb[h * 64 + lane];
+  const f32x2_t* sp = reinterpret_cast<const f32x2_t*>(fq.stats) + (long long)b * fq.n_part;
+#pragma unroll
+  for (int m = 0; m < QRaw<T>::MAXP; ++m) r.st[m] = sp[min(lane + 64 * m, fq.n_part - 1)];
+}
+// qrow: this wavefront's 64-element LDS row.  Returns with the element `lane` of the query stored there (type T).
+template <typename T>
+__device__ __forceinline__ void fq_finish(const QRaw<T>& r, const FusedQ& fq, int lane, T* qrow) {
+  float s = 0.f, ss = 0.f;
+#pragma unroll
+  for (int m = 0; m < QRaw<T>::MAXP; ++m) {
+    const bool on = lane + 64 * m < fq.n_part;
+    s += on ? r.st[m][0] : 0.f;
+    ss += on ? r.st[m][1] : 0.f;
+  }
+  s = tw_wave_sum(s);
+  ss = tw_wave_sum(ss);
+  const float inv_k = __builtin_amdgcn_rcpf((float)fq.d);
+  const float mean = s * inv_k;
+  const float rstd = __frsqrt_rn(fmaxf(ss * inv_k - mean * mean, 0.f) + 1e-5f);
+  qrow[lane] = (T)(rstd * (r.u - mean * r.gw) + r.cb);
+}
+
 // SINGLE: n_bound <= NW*64, so every K and V^T fragment of the head is requested before anything is waited for
 // (one memory round trip per head); otherwise two passes over chunks of NW*64 keys.
 // n_keys = valid keys (rest masked), n_bound = keys addressable (multiple of 64, <= rows allocated per head).
 // sc: LDS float[n_bound] (unnormalised probabilities on return); red: LDS float[2*NW + NW*64].
 // Returns 1/L in every thread; threads 0..63 write the context vector (fragment-major activation layout).
-template <typename T, int NW, bool SINGLE>
+// FQ: the query comes as a FusedQ (stream fq_b, head fq_h; qst = LDS T[NW][64]) instead of through q
+template <typename T, int NW, bool SINGLE, bool FQ = false>
 __device__ __forceinline__ float attn_mfma_block(const T* __restrict__ q, const T* __restrict__ kf, const T* __restrict__ vtf,
                                                  int n_keys, int n_bound, float* sc, float* red, T* __restrict__ out_base,
-                                                 int out_j, int out_k0) {
+                                                 int out_j, int out_k0, const FusedQ& fq = FusedQ{}, int fq_b = 0, int fq_h = 0,
+                                                 T* qst = nullptr) {
   constexpr int E = ElemTraits<T>::kPer16B;
   constexpr int DS = 64 / (4 * E);  // dim steps per key tile (QK^T) = key steps per 64 keys (P.V)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -608,11 +704,22 @@ __device__ __forceinline__ float attn_mfma_block(const T* __restrict__ q, const 
 #pragma unroll
     for (int i = 0; i < 4 * DS; ++i) vfr[i] = *reinterpret_cast<const u32x4_t*>(p + (long long)i * 64 * E);
   };
+  QRaw<T> qr;
+  if constexpr (FQ) {
+    fq_request<T>(qr, fq, fq_b, fq_h, lane);
+  } else {
 #pragma unroll
-  for (int ds = 0; ds < DS; ++ds) qf[ds] = *reinterpret_cast<const u32x4_t*>(q + ds * 4 * E + kq * E);
+    for (int ds = 0; ds < DS; ++ds) qf[ds] = *reinterpret_cast<const u32x4_t*>(q + ds * 4 * E + kq * E);
+  }
   load_k(wave);
   if (SINGLE) load_v(wave);
   __builtin_amdgcn_sched_barrier(0);
+  if constexpr (FQ) {
+    T* qrow = qst + wave * 64;
+    fq_finish<T>(qr, fq, lane, qrow);
+#pragma unroll
+    for (int ds = 0; ds < DS; ++ds) qf[ds] = *reinterpret_cast<const u32x4_t*>(qrow + ds * 4 * E + kq * E);
+  }
 
   // ---- scores: D[i = key (lane>>4)*4 + r][j] identical in every column j; column 0 lanes publish them ----
   float m = -1.0e30f;
@@ -714,11 +821,13 @@ __device__ __forceinline__ void kv8_widen(const u32x4_t& raw, float X, u32x4_t& 
 // 30 s).  At 32 registers per group and operand the whole head fits the register file, so - unlike the bf16 kernel, which
 // falls back to two dependent passes above 512 keys - EVERY fragment of the head is requested before anything is waited for:
 // one memory round trip per head whatever the chunk length.
-template <int NW, int G>
+template <int NW, int G, bool FQ = false>
 __device__ __forceinline__ float attn_mfma_block_kv8(const bf16_t* __restrict__ q, const unsigned char* __restrict__ kf8,
                                                      const unsigned char* __restrict__ vtf8, const unsigned char* __restrict__ ksc,
                                                      const unsigned char* __restrict__ vsc, int n_keys, int n_bound, float* sc,
-                                                     float* scv, float* red, bf16_t* __restrict__ out_base, int out_j, int out_k0) {
+                                                     float* scv, float* red, bf16_t* __restrict__ out_base, int out_j, int out_k0,
+                                                     const FusedQ& fq = FusedQ{}, int fq_b = 0, int fq_h = 0,
+                                                     bf16_t* qst = nullptr) {
   typedef bf16_t T;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -726,8 +835,13 @@ __device__ __forceinline__ float attn_mfma_block_kv8(const bf16_t* __restrict__ 
   const int last64 = n_bound / 64 - 1;
   u32x4_t qf[2], kraw[G][4], vraw[G][4];
   unsigned ks4[G], vsb[G];
-  qf[0] = *reinterpret_cast<const u32x4_t*>(q + kq * 16);
-  qf[1] = *reinterpret_cast<const u32x4_t*>(q + kq * 16 + 8);
+  QRaw<T> qr;
+  if constexpr (FQ) {
+    fq_request<T>(qr, fq, fq_b, fq_h, lane);
+  } else {
+    qf[0] = *reinterpret_cast<const u32x4_t*>(q + kq * 16);
+    qf[1] = *reinterpret_cast<const u32x4_t*>(q + kq * 16 + 8);
+  }
 #pragma unroll
   for (int g = 0; g < G; ++g) {  // 64 keys = 4 tiles of 1 KiB + their 64 scale bytes ([group][key % 16][tile]: one 32-bit load)
     const int gi = min(g * NW + wave, last64);
@@ -745,6 +859,12 @@ __device__ __forceinline__ float attn_mfma_block_kv8(const bf16_t* __restrict__ 
     vsb[g] = vsc[gi * 64 + lane];
   }
   __builtin_amdgcn_sched_barrier(0);
+  if constexpr (FQ) {
+    T* qrow = qst + wave * 64;
+    fq_finish<T>(qr, fq, lane, qrow);
+    qf[0] = *reinterpret_cast<const u32x4_t*>(qrow + kq * 16);
+    qf[1] = *reinterpret_cast<const u32x4_t*>(qrow + kq * 16 + 8);
+  }
 
   float m = -1.0e30f;
 #pragma unroll
@@ -846,8 +966,8 @@ __global__ __launch_bounds__(NW * 64) void dec_self_attn_kernel(const T* __restr
                                 out + (long long)(b >> 4) * 16 * H * 64, b & 15, h * 64);  // fragment-major, groups of 16 streams
 }
 
-template <typename T, bool SINGLE>
-__global__ __launch_bounds__(512) void dec_cross_attn_kernel(const T* __restrict__ q, const T* __restrict__ ck,
+template <typename T, bool SINGLE, bool FQ>
+__global__ __launch_bounds__(512) void dec_cross_attn_kernel(const T* __restrict__ q, FusedQ fq, const T* __restrict__ ck,
                                                               const T* __restrict__ cv, T* __restrict__ out, int H,
                                                               int Tlen, int Tp, const int* __restrict__ align_slot,
                                                               float* __restrict__ align, int Ha, int P,
@@ -855,12 +975,13 @@ __global__ __launch_bounds__(512) void dec_cross_attn_kernel(const T* __restrict
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* sc = reinterpret_cast<float*>(smem);  // [Tp] scores -> unnormalised probabilities
   __shared__ float red[2 * 8 + 8 * 64];
+  __shared__ __attribute__((aligned(16))) T qst[FQ ? 8 * 64 : 8];
   asm volatile("" ::"s"(q), "s"(ck), "s"(cv), "s"(out), "s"(H), "s"(Tlen), "s"(Tp), "s"(align_slot), "s"(align), "s"(Ha), "s"(P),
-               "s"(stt));
+               "s"(stt), "s"(fq.u), "s"(fq.stats), "s"(fq.n_part), "s"(fq.gw), "s"(fq.cb), "s"(fq.d));
   const int h = blockIdx.x, b = blockIdx.y;
   const long long base = ((long long)b * H + h) * Tp * 64;
-  const float inv = attn_mfma_block<T, 8, SINGLE>(q + ((long long)b * H + h) * 64, ck + base, cv + base, Tlen, Tp, sc, red,
-                                                  out + (long long)(b >> 4) * 16 * H * 64, b & 15, h * 64);
+  const float inv = attn_mfma_block<T, 8, SINGLE, FQ>(q + ((long long)b * H + h) * 64, ck + base, cv + base, Tlen, Tp, sc, red,
+                                                      out + (long long)(b >> 4) * 16 * H * 64, b & 15, h * 64, fq, b, h, qst);
   const int slot = align_slot ? align_slot[h] : -1;
   if (slot >= 0) {  // A11 side output: softmax row of an alignment head
     __syncthreads();
@@ -869,8 +990,8 @@ __global__ __launch_bounds__(512) void dec_cross_attn_kernel(const T* __restrict
   }
 }
 
-template <int G>
-__global__ __launch_bounds__(512) void dec_cross_attn_kv8_kernel(const bf16_t* __restrict__ q, const unsigned char* __restrict__ ck,
+template <int G, bool FQ>
+__global__ __launch_bounds__(512) void dec_cross_attn_kv8_kernel(const bf16_t* __restrict__ q, FusedQ fq, const unsigned char* __restrict__ ck,
                                                                   const unsigned char* __restrict__ cv,
                                                                   const unsigned char* __restrict__ ksc,
                                                                   const unsigned char* __restrict__ vsc, bf16_t* __restrict__ out,
@@ -881,12 +1002,14 @@ __global__ __launch_bounds__(512) void dec_cross_attn_kv8_kernel(const bf16_t* _
   float* sc = reinterpret_cast<float*>(smem);  // [Tp] scores -> unnormalised probabilities
   float* scv = sc + Tp;                        // [Tp] probabilities x V scale
   __shared__ float red[2 * 8 + 8 * 64];
+  __shared__ __attribute__((aligned(16))) bf16_t qst[FQ ? 8 * 64 : 8];
   asm volatile("" ::"s"(q), "s"(ck), "s"(cv), "s"(ksc), "s"(vsc), "s"(out), "s"(H), "s"(Tlen), "s"(Tp), "s"(align_slot), "s"(align),
-               "s"(Ha), "s"(P), "s"(stt));
+               "s"(Ha), "s"(P), "s"(stt), "s"(fq.u), "s"(fq.stats), "s"(fq.n_part), "s"(fq.gw), "s"(fq.cb), "s"(fq.d));
   const int h = blockIdx.x, b = blockIdx.y;
   const long long hb = ((long long)b * H + h) * Tp;
-  const float inv = attn_mfma_block_kv8<8, G>(q + ((long long)b * H + h) * 64, ck + hb * 64, cv + hb * 64, ksc + hb, vsc + hb,
-                                                   Tlen, Tp, sc, scv, red, out + (long long)(b >> 4) * 16 * H * 64, b & 15, h * 64);
+  const float inv = attn_mfma_block_kv8<8, G, FQ>(q + ((long long)b * H + h) * 64, ck + hb * 64, cv + hb * 64, ksc + hb, vsc + hb,
+                                                  Tlen, Tp, sc, scv, red, out + (long long)(b >> 4) * 16 * H * 64, b & 15, h * 64,
+                                                  fq, b, h, qst);
   const int slot = align_slot ? align_slot[h] : -1;
   if (slot >= 0) {  // A11 side output: softmax row of an alignment head
     __syncthreads();
@@ -1249,8 +1372,17 @@ static hipError_t skinny_launch(const GemvArgs& a, hipStream_t st) {
 }
 
 template <typename T>
-static hipError_t gemv_b(const GemvArgs& a, hipStream_t st) {
-  if (a.B < 1 || a.B > 64) return hipErrorInvalidValue;
+static hipError_t gemv_b(const GemvArgs& a0, hipStream_t st) {
+  if (a0.B < 1 || a0.B > 64) return hipErrorInvalidValue;
+  GemvArgs a = a0;
+  if (a.kcache) {   // QKV launch: a fourth segment of d_model rows only together with its destination
+    if ((a.N == 4 * a.d_model) != (a.u != nullptr)) return hipErrorInvalidValue;
+    a.nsplit = a.N;
+  } else if (a.u) {  // residual launch with a composed half
+    if (!a.res || !a.stats || a.nsplit <= 0 || a.nsplit >= a.N || a.nsplit % 16 != 0) return hipErrorInvalidValue;
+  } else {
+    a.nsplit = a.N;
+  }
   return skinny_launch<T>(a, st);
 }
 
@@ -1275,26 +1407,37 @@ hipError_t launch_dec_self_attn(int dtype, const void* q, const void* kc, const 
   return hipGetLastError();
 }
 
-hipError_t launch_dec_cross_attn(int dtype, const void* q, const void* ck, const void* cv, void* out, int B, int H,
+hipError_t launch_dec_cross_attn(int dtype, const void* q, const FusedQ& fq, const void* ck, const void* cv, void* out, int B, int H,
                                  int T, int Tp, const int* align_slot_for_head, float* align, int Ha, int P,
                                  const DecState* stt, const unsigned char* ksc, const unsigned char* vsc, hipStream_t st) {
   if (Tp % 64 != 0 || Tp < T) return hipErrorInvalidValue;
   const bool single = Tp <= 512;
+  const bool f = fq.u != nullptr;
+  if (f) {   // the partial statistics must fit the per-lane request budget of fq_request
+    if (!fq.stats || !fq.gw || !fq.cb || fq.d != H * 64 || fq.n_part < 1 || fq.n_part > 192) return hipErrorInvalidValue;
+  } else if (!q) {
+    return hipErrorInvalidValue;
+  }
   if (ksc || vsc) {  // fp8 K / V^T caches with per-key scales (TW_BF16_MXFP8 contexts)
     if (!ksc || !vsc || dtype != 1) return hipErrorInvalidValue;
     const size_t lds8 = (size_t)Tp * sizeof(float) * 2;
-#define CA8_GO(GV) hipLaunchKernelGGL((dec_cross_attn_kv8_kernel<GV>), dim3(H, B), dim3(512), lds8, st, (const bf16_t*)q, \
-                                      (const unsigned char*)ck, (const unsigned char*)cv, ksc, vsc, (bf16_t*)out, H, T, Tp,      \
-                                      align_slot_for_head, align, Ha, P, stt)
-    if (Tp <= 512) CA8_GO(1); else if (Tp <= 1024) CA8_GO(2); else if (Tp <= 1536) CA8_GO(3); else return hipErrorInvalidValue;
+#define CA8_GO(GV, FV) hipLaunchKernelGGL((dec_cross_attn_kv8_kernel<GV, FV>), dim3(H, B), dim3(512), lds8, st, (const bf16_t*)q, fq, \
+                                          (const unsigned char*)ck, (const unsigned char*)cv, ksc, vsc, (bf16_t*)out, H, T, Tp,       \
+                                          align_slot_for_head, align, Ha, P, stt)
+#define CA8_PICK(FV) do { if (Tp <= 512) CA8_GO(1, FV); else if (Tp <= 1024) CA8_GO(2, FV); else if (Tp <= 1536) CA8_GO(3, FV);      \
+                          else return hipErrorInvalidValue; } while (0)
+    if (f) CA8_PICK(true); else CA8_PICK(false);
+#undef CA8_PICK
 #undef CA8_GO
     return hipGetLastError();
   }
   const size_t lds = (size_t)Tp * sizeof(float);
-#define CA_GO(TT, SV) hipLaunchKernelGGL((dec_cross_attn_kernel<TT, SV>), dim3(H, B), dim3(512), lds, st, (const TT*)q, (const TT*)ck, \
-                                         (const TT*)cv, (TT*)out, H, T, Tp, align_slot_for_head, align, Ha, P, stt)
-  if (dtype == 1) { if (single) CA_GO(bf16_t, true); else CA_GO(bf16_t, false); }
-  else { if (single) CA_GO(float, true); else CA_GO(float, false); }
+#define CA_GO(TT, SV, FV) hipLaunchKernelGGL((dec_cross_attn_kernel<TT, SV, FV>), dim3(H, B), dim3(512), lds, st, (const TT*)q, fq,   \
+                                             (const TT*)ck, (const TT*)cv, (TT*)out, H, T, Tp, align_slot_for_head, align, Ha, P, stt)
+#define CA_PICK(TT) do { if (single) { if (f) CA_GO(TT, true, true); else CA_GO(TT, true, false); }                                  \
+                         else { if (f) CA_GO(TT, false, true); else CA_GO(TT, false, false); } } while (0)
+  if (dtype == 1) CA_PICK(bf16_t); else CA_PICK(float);
+#undef CA_PICK
 #undef CA_GO
   return hipGetLastError();
 }
@@ -1338,6 +1481,18 @@ hipError_t launch_quant_mx8(const void* src_bf16, void* dst_fp8, void* dst_scale
   const long long total = (long long)((N + 15) / 16) * (K / 128) * 64;
   hipLaunchKernelGGL(quant_mx8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const bf16_t*)src_bf16,
                      (unsigned char*)dst_fp8, (unsigned char*)dst_scales, N, K, tr);
+  return hipGetLastError();
+}
+
+hipError_t launch_compose(int dtype, const void* A, const void* Bm, const void* bvec, void* out, float* c0, int N, int J, int K,
+                          hipStream_t st) {
+  const dim3 grid((K + 15) / 16, (N + 15) / 16);
+  if (dtype == 1)
+    hipLaunchKernelGGL(compose_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)A, (const bf16_t*)Bm, (const bf16_t*)bvec,
+                       (bf16_t*)out, c0, N, J, K);
+  else
+    hipLaunchKernelGGL(compose_kernel<float>, grid, dim3(256), 0, st, (const float*)A, (const float*)Bm, (const float*)bvec,
+                       (float*)out, c0, N, J, K);
   return hipGetLastError();
 }
 

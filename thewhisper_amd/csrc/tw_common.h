@@ -8,6 +8,7 @@ typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;  // a 16-B register quad (native vector: stays in VGPRs)
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 
@@ -178,6 +179,13 @@ struct GemvArgs {
   void* kcache; void* vcache; long long cache_bstride; int d_model; const DecState* stt;
   int rg;  // skinny path: 16-row tiles walked per workgroup (set by the launcher)
   int tr;  // weight rows per workgroup tile the weights were laid out for by launch_tile_weights (0 / 16, 8 or 4)
+  // "cross query ahead" (api.hip: decode_core): float32 [B][d_model] pre-activation of the NEXT LayerNorm'd projection.
+  //  * QKV launch (kcache set): rows [3d,4d) of W are that projection's folded weight; x . W^T + ln_cb is stored here;
+  //  * residual launch (res set, nsplit = d_model < N): rows [nsplit,N) of W are the composed matrix (projection . this one);
+  //    they add their product to u in place, rows [0,nsplit) produce the residual stream as usual.
+  //    They also leave (sum, sum of squares) of the residual rows they produced in stats[stream][tile][2] (tile = n / tr):
+  //    the consumer of u applies the folded LayerNorm with them.
+  float* u; int nsplit; float* stats;
 };
 hipError_t launch_gemv(int dtype, const GemvArgs& a, hipStream_t st);
 hipError_t init_decode_kernels();
@@ -196,9 +204,20 @@ hipError_t launch_dec_self_attn(int dtype, const void* q, const void* kc, const 
 // cross attention over cached encoder K/V: ck/cv per (stream, head) Tp keys fragment-major; out fragment-major; align rows:
 // for head h with align_slot[h] >= 0 write the softmax row to align[((b*Ha + slot)*P + pos)*T + t]
 // ksc / vsc non-null: ck / cv are the fp8 caches above (bf16 contexts only), these their per-key scale bytes [B][H][Tp]
-hipError_t launch_dec_cross_attn(int dtype, const void* q, const void* ck, const void* cv, void* out, int B, int H,
+// Query operand: either q [B,d] row-major (T), or - fq.u non-null - the un-normalised pre-activation u of the folded
+// LayerNorm'd query projection: q = rstd (u - mean gw) + cb with the statistics of x's row taken inside the launch.
+struct FusedQ {
+  const float* u;    // [B][d] float32
+  const float* stats; int n_part;   // [B][n_part][2]: partial (sum, sum of squares) of the residual row the LayerNorm normalises
+  const float* gw; const float* cb;   // folded-LayerNorm companions of the query projection (float32 [d])
+  int d;
+};
+hipError_t launch_dec_cross_attn(int dtype, const void* q, const FusedQ& fq, const void* ck, const void* cv, void* out, int B, int H,
                                  int T, int Tp, const int* align_slot_for_head, float* align, int Ha, int P,
                                  const DecState* stt, const unsigned char* ksc, const unsigned char* vsc, hipStream_t st);
+// load-time composition for "cross query ahead": out[n][k] = sum_j A[n][j] Bm[j][k] (row-major, T), c0[n] = sum_j A[n][j] bvec[j]
+hipError_t launch_compose(int dtype, const void* A, const void* Bm, const void* bvec, void* out, float* c0, int N, int J, int K,
+                          hipStream_t st);
 
 struct SamplerPartial { float bt_v; int bt_i; float bs_v; int bs_i; float sum; int pad_[3]; };  // per vocabulary slice
 struct SamplerArgs {   // A10 + argmax + bookkeeping
