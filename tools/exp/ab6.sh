@@ -1,0 +1,8 @@
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-$(pwd)}
+run() { env $1 python bench.py --no-cpu-baseline --no-pipeline-leg --latency-iters 0 --steps 6 $2 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1 $2', d['value'], d['roofline']['avg_step_ms'])"; }
+for i in 1 2; do
+  run "TW_X=0" ""
+  run "THEWHISPER_LIB=$PWD/thewhisper_amd/lib/variants/libCA3.so" ""
+  run "TW_SK_TR_O16=1" ""
+done
