@@ -477,7 +477,7 @@ def main(argv=None):
             "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage.items()},
             "decode_tok_per_s": round(B * args.new_tokens / (greedy_ms * 1e-3), 1) if greedy_ms > 0 else None,
             "roofline": {
-                "kernel": "decode step = one replay of the captured step graph (weight-streaming projections + single-query attention "
+                "kernel": "decode step (the captured graph replays two at a time; weight-streaming projections + single-query attention "
                           "over the K/V caches + sampler); averaged over all steps of a greedy call",
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
