@@ -151,3 +151,27 @@ def test_special_id_cache_is_transparent():
     plain.add_special_tokens({"additional_special_tokens": ["<|brandnew|>"]})
     assert tok.all_special_ids == plain.all_special_ids
     assert cache_special_ids(tok) is tok
+
+
+def test_model_size_s_maps_to_fp8_only_by_deployment_switch(monkeypatch):
+    """The reference's model_size="S" is its quantised engine flavour (R:thestage_speechkit/nvidia/asr_pipeline.py:47-56).  Here
+    every size runs the bf16 kernels unless the deployment sets THEWHISPER_SIZE_S=fp8 (or the caller passes decoder_weights)."""
+    seen = []
+
+    def spy_factory(dims, T, max_batch, dtype, heads, dev):
+        seen.append(dtype)
+        return oracle_engine_factory(dims, T, max_batch, "f32", heads, dev)
+
+    def build(size, **kw):
+        from thewhisper_amd import ASRPipeline
+        dims = wo.PRESETS["micro"]
+        model = hr.build_hf_model(dims, wo.make_weights(dims, 0)).to(torch.bfloat16)
+        return ASRPipeline(model, feature_extractor=hr.build_feature_extractor(dims, 10), tokenizer=hr.build_tokenizer(dims),
+                           model_size=size, chunk_length_s=10, device="cpu", torch_dtype=torch.bfloat16, engine_factory=spy_factory, **kw)
+
+    build("S")
+    monkeypatch.setenv("THEWHISPER_SIZE_S", "fp8")
+    build("S")
+    build("XL")
+    build("S", decoder_weights="bf16")
+    assert seen == ["bf16", "fp8", "bf16", "bf16"]

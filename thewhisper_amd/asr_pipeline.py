@@ -52,9 +52,12 @@ class ASRPipeline(AutomaticSpeechRecognitionPipeline):
             raise ValueError(f"Invalid model_size: {model_size}")
         # model_size selects a TheStage engine flavour on NVIDIA (S = quantised, XL = fp16).  On MI355X every size maps to the
         # bf16 kernels (results identical to the reference arithmetic within the bf16 tolerance); the quantised flavour is an
-        # explicit opt-in, ``decoder_weights="fp8"`` (BASELINE config 5: MXFP8 decoder projection weights).
+        # explicit opt-in, ``decoder_weights="fp8"`` (BASELINE config 5: MXFP8 decoder projection weights) - or, for callers
+        # that cannot change their code, the deployment switch THEWHISPER_SIZE_S=fp8, which gives model_size="S" that meaning.
         if decoder_weights not in (None, "bf16", "fp8"):
             raise ValueError(f"Invalid decoder_weights: {decoder_weights}")
+        if decoder_weights is None and model_size == "S" and os.environ.get("THEWHISPER_SIZE_S", "").lower() == "fp8":
+            decoder_weights = "fp8"
 
         if type(model) is str:
             model_name = model
