@@ -153,6 +153,39 @@ def test_special_id_cache_is_transparent():
     assert cache_special_ids(tok) is tok
 
 
+def test_short_decode_memo_is_transparent():
+    """tokenizer_cache memoises decode() of <= 4 ids with default options (what HF's word splitting calls once per token):
+    every such call returns what HF's decode returns, repeated calls hit the memo, other argument shapes bypass it, and a
+    change of the special-token tables drops it."""
+    from thewhisper_amd.tokenizer_cache import cache_special_ids
+
+    dims = wo.PRESETS["micro"]
+    plain, tok = hr.build_tokenizer(dims), cache_special_ids(hr.build_tokenizer(dims))
+    rng = np.random.default_rng(0)
+    pool = [50257, 50258, 50259, 50360, 50364, 50365, 50400, 51865, 0, 1, 195, 220, 255, 256, 300, 301, 4000, 50256]
+    for _ in range(400):
+        ids = [int(x) for x in rng.choice(pool, size=int(rng.integers(1, 6)))]
+        for kw in ({}, {"decode_with_timestamps": True}, {"skip_special_tokens": True},
+                   {"decode_with_timestamps": True, "skip_special_tokens": True}):
+            assert tok.decode(ids, **kw) == plain.decode(ids, **kw), (ids, kw)
+    memo = tok.__dict__["_tw_decode_memo"][1]
+    assert 0 < len(memo) and all(len(k[0]) <= 4 for k in memo)
+    n = len(memo)
+    assert tok.decode([300], decode_with_timestamps=True) is tok.decode([300], decode_with_timestamps=True)   # memo hit
+    assert len(memo) == n
+    # bypass: tensors / numpy ids / other options go to HF's decode and are not stored
+    assert tok.decode(np.array([300, 301])) == plain.decode(np.array([300, 301]))
+    assert tok.decode(torch.tensor([300, 301])) == plain.decode(torch.tensor([300, 301]))
+    assert tok.decode([300, 50365, 301, 50370], output_offsets=True) == plain.decode([300, 50365, 301, 50370], output_offsets=True)
+    assert len(memo) == n
+    tok.add_special_tokens({"additional_special_tokens": ["<|brandnew|>"]})
+    plain.add_special_tokens({"additional_special_tokens": ["<|brandnew|>"]})
+    new_id = tok.convert_tokens_to_ids("<|brandnew|>")
+    for kw in ({}, {"skip_special_tokens": True}):
+        assert tok.decode([300, new_id], **kw) == plain.decode([300, new_id], **kw)
+    assert tok.__dict__["_tw_decode_memo"][1] is not memo     # tables changed -> fresh memo
+
+
 def test_model_size_s_maps_to_fp8_only_by_deployment_switch(monkeypatch):
     """The reference's model_size="S" is its quantised engine flavour (R:thestage_speechkit/nvidia/asr_pipeline.py:47-56).  Here
     every size runs the bf16 kernels unless the deployment sets THEWHISPER_SIZE_S=fp8 (or the caller passes decoder_weights)."""

@@ -1,4 +1,4 @@
-"""Cache of ``tokenizer.all_special_ids`` for the lifetime of a pipeline.
+"""Host-side caches of tokenizer work for the lifetime of a pipeline: ``all_special_ids`` and short ``decode`` calls.
 
 HF's ``WhisperTokenizer._decode_with_timestamps`` evaluates the ``all_special_ids`` property - a ``convert_tokens_to_ids`` over
 every special token - once per decoded word when word timestamps are requested (``_split_tokens_on_unicode``,
@@ -6,12 +6,21 @@ HF:models/whisper/tokenization_whisper.py:279-286, :1315-1345).  Measured on the
 ten-second streams: 1756 evaluations = 111 ms of the 149 ms the whole post-processing takes (11 % of the call).  The value
 only depends on the tokenizer's special-token tables, which do not change while a pipeline lives; the cached subclass
 re-derives it whenever those tables change, so results are identical by construction.
+
+The same function decodes every token of a transcript on its own (``tokenizer.decode([id], decode_with_timestamps=True)``,
+one call per token and a second one per partial UTF-8 sequence): ~840 calls of ~25 us per stream and engine call, i.e. most of
+what is left of the post-processing.  Decoding a list of at most four ids with default options is a pure function of the ids,
+the two flags and the tokenizer's tables, so the cached subclass memoises exactly those calls (same key discipline: the memo
+is dropped when the special-token tables change; anything else - other argument types, other options - goes to HF's decode).
 """
 from __future__ import annotations
 
+_MEMO_MAX = 1 << 18
+
 
 def _key(tok):
-    return (len(tok._extra_special_tokens), tuple(str(v) for v in tok._special_tokens_map.values()))
+    # identity of the table entries: replacing a special token creates new objects -> new key -> the caches are rebuilt
+    return (len(tok._extra_special_tokens), tuple(map(id, tok._special_tokens_map.values())))
 
 
 def cache_special_ids(tokenizer):
@@ -22,6 +31,7 @@ def cache_special_ids(tokenizer):
     base_ids = cls.all_special_ids.fget if isinstance(getattr(cls, "all_special_ids", None), property) else None
     if base_ids is None:
         return tokenizer
+    base_decode = cls.decode
 
     def all_special_ids(self):
         k = _key(self)
@@ -31,7 +41,40 @@ def cache_special_ids(tokenizer):
             self.__dict__["_tw_special_ids"] = hit
         return hit[1]
 
-    cached = type(cls.__name__, (cls,), {"all_special_ids": property(all_special_ids), "_tw_special_id_cache": True})
+    def decode(self, token_ids, skip_special_tokens=False, clean_up_tokenization_spaces=None, output_offsets=False,
+               time_precision=0.02, decode_with_timestamps=False, normalize=False, basic_normalize=False,
+               remove_diacritics=False, **kwargs):
+        short = (type(token_ids) is list and 0 < len(token_ids) <= 4 and clean_up_tokenization_spaces is None
+                 and not output_offsets and time_precision == 0.02 and not normalize and not basic_normalize
+                 and not remove_diacritics and not kwargs and type(skip_special_tokens) is bool
+                 and type(decode_with_timestamps) is bool)
+        if short:
+            for t in token_ids:
+                if type(t) is not int:
+                    short = False
+                    break
+        if not short:
+            return base_decode(self, token_ids, skip_special_tokens=skip_special_tokens,
+                               clean_up_tokenization_spaces=clean_up_tokenization_spaces, output_offsets=output_offsets,
+                               time_precision=time_precision, decode_with_timestamps=decode_with_timestamps,
+                               normalize=normalize, basic_normalize=basic_normalize, remove_diacritics=remove_diacritics,
+                               **kwargs)
+        k = _key(self)
+        memo = self.__dict__.get("_tw_decode_memo")
+        if memo is None or memo[0] != k or len(memo[1]) > _MEMO_MAX:
+            memo = (k, {})
+            self.__dict__["_tw_decode_memo"] = memo
+        mk = (tuple(token_ids), skip_special_tokens, decode_with_timestamps)
+        text = memo[1].get(mk)
+        if text is None:
+            text = base_decode(self, list(token_ids), skip_special_tokens=skip_special_tokens,
+                               decode_with_timestamps=decode_with_timestamps)
+            if type(text) is str:
+                memo[1][mk] = text
+        return text
+
+    cached = type(cls.__name__, (cls,), {"all_special_ids": property(all_special_ids), "decode": decode,
+                                         "_tw_special_id_cache": True})
     try:
         tokenizer.__class__ = cached
     except TypeError:   # exotic tokenizer classes that cannot be re-classed keep HF's behaviour
