@@ -127,6 +127,46 @@ def test_decoder_teacher_forced(preset, T, B, dtype, layers, tol):
     eng.close()
 
 
+_PLAIN_SEQUENCE = r"""
+import sys, numpy as np, torch
+from oracle import whisper_oracle as wo
+from tests.util import PROMPT, clips, dims_variant, make_engine
+preset, T, B, dtype, layers, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]), sys.argv[6]
+dims = dims_variant(preset, enc_layers=1, dec_layers=layers)
+eng = make_engine(dims, wo.make_weights(dims, 2), T=T, max_batch=B, dtype=dtype)
+eng.encode(torch.from_numpy(wo.log_mel(clips(T * 320, B), dims.n_mels)).cuda())
+eng.cross_kv(B); eng.decoder_reset(B)
+ids = np.concatenate([np.tile(np.array(PROMPT), (B, 1)), np.random.default_rng(3).integers(0, 50000, size=(B, 3))], axis=1)
+np.save(out, np.stack([eng.decode_step(ids[:, s].tolist()).cpu().numpy() for s in range(ids.shape[1])]))
+"""
+
+
+@pytest.mark.parametrize("preset,T,B,dtype,layers,tol", [("micro", 100, 3, "f32", 2, 2e-5), ("tiny.en", 500, 20, "f32", 4, 5e-5),
+                                                         ("large-v3", 500, 16, "bf16", 2, 1.5e-2)])
+def test_cross_query_ahead_matches_the_plain_launch_sequence(preset, T, B, dtype, layers, tol, tmp_path):
+    """decode_core accumulates the cross-attention query ahead of its LayerNorm (x0 W'^T in the QKV launch, attn (W' Wo)^T in
+    the out-projection launch, LayerNorm applied inside the cross attention: DESIGN.md section 4).  TW_FUSE_CQ=0 runs the
+    plain 8-launch sequence on the same context layout; the logits of both agree to rounding (f32) / to the bf16 rounding of
+    W' Wo and of the un-normalised accumulator (bf16).  The plain sequence runs in a child process (the switch is read once)."""
+    import subprocess
+    import sys
+    out = str(tmp_path / "plain.npy")
+    env = dict(os.environ, TW_FUSE_CQ="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, "-c", _PLAIN_SEQUENCE, preset, str(T), str(B), dtype, str(layers), out], check=True, env=env, cwd=root)
+    plain = np.load(out)
+    dims = dims_variant(preset, enc_layers=1, dec_layers=layers)
+    eng = make_engine(dims, wo.make_weights(dims, 2), T=T, max_batch=B, dtype=dtype)
+    eng.encode(torch.from_numpy(wo.log_mel(clips(T * 320, B), dims.n_mels)).cuda())
+    eng.cross_kv(B)
+    eng.decoder_reset(B)
+    ids = np.concatenate([np.tile(np.array(PROMPT), (B, 1)), np.random.default_rng(3).integers(0, 50000, size=(B, 3))], axis=1)
+    for s in range(ids.shape[1]):
+        got = eng.decode_step(ids[:, s].tolist()).cpu().numpy()
+        assert rel_l2(got, plain[s]) < tol, (s, rel_l2(got, plain[s]))
+    eng.close()
+
+
 FP8_CASES = [("micro", 100, 3, 0), ("micro", 100, 3, 1), ("micro", 100, 16, 2), ("large-v3", 500, 2, 1), ("tiny.en", 1500, 1, 2)]
 
 
