@@ -307,9 +307,11 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=32, help="forced tokens per CPU-baseline call (BASELINE.md section 3: >= 3 calls x 32)")
     ap.add_argument("--cpu-calls", type=int, default=3)
-    ap.add_argument("--encoder-cus", type=int, default=64,
+    ap.add_argument("--encoder-cus", type=int, default=96,
                     help="overlap the encoder of batch k+1 (confined to this many CUs, second context) with the decode loop of "
-                         "batch k (thewhisper_amd/overlap.py); 0 = one context, strictly sequential stages")
+                         "batch k (thewhisper_amd/overlap.py); 0 = one context, strictly sequential stages.  96: the decode "
+                         "launches have 160 or 320 workgroups, which 256 - 96 = 160 CUs take in exactly one or two rounds "
+                         "(same box: 10 436 vs 10 340 tok/s with 64)")
     ap.add_argument("--latency-iters", type=int, default=100, help="single-stream chunk calls timed for the p50 (after 10 warm-ups; SURVEY.md section 8d)")
     ap.add_argument("--no-pipeline-leg", action="store_true", help="skip the measurement through ASRPipeline / BatchingHub")
     ap.add_argument("--hub-rounds", type=int, default=4)
