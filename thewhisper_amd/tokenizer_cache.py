@@ -19,8 +19,9 @@ _MEMO_MAX = 1 << 18
 
 
 def _key(tok):
-    # identity of the table entries: replacing a special token creates new objects -> new key -> the caches are rebuilt
-    return (len(tok._extra_special_tokens), tuple(map(id, tok._special_tokens_map.values())))
+    # the table entries themselves (compared by value; the tuple keeps them alive, so a replaced entry can never be mistaken
+    # for its predecessor): replacing or adding a special token -> new key -> the caches are rebuilt
+    return (len(tok._extra_special_tokens), tuple(tok._special_tokens_map.values()))
 
 
 def cache_special_ids(tokenizer):
