@@ -10,11 +10,16 @@ are consumed, so only small outputs are stored under tests/golden/full_*.npz):
   full_large-v3_c10    whisper-large-v3   32+32 layers, 10 s chunks (T = 500), 2 clips     (BASELINE configs 3/4)
   full_turbo_c30       large-v3-turbo     32+4  layers, 30 s chunk  (T = 1500), 1 clip     (BASELINE config 2)
   full_large-v3_c15    whisper-large-v3   32+32 layers, 15 s chunks (T = 750), 1 clip      (BASELINE config 5)
+  full_large-v3_c10_b16  whisper-large-v3 32+32 layers, 10 s chunks, **16 clips, 160 new tokens** (the batch and the length
+                       bench.py times: configs[3]'s per-GPU share; reaches the 128- / 192-key self-attention variants)
 
 Per case: log-mel rows (HF feature extractor), encoder-state samples, HF ``generate`` greedy ids with the timestamp
 grammar on (``max_new_tokens`` 32) + token timestamps (DTW), and - teacher-forced along that greedy path - per step the
 top-8 raw logits, a strided sample of the logits row, its norm, and the top1-top2 margin of the PROCESSED scores
 (the quantity the greedy decision is made on); the same logits summary for a teacher-forced pass over random tokens.
+``dtw_matrix`` = the [new tokens, T] alignment matrix HF hands (negated) to ``_dynamic_time_warping`` for every clip
+(z-scored, median-filtered, head-averaged cross-attention rows): the cost surface the DTW margin rule of
+tests/test_gpu_full_depth.py evaluates an engine path on.
 """
 from __future__ import annotations
 
@@ -36,7 +41,11 @@ CASES = {
     "full_large-v3_c10": ("large-v3", 10, [("speechlike", 21), ("noise", 22)], 0, 32),
     "full_turbo_c30": ("large-v3-turbo", 30, [("speechlike", 23)], 0, 32),
     "full_large-v3_c15": ("large-v3", 15, [("speechlike", 24)], 0, 32),
+    "full_large-v3_c10_b16": ("large-v3", 10, [(("speechlike", "noise", "sine", "speechlike")[i % 4], 100 + i) for i in range(16)], 0, 160),
 }
+# stride of the stored logits-row sample per case (rel-L2 estimate): the 16 x 163-row case keeps 1/8 of the others' density
+LOGIT_STRIDES = {"full_large-v3_c10_b16": 233}
+RAND_LEN = {"full_large-v3_c10_b16": 170}   # random text tokens of the second teacher-forced pass (default 13)
 WSCALE, QGAIN = 0.5, 8.0   # make_weights(scale, q_gain): see its docstring (unit-gain random models degenerate at 32 layers)
 LOGIT_STRIDE = 29   # strided sample of every logits row kept for the relative-L2 estimate
 ENC_TSTRIDE, ENC_DSTRIDE = 25, 16
@@ -47,6 +56,7 @@ def run_case(name: str):
     from transformers.generation.utils import GenerationMixin
 
     preset, chunk_s, clip_spec, wseed, max_new = CASES[name]
+    stride = LOGIT_STRIDES.get(name, LOGIT_STRIDE)
     dims = wo.PRESETS[preset]
     T = 50 * chunk_s
     t0 = time.time()
@@ -73,6 +83,16 @@ def run_case(name: str):
         calls.append(out)
         return out
 
+    import transformers.models.whisper.generation_whisper as gw
+
+    dtw_inputs = []
+    orig_dtw = gw._dynamic_time_warping
+
+    def dtw_spy(matrix):
+        dtw_inputs.append(np.array(matrix, dtype=np.float64))
+        return orig_dtw(matrix)
+
+    gw._dynamic_time_warping = dtw_spy
     GenerationMixin.generate = spy
     t0 = time.time()
     try:
@@ -81,11 +101,15 @@ def run_case(name: str):
                        do_sample=False, use_cache=True)
     finally:
         GenerationMixin.generate = orig
+        gw._dynamic_time_warping = orig_dtw
     print(f"[{name}] generate {time.time() - t0:.1f} s", flush=True)
     first = calls[0]   # the inner greedy call of the first seek iteration: prompt + new tokens, eos-padded
     seq = first["sequences"].numpy().astype(np.int64)
     tok_ts = first["token_timestamps"].numpy().astype(np.float32)
     assert (seq[:, :3] == np.array(PROMPT)).all()
+    # the first B DTW calls belong to that first greedy call (one per clip, in batch order): [N = L - 1 - prompt, T]
+    dtw_matrix = -np.stack(dtw_inputs[:B]).astype(np.float32)
+    assert dtw_matrix.shape == (B, seq.shape[1] - 1 - len(PROMPT), T), dtw_matrix.shape
 
     # teacher-forced along the greedy path (no cache: one pass)
     t0 = time.time()
@@ -107,7 +131,7 @@ def run_case(name: str):
 
     # a second teacher-forced pass over RANDOM text tokens (the greedy path of a random-weight model turns repetitive
     # after a dozen steps; random tokens keep every step informative)
-    rnd = np.random.default_rng(1234).integers(0, 50000, size=(B, 13))
+    rnd = np.random.default_rng(1234).integers(0, 50000, size=(B, RAND_LEN.get(name, 13)))
     ids2 = np.concatenate([np.tile(np.array(PROMPT + [50364]), (B, 1)), rnd], axis=1).astype(np.int64)
     logits2 = model(input_features=mel, decoder_input_ids=torch.from_numpy(ids2)).logits.numpy()
     top2 = torch.topk(torch.from_numpy(logits2), 8, dim=-1)
@@ -116,7 +140,7 @@ def run_case(name: str):
         os.path.join(OUT, f"{name}.npz"),
         rand_ids=ids2.astype(np.int32),
         rand_logits_top=top2.values.numpy().astype(np.float32), rand_logits_top_idx=top2.indices.numpy().astype(np.int32),
-        rand_logits_sample=logits2[:, :, ::LOGIT_STRIDE].astype(np.float32),
+        rand_logits_sample=logits2[:, :, ::stride].astype(np.float32),
         rand_logits_norm=np.linalg.norm(logits2, axis=-1).astype(np.float32),
         preset=preset, chunk_s=chunk_s, weight_seed=wseed, weight_scale=WSCALE, q_gain=QGAIN, max_new=max_new,
         clip_kinds=np.array([k for k, _ in clip_spec]), clip_seeds=np.array([s for _, s in clip_spec]),
@@ -126,7 +150,8 @@ def run_case(name: str):
         sequences=seq.astype(np.int32),
         token_timestamps=tok_ts,
         logits_top=top.values.numpy().astype(np.float32), logits_top_idx=top.indices.numpy().astype(np.int32),
-        logits_sample=logits[:, :, ::LOGIT_STRIDE].astype(np.float32),
+        logits_sample=logits[:, :, ::stride].astype(np.float32), logit_stride=stride,
+        dtw_matrix=dtw_matrix,
         logits_norm=np.linalg.norm(logits, axis=-1).astype(np.float32),
         margins=margins,
         alignment_heads=np.array(model.generation_config.alignment_heads, dtype=np.int32),

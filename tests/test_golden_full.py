@@ -9,7 +9,7 @@ from oracle import whisper_oracle as wo
 from tests.util import rel_l2
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-NAMES = ["full_large-v3_c10", "full_turbo_c30", "full_large-v3_c15"]
+NAMES = ["full_large-v3_c10", "full_turbo_c30", "full_large-v3_c15", "full_large-v3_c10_b16"]
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -20,7 +20,8 @@ def test_full_depth_golden_is_self_consistent(name):
     assert (seq[:, :3] == [50258, 50259, 50360]).all() and L == 3 + int(z["max_new"])
     assert z["logits_top"].shape == (B, L, 8) and z["rand_logits_top"].shape[:2] == z["rand_ids"].shape
     assert (np.diff(z["logits_top"], axis=-1) <= 0).all()
-    assert z["logits_sample"].shape[-1] == (dims.vocab + 28) // 29
+    stride = int(z["logit_stride"])
+    assert z["logits_sample"].shape[-1] == (dims.vocab + stride - 1) // stride
     # timestamp grammar: the first generated token is a timestamp <= max_initial_timestamp_index
     assert ((seq[:, 3] > 50364) & (seq[:, 3] <= 50365 + 50)).all()
     ts = z["token_timestamps"]
@@ -28,6 +29,26 @@ def test_full_depth_golden_is_self_consistent(name):
     assert ts.max() <= float(z["chunk_s"]) + 1e-6
     m = z["margins"][:, 2 : L - 1]
     assert np.isfinite(m).all() and (m >= 0).all()
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_stored_dtw_surface_reproduces_the_stored_timestamps(name):
+    """`dtw_matrix` (what HF handed, negated, to its DTW) pins the word-timestamp stage at depth: the oracle's DTW on it gives
+    exactly the stored token timestamps, and the margin helper of the GPU tests scores the reference's own jumps as optimal."""
+    from tests.util import dtw_jump_margins
+
+    z = np.load(os.path.join(GOLD, f"{name}.npz"))
+    M, ts = z["dtw_matrix"], z["token_timestamps"]
+    B, N, T = M.shape
+    assert N == ts.shape[1] - 4 and T == 50 * int(z["chunk_s"])
+    for b in range(min(B, 3)):
+        ti, tj = wo.dtw(-M[b].astype(np.float64))
+        jumps = np.pad(np.diff(ti), (1, 0), constant_values=1).astype(bool)
+        jt = (tj[jumps] * 0.02).astype(np.float32)
+        assert np.array_equal(jt, ts[b, 3:-1]) and ts[b, -1] == jt[-1]
+    for b in range(B):
+        mar, best = dtw_jump_margins(M[b], np.round(ts[b, 3:-1] / 0.02).astype(int))
+        assert np.abs(mar).max() < 1e-9 and best < 0
 
 
 def test_numpy_oracle_matches_full_depth_golden():

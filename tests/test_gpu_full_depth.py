@@ -4,17 +4,24 @@ by oracle/make_golden_full.py at the true model sizes with the oracle's seeded w
 
   full_large-v3_c10   large-v3 32+32 layers, T = 500   (configs 3/4)      bf16 + strict f32
   full_turbo_c30      turbo 32+4 layers,    T = 1500   (config 2)         bf16 (+ f32: two-pass 1500-key cross attention)
-  full_large-v3_c15   large-v3 32+32 layers, T = 750   (config 5)         bf16 + fp8-vs-bf16 statement
+  full_large-v3_c15   large-v3 32+32 layers, T = 750   (config 5)         bf16 + the fp8 context (ids, timestamps, logits)
+  full_large-v3_c10_b16  large-v3, T = 500, 16 clips x 160 new tokens (what bench.py times)   bf16 + strict f32
 
 Tolerances (stated once; measured values are printed by the tests and recorded in DESIGN.md section 2):
   log-mel            max-abs 2e-4 against the HF feature extractor rows
   strict f32         encoder rows rel-L2 <= 2e-4, teacher-forced logits rel-L2 <= 2e-4 per step and top-8 values within 2e-3,
                      greedy ids IDENTICAL wherever the golden margin exceeds 4 x 2e-3 (and the first step below that margin is
                      reported), token timestamps within one 0.02 s frame given identical ids
-  bf16               encoder rows rel-L2 <= 3e-2, logits rel-L2 <= 5e-2 per step; top-1 identical on every step whose golden
-                     raw top1-top2 margin exceeds 4 x the measured max top-8 abs error bound (0.25); greedy ids identical up to
-                     the first step whose golden decision margin is below that bound (that step is reported)
-The rel-L2 of a logits row is estimated on the stored stride-29 sample of the row (1789 of 51866 values).
+  bf16               encoder rows rel-L2 <= 3e-2, logits rel-L2 <= 3e-2 per step, top-8 logit values within 0.12; top-1 identical
+                     on every step whose golden raw top1-top2 margin exceeds 4 x 0.12; greedy ids identical up to the first step
+                     whose golden decision margin is below that bound (that step is reported)
+  fp8 (config 5)     logits rel-L2 <= 0.13 (1.5 x the measured 0.087), top-8 within FP8["top_abs"], same margin rules
+  token timestamps   (every dtype, given identical ids) identical +-0.02 s wherever the DTW margin exceeds EPS_DTW: a token may
+                     sit elsewhere ONLY if, on the REFERENCE's own cost surface (`dtw_matrix` of the golden file), the best path
+                     with the token's jump at the engine's frame costs within EPS_DTW of the optimal path (tests/util.py:
+                     dtw_jump_margins) - i.e. the reference's arg-min was a tie at the surface's own resolution
+The rel-L2 of a logits row is estimated on the stored strided sample of the row (stride 29: 1789 of 51866 values; 233 for
+the 16-clip case).
 """
 import os
 
@@ -23,12 +30,15 @@ import pytest
 import torch
 
 from oracle import whisper_oracle as wo
-from tests.util import make_engine, rel_l2
+from tests.util import alignment_matrix, dtw_jump_margins, make_engine, rel_l2
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 PROMPT = [50258, 50259, 50360]
 STRIDE = 29
+# DTW margin (cost units of the z-scored alignment matrix, whose cells are O(1) and whose optimal paths cost ~ -250): see above
+EPS_DTW = 0.05
+DUMP = os.environ.get("TW_DUMP_DIR")   # diagnostics: engine ids / timestamps / alignment rows of every case as .npz
 
 _weights_cache = {}
 
@@ -53,12 +63,42 @@ def load_case(name):
     return z, dims, _weights_cache[key], pcm, heads
 
 
+def check_timestamps(z, ts, streams, dtype, dump=None):
+    """Token timestamps of `streams` (engine ids == golden ids there) against the golden ones: identical +-one frame, except
+    where the reference's own DTW was a tie (margin rule, module docstring).  Returns the measured statistics."""
+    gts = z["token_timestamps"]
+    dev = np.abs(ts[streams] - gts[streams])
+    rep = {"token_ts_maxdev_s": float(dev.max()), "token_ts_exact_frac": float((dev < 1e-6).mean()),
+           "token_ts_within_1_frame_frac": float((dev <= 0.0201).mean())}
+    worst_margin, n_moved, margins_moved = 0.0, 0, []
+    for b in streams:
+        moved = np.nonzero(np.abs(ts[b, 3:-1] - gts[b, 3:-1]) > 0.0201)[0]
+        if len(moved) == 0:
+            continue
+        jf = np.round(ts[b, 3:-1] / 0.02).astype(int)
+        mar, _ = dtw_jump_margins(z["dtw_matrix"][b], jf)
+        n_moved += len(moved)
+        margins_moved.extend(float(x) for x in mar[moved])
+        worst_margin = max(worst_margin, float(mar[moved].max()))
+    rep["tokens_moved_gt_1_frame"] = n_moved
+    rep["worst_dtw_margin_of_a_moved_token"] = worst_margin
+    if dump is not None:
+        dump["moved_margins"] = np.array(margins_moved)
+    if dtype == "f32":
+        assert dev.max() <= 0.0201, rep
+    assert worst_margin <= EPS_DTW, rep
+    # the last entry duplicates the last jump (HF :377-379)
+    return rep
+
+
 def run_case(name, dtype, logit_tol, enc_tol, top_abs, check_ids=True):
     """Shared body: returns a dict of measured deviations (printed, asserted against the stated bounds)."""
     z, dims, w, pcm, heads = load_case(name)
     T, B = 50 * int(z["chunk_s"]), pcm.shape[0]
+    stride = int(z["logit_stride"]) if "logit_stride" in z.files else STRIDE
     eng = make_engine(dims, w, T=T, max_batch=B, dtype=dtype, heads=heads, use_graph=True)
     rep = {}
+    dump = {}
     try:
         # A1
         mel = eng.logmel(torch.from_numpy(pcm).cuda(), out_dtype=torch.float32)
@@ -78,7 +118,7 @@ def run_case(name, dtype, logit_tol, enc_tol, top_abs, check_ids=True):
             worst_rel, worst_top, flips = 0.0, 0.0, []
             for s in range(ids.shape[1]):
                 lg = eng.decode_step(ids[:, s].tolist()).cpu().numpy()
-                worst_rel = max(worst_rel, rel_l2(lg[:, ::STRIDE], sample[:, s]))
+                worst_rel = max(worst_rel, rel_l2(lg[:, ::stride], sample[:, s]))
                 for b in range(B):
                     worst_top = max(worst_top, float(np.abs(lg[b, top_idx[b, s]] - tops[b, s]).max()))
                     margin = tops[b, s, 0] - tops[b, s, 1]
@@ -91,6 +131,15 @@ def run_case(name, dtype, logit_tol, enc_tol, top_abs, check_ids=True):
         seq = z["sequences"].astype(np.int64)
         rep["greedy_path_logits_rel_l2"], rep["greedy_path_top8_maxabs"], rep["greedy_path_subm_flips"] = teacher(
             seq[:, :-1], z["logits_top"], z["logits_top_idx"], z["logits_sample"])
+        # A11 given IDENTICAL ids by construction: the teacher-forced pass left the alignment heads' softmax rows of the
+        # reference's own greedy path in the context, for every stream (whether or not the free-running loop below stays on it)
+        Lg = seq.shape[1]
+        ts_tf = eng.token_timestamps(B, 3, Lg, [2 * T] * B)
+        rep.update(check_timestamps(z, ts_tf, list(range(B)), dtype, dump if DUMP else None))
+        if DUMP:
+            al = eng.get_alignment(B, Lg - 1)
+            dump.update(ts_teacher_forced=ts_tf, matrix_teacher_forced=np.stack([alignment_matrix(al[b], 3) for b in range(B)]))
+            del al
         rep["rand_path_logits_rel_l2"], rep["rand_path_top8_maxabs"], rep["rand_path_subm_flips"] = teacher(
             z["rand_ids"].astype(np.int64), z["rand_logits_top"], z["rand_logits_top_idx"], z["rand_logits_sample"])
         assert rep["greedy_path_logits_rel_l2"] < logit_tol and rep["rand_path_logits_rel_l2"] < logit_tol, rep
@@ -117,64 +166,38 @@ def run_case(name, dtype, logit_tol, enc_tol, top_abs, check_ids=True):
             rep["first_divergence(pos, golden_margin)"] = first_div
             rep["min_golden_margin"] = float(margins[:, 2 : seq.shape[1] - 1].min())
             same = [b for b in range(B) if first_div[b] is None and got.shape[1] == seq.shape[1]]
+            rep["streams_with_identical_ids"] = len(same)
+            ts = eng.token_timestamps(B, 3, got.shape[1], [2 * T] * B)
+            if DUMP:
+                dump.update(ids=got, ts=ts)
             if same:
-                ts = eng.token_timestamps(B, 3, got.shape[1], [2 * T] * B)
-                dev = float(np.abs(ts[same] - z["token_timestamps"][same]).max())
-                rep["token_ts_maxdev_s"] = dev
-                rep["token_ts_exact_frac"] = float((np.abs(ts[same] - z["token_timestamps"][same]) < 1e-6).mean())
-                rep["token_ts_within_1_frame_frac"] = float((np.abs(ts[same] - z["token_timestamps"][same]) <= 0.0201).mean())
-                if dtype == "f32":
-                    assert dev <= 0.0201, rep
-                else:
-                    # bf16 attention weights on the repetitive tail of a random-weight model's greedy path make the DTW
-                    # path ill-conditioned (near-tied costs): most tokens stay within one frame, a few jump - reported
-                    assert rep["token_ts_within_1_frame_frac"] >= 0.75, rep
+                # same ids, same arithmetic (captured step graph or not): the free-running loop's timestamps ARE the teacher-forced ones
+                assert np.array_equal(ts[same], ts_tf[same]), (name, dtype, "free-running vs teacher-forced token timestamps")
     finally:
         eng.close()
+        if DUMP and dump:
+            os.makedirs(DUMP, exist_ok=True)
+            np.savez_compressed(os.path.join(DUMP, f"{name}_{dtype}.npz"), **dump)
     print(f"\nFULLDEPTH {name} {dtype}: " + ", ".join(f"{k}={v}" for k, v in rep.items()))
     return rep
 
 
 # bounds: (logits rel-L2, encoder rel-L2, top-8 abs)
 F32 = dict(logit_tol=2e-4, enc_tol=2e-4, top_abs=2e-3)
-BF16 = dict(logit_tol=5e-2, enc_tol=3e-2, top_abs=0.25)
+BF16 = dict(logit_tol=3e-2, enc_tol=3e-2, top_abs=0.12)
+# MXFP8 decoder weights + e4m3 cross-K/V (BASELINE config 5): the encoder is bf16, so its bound is bf16's
+FP8 = dict(logit_tol=0.13, enc_tol=3e-2, top_abs=0.6)
 
 
 # ordered so that consecutive cases share the (6 GB, ~20 s to generate) seeded state dict
 CASES = [("full_turbo_c30", "bf16"), ("full_turbo_c30", "f32"), ("full_large-v3_c10", "bf16"), ("full_large-v3_c10", "f32"),
-         ("full_large-v3_c15", "bf16")]
+         ("full_large-v3_c10_b16", "bf16"), ("full_large-v3_c10_b16", "f32"), ("full_large-v3_c15", "bf16"),
+         ("full_large-v3_c15", "fp8")]
 
 
 @pytest.mark.parametrize("name,dtype", CASES)
 def test_full_depth(name, dtype):
-    rep = run_case(name, dtype, **(F32 if dtype == "f32" else BF16))
+    rep = run_case(name, dtype, **{"f32": F32, "bf16": BF16, "fp8": FP8}[dtype])
     if dtype == "f32" and rep["min_golden_margin"] > 4 * F32["top_abs"]:
         # strict mode: every decision margin on these clips is above the bound, so the ids must be identical outright
         assert all(d is None for d in rep["first_divergence(pos, golden_margin)"]), rep
-
-
-def test_full_depth_fp8_vs_bf16_statement():
-    """BASELINE config 5 (large-v3, 15 s chunks, MXFP8 decoder weights + fp8 cross-K/V caches): full-depth logit error of the fp8
-    context against the fp32 reference, beside bf16's (no reference exists for fp8 results; this states the quantisation error
-    at depth: measured 8.5e-2 vs 1.5e-2 for bf16).
-    Bounds: rel-L2 <= 0.25 and top-1 identical wherever the golden margin exceeds 1.5."""
-    name = "full_large-v3_c15"
-    z, dims, w, pcm, heads = load_case(name)
-    T, B = 50 * int(z["chunk_s"]), pcm.shape[0]
-    eng = make_engine(dims, w, T=T, max_batch=B, dtype="fp8", heads=heads)
-    try:
-        eng.encode(eng.logmel(torch.from_numpy(pcm).cuda()))
-        eng.cross_kv(B)
-        eng.decoder_reset(B)
-        ids = z["rand_ids"].astype(np.int64)
-        worst = 0.0
-        for s in range(ids.shape[1]):
-            lg = eng.decode_step(ids[:, s].tolist()).cpu().numpy()
-            worst = max(worst, rel_l2(lg[:, ::STRIDE], z["rand_logits_sample"][:, s]))
-            for b in range(B):
-                if z["rand_logits_top"][b, s, 0] - z["rand_logits_top"][b, s, 1] > 1.5:
-                    assert int(lg[b].argmax()) == int(z["rand_logits_top_idx"][b, s, 0])
-        print(f"\nFULLDEPTH {name} fp8: rand_path_logits_rel_l2={worst}")
-        assert worst < 0.25
-    finally:
-        eng.close()
