@@ -16,10 +16,10 @@ Tolerances (stated once; measured values are printed by the tests and recorded i
                      on every step whose golden raw top1-top2 margin exceeds 4 x 0.12; greedy ids identical up to the first step
                      whose golden decision margin is below that bound (that step is reported)
   fp8 (config 5)     logits rel-L2 <= 0.13 (1.5 x the measured 0.087), top-8 within FP8["top_abs"], same margin rules
-  token timestamps   (every dtype, given identical ids) identical +-0.02 s wherever the DTW margin exceeds EPS_DTW: a token may
-                     sit elsewhere ONLY if, on the REFERENCE's own cost surface (`dtw_matrix` of the golden file), the best path
-                     with the token's jump at the engine's frame costs within EPS_DTW of the optimal path (tests/util.py:
-                     dtw_jump_margins) - i.e. the reference's arg-min was a tie at the surface's own resolution
+  token timestamps   given identical ids (teacher-forced along the reference's greedy path, all streams): see check_timestamps -
+                     exact stage parity on the engine's own alignment rows, a bound on the alignment surface, and strict f32
+                     within one 0.02 s frame; in reduced precision a token may move only within what that surface error can
+                     overturn on the reference's own cost surface (`dtw_matrix` of the golden file)
 The rel-L2 of a logits row is estimated on the stored strided sample of the row (stride 29: 1789 of 51866 values; 233 for
 the 16-clip case).
 """
@@ -36,8 +36,6 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 PROMPT = [50258, 50259, 50360]
 STRIDE = 29
-# DTW margin (cost units of the z-scored alignment matrix, whose cells are O(1) and whose optimal paths cost ~ -250): see above
-EPS_DTW = 0.05
 DUMP = os.environ.get("TW_DUMP_DIR")   # diagnostics: engine ids / timestamps / alignment rows of every case as .npz
 
 _weights_cache = {}
@@ -63,35 +61,66 @@ def load_case(name):
     return z, dims, _weights_cache[key], pcm, heads
 
 
-def check_timestamps(z, ts, streams, dtype, dump=None):
-    """Token timestamps of `streams` (engine ids == golden ids there) against the golden ones: identical +-one frame, except
-    where the reference's own DTW was a tie (margin rule, module docstring).  Returns the measured statistics."""
-    gts = z["token_timestamps"]
+def check_timestamps(z, eng, ts, streams, dtype, n_rows, bounds, dump=None):
+    """Word-timestamp stage (A11) of `streams` (engine ids == golden ids there) against the reference, in three statements:
+      1. STAGE PARITY, exact: the engine's timestamps are the reference algorithm (z-score, median filter, head mean, DTW with
+         its tie-breaks: oracle restatement pinned to HF on CPU) applied to the engine's OWN alignment rows - bit for bit;
+      2. SURFACE: the engine's alignment matrix is within `bounds` of the reference's `dtw_matrix` (rel-L2 and max-abs);
+      3. CONSEQUENCE: strict f32 - every timestamp within one 0.02 s frame; reduced precision - a token may sit elsewhere only
+         where the reference's arg-min is within reach of that surface error: the engine path's excess cost on the REFERENCE
+         surface is (a) at most the sum of |surface error| over the cells where the two paths differ (what optimality on the
+         engine's surface implies) and (b) at most `bounds["excess_frac"]` of the optimal cost; per moved token the margin
+         (dtw_jump_margins) is reported.  On these random-weight fixtures the reference's own per-token margins are 0.1-0.3
+         cost units at an optimal cost of ~ -250 (tests/test_golden_full.py), i.e. the surface is flat almost everywhere."""
+    gts, Mg = z["token_timestamps"], z["dtw_matrix"]
+    al = eng.get_alignment(len(gts), n_rows)
     dev = np.abs(ts[streams] - gts[streams])
     rep = {"token_ts_maxdev_s": float(dev.max()), "token_ts_exact_frac": float((dev < 1e-6).mean()),
            "token_ts_within_1_frame_frac": float((dev <= 0.0201).mean())}
-    worst_margin, n_moved, margins_moved = 0.0, 0, []
+    worst_margin, n_moved, worst_excess_frac, surf_rel, surf_abs, problems = 0.0, 0, 0.0, 0.0, 0.0, []
+    mats = []
     for b in streams:
+        Me = alignment_matrix(al[b], 3)
+        mats.append(Me)
+        surf_rel = max(surf_rel, rel_l2(Me, Mg[b]))
+        surf_abs = max(surf_abs, float(np.abs(Me - Mg[b]).max()))
+        # 1. the engine's timestamps = the reference algorithm on the engine's rows
+        ti, tj = wo.dtw(-Me.astype(np.float64))
+        jumps = np.pad(np.diff(ti), (1, 0), constant_values=1).astype(bool)
+        jt = (tj[jumps] * 0.02).astype(np.float32)
+        if not (np.array_equal(jt, ts[b, 3:-1]) and ts[b, -1] == jt[-1] and (ts[b, :3] == 0).all()):
+            problems.append(f"stream {b}: engine timestamps are not the DTW of the engine's own alignment rows")
+        # 3. the engine path on the reference surface
+        Cg = -Mg[b].astype(np.float64)
+        gi, gj = wo.dtw(Cg)
+        on_e = np.zeros(Cg.shape, bool); on_e[ti, tj] = True
+        on_g = np.zeros(Cg.shape, bool); on_g[gi, gj] = True
+        excess = float(Cg[on_e].sum() - Cg[on_g].sum())
+        budget = float(np.abs(Me.astype(np.float64) - Mg[b])[on_e ^ on_g].sum())
+        if excess > budget + 1e-3:
+            problems.append(f"stream {b}: excess cost {excess:.4f} on the reference surface exceeds the error budget {budget:.4f}")
+        worst_excess_frac = max(worst_excess_frac, excess / abs(float(Cg[on_g].sum())))
         moved = np.nonzero(np.abs(ts[b, 3:-1] - gts[b, 3:-1]) > 0.0201)[0]
-        if len(moved) == 0:
-            continue
-        jf = np.round(ts[b, 3:-1] / 0.02).astype(int)
-        mar, _ = dtw_jump_margins(z["dtw_matrix"][b], jf)
-        n_moved += len(moved)
-        margins_moved.extend(float(x) for x in mar[moved])
-        worst_margin = max(worst_margin, float(mar[moved].max()))
-    rep["tokens_moved_gt_1_frame"] = n_moved
-    rep["worst_dtw_margin_of_a_moved_token"] = worst_margin
+        if len(moved):
+            mar, _ = dtw_jump_margins(Mg[b], np.round(ts[b, 3:-1] / 0.02).astype(int))
+            n_moved += len(moved)
+            worst_margin = max(worst_margin, float(mar[moved].max()))
+    rep.update(tokens_moved_gt_1_frame=n_moved, worst_dtw_margin_of_a_moved_token=worst_margin,
+               worst_path_excess_frac=worst_excess_frac, surface_rel_l2=surf_rel, surface_maxabs=surf_abs)
     if dump is not None:
-        dump["moved_margins"] = np.array(margins_moved)
-    if dtype == "f32":
-        assert dev.max() <= 0.0201, rep
-    assert worst_margin <= EPS_DTW, rep
-    # the last entry duplicates the last jump (HF :377-379)
-    return rep
+        dump["matrix"] = np.stack(mats)
+    if dtype == "f32" and dev.max() > 0.0201:
+        problems.append(f"strict f32: token timestamps deviate by {dev.max():.3f} s")
+    if surf_rel > bounds["surface_rel"]:
+        problems.append(f"alignment surface rel-L2 {surf_rel:.4f} > {bounds['surface_rel']}")
+    if worst_excess_frac > bounds["excess_frac"]:
+        problems.append(f"engine path costs {worst_excess_frac:.5f} of the optimum more on the reference surface (> {bounds['excess_frac']})")
+    if rep["token_ts_within_1_frame_frac"] < bounds["within_1_frame"]:
+        problems.append(f"only {rep['token_ts_within_1_frame_frac']:.3f} of the token timestamps within one frame (< {bounds['within_1_frame']})")
+    return rep, problems
 
 
-def run_case(name, dtype, logit_tol, enc_tol, top_abs, check_ids=True):
+def run_case(name, dtype, logit_tol, enc_tol, top_abs, ts_bounds, check_ids=True):
     """Shared body: returns a dict of measured deviations (printed, asserted against the stated bounds)."""
     z, dims, w, pcm, heads = load_case(name)
     T, B = 50 * int(z["chunk_s"]), pcm.shape[0]
@@ -113,6 +142,8 @@ def run_case(name, dtype, logit_tol, enc_tol, top_abs, check_ids=True):
         eng.cross_kv(B)
 
         # A5-A8 teacher-forced along the reference's greedy path and over random tokens
+        top1_bad = []   # (stream, step, golden margin) of a wrong arg-max above the margin bound
+
         def teacher(ids, tops, top_idx, sample):
             eng.decoder_reset(B)
             worst_rel, worst_top, flips = 0.0, 0.0, []
@@ -123,7 +154,8 @@ def run_case(name, dtype, logit_tol, enc_tol, top_abs, check_ids=True):
                     worst_top = max(worst_top, float(np.abs(lg[b, top_idx[b, s]] - tops[b, s]).max()))
                     margin = tops[b, s, 0] - tops[b, s, 1]
                     if margin > 4 * top_abs:
-                        assert int(lg[b].argmax()) == int(top_idx[b, s, 0]), (name, dtype, b, s, margin)
+                        if int(lg[b].argmax()) != int(top_idx[b, s, 0]):
+                            top1_bad.append((b, s, float(margin)))
                     elif int(lg[b].argmax()) != int(top_idx[b, s, 0]):
                         flips.append((b, s, float(margin)))
             return worst_rel, worst_top, flips
@@ -135,15 +167,18 @@ def run_case(name, dtype, logit_tol, enc_tol, top_abs, check_ids=True):
         # reference's own greedy path in the context, for every stream (whether or not the free-running loop below stays on it)
         Lg = seq.shape[1]
         ts_tf = eng.token_timestamps(B, 3, Lg, [2 * T] * B)
-        rep.update(check_timestamps(z, ts_tf, list(range(B)), dtype, dump if DUMP else None))
         if DUMP:
-            al = eng.get_alignment(B, Lg - 1)
-            dump.update(ts_teacher_forced=ts_tf, matrix_teacher_forced=np.stack([alignment_matrix(al[b], 3) for b in range(B)]))
-            del al
+            dump.update(ts_teacher_forced=ts_tf)
+        ts_rep, problems = check_timestamps(z, eng, ts_tf, list(range(B)), dtype, Lg - 1, ts_bounds, dump if DUMP else None)
+        rep.update(ts_rep)
         rep["rand_path_logits_rel_l2"], rep["rand_path_top8_maxabs"], rep["rand_path_subm_flips"] = teacher(
             z["rand_ids"].astype(np.int64), z["rand_logits_top"], z["rand_logits_top_idx"], z["rand_logits_sample"])
-        assert rep["greedy_path_logits_rel_l2"] < logit_tol and rep["rand_path_logits_rel_l2"] < logit_tol, rep
-        assert rep["greedy_path_top8_maxabs"] < top_abs and rep["rand_path_top8_maxabs"] < top_abs, rep
+        if top1_bad:
+            problems.append(f"top-1 differs above the margin bound at (stream, step, margin) {top1_bad[:8]}")
+        if not (rep["greedy_path_logits_rel_l2"] < logit_tol and rep["rand_path_logits_rel_l2"] < logit_tol):
+            problems.append(f"logits rel-L2 above {logit_tol}")
+        if not (rep["greedy_path_top8_maxabs"] < top_abs and rep["rand_path_top8_maxabs"] < top_abs):
+            problems.append(f"top-8 logit values off by more than {top_abs}")
 
         # A9-A11 free-running greedy with the timestamp grammar + token timestamps
         if check_ids:
@@ -162,7 +197,8 @@ def run_case(name, dtype, logit_tol, enc_tol, top_abs, check_ids=True):
                 m = float(margins[b, p - 1])
                 first_div.append((p, m))
                 # identical up to the first sub-margin decision: a divergence is only legitimate there
-                assert m <= 4 * top_abs, f"{name}/{dtype}: stream {b} diverges at position {p} where the golden margin is {m}"
+                if m > 4 * top_abs:
+                    problems.append(f"stream {b} diverges at position {p} where the golden margin is {m}")
             rep["first_divergence(pos, golden_margin)"] = first_div
             rep["min_golden_margin"] = float(margins[:, 2 : seq.shape[1] - 1].min())
             same = [b for b in range(B) if first_div[b] is None and got.shape[1] == seq.shape[1]]
@@ -172,21 +208,29 @@ def run_case(name, dtype, logit_tol, enc_tol, top_abs, check_ids=True):
                 dump.update(ids=got, ts=ts)
             if same:
                 # same ids, same arithmetic (captured step graph or not): the free-running loop's timestamps ARE the teacher-forced ones
-                assert np.array_equal(ts[same], ts_tf[same]), (name, dtype, "free-running vs teacher-forced token timestamps")
+                if not np.array_equal(ts[same], ts_tf[same]):
+                    problems.append("free-running and teacher-forced token timestamps differ on identical ids")
     finally:
         eng.close()
         if DUMP and dump:
             os.makedirs(DUMP, exist_ok=True)
             np.savez_compressed(os.path.join(DUMP, f"{name}_{dtype}.npz"), **dump)
     print(f"\nFULLDEPTH {name} {dtype}: " + ", ".join(f"{k}={v}" for k, v in rep.items()))
+    assert not problems, (name, dtype, problems, rep)
     return rep
 
 
 # bounds: (logits rel-L2, encoder rel-L2, top-8 abs)
-F32 = dict(logit_tol=2e-4, enc_tol=2e-4, top_abs=2e-3)
-BF16 = dict(logit_tol=3e-2, enc_tol=3e-2, top_abs=0.12)
+# ts_bounds: alignment-surface rel-L2, engine-path excess cost on the reference surface (fraction of the optimum), floor of the
+# fraction of token timestamps within one frame (a regression alarm, not the parity statement - see check_timestamps)
+# Measured on the MI355X (profiles/r03_gpu_tests_full_depth.log), bounds = ~1.5 x the worst case:
+#   bf16: logits rel-L2 0.0095-0.0161, top-8 0.035-0.073, alignment surface rel-L2 0.032 (turbo) - 0.123 (32 decoder layers,
+#         16 clips), engine-path excess 1e-4 - 7.2e-3 of the optimum, 77 % (16 clips x 159 tokens) - 94 % within one frame
+#   fp8 : logits 0.087, top-8 0.29, surface 0.34, excess 0.050, 57 % within one frame (e4m3 cross keys feed the alignment rows)
+F32 = dict(logit_tol=2e-4, enc_tol=2e-4, top_abs=2e-3, ts_bounds=dict(surface_rel=1e-4, excess_frac=1e-6, within_1_frame=1.0))
+BF16 = dict(logit_tol=3e-2, enc_tol=3e-2, top_abs=0.12, ts_bounds=dict(surface_rel=0.18, excess_frac=0.011, within_1_frame=0.70))
 # MXFP8 decoder weights + e4m3 cross-K/V (BASELINE config 5): the encoder is bf16, so its bound is bf16's
-FP8 = dict(logit_tol=0.13, enc_tol=3e-2, top_abs=0.6)
+FP8 = dict(logit_tol=0.13, enc_tol=3e-2, top_abs=0.45, ts_bounds=dict(surface_rel=0.5, excess_frac=0.075, within_1_frame=0.45))
 
 
 # ordered so that consecutive cases share the (6 GB, ~20 s to generate) seeded state dict

@@ -1,0 +1,140 @@
+"""thewhisper_amd/shortform.py (the restated short-form seek loop) against HF's own ``WhisperGenerationMixin.generate``.
+
+Both run on the SAME engine (the numpy oracle behind the engine interface, tests/oracle_engine.py), so every difference
+would be a difference in control flow: segment cut-out, padding removal, segment slicing at the timestamp tokens, seek
+advance, time offsets of the token timestamps, padding of the batch.  Compared: the raw ``generate`` return values
+(ids, token timestamps, every field of every segment) and the finished pipeline dictionaries, for all three
+``return_timestamps`` modes, ragged buffers (several seek passes per chunk) and batches that shrink.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import hf_reference as hr
+from oracle import whisper_oracle as wo
+from tests.oracle_engine import oracle_engine_factory
+
+torch.set_grad_enabled(False)
+GK = {"num_beams": 1, "do_sample": False, "use_cache": True, "language": "en", "max_new_tokens": 24}
+
+
+def build(preset="micro", chunk_s=10, batch_size=4, seed=0):
+    from thewhisper_amd import ASRPipeline
+
+    dims = wo.PRESETS[preset]
+    model = hr.build_hf_model(dims, wo.make_weights(dims, seed))
+    return ASRPipeline(model, feature_extractor=hr.build_feature_extractor(dims, chunk_s), tokenizer=hr.build_tokenizer(dims),
+                       chunk_length_s=chunk_s, device="cpu", torch_dtype=torch.float32, batch_size=batch_size,
+                       engine_factory=oracle_engine_factory)
+
+
+def same(a, b, path=""):
+    """Deep equality of generate() results: tensors by dtype + shape + value, containers recursively."""
+    if isinstance(a, torch.Tensor) or isinstance(b, torch.Tensor):
+        assert isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor), path
+        assert a.dtype == b.dtype and a.shape == b.shape, (path, a.dtype, b.dtype, a.shape, b.shape)
+        assert torch.equal(a, b), path
+    elif isinstance(a, dict):
+        assert isinstance(b, dict) and sorted(a.keys()) == sorted(b.keys()), (path, a.keys(), b.keys())
+        for k in a:
+            same(a[k], b[k], f"{path}.{k}")
+    elif isinstance(a, (list, tuple)):
+        assert isinstance(b, (list, tuple)) and len(a) == len(b), (path, len(a), len(b))
+        for i, (x, y) in enumerate(zip(a, b)):
+            same(x, y, f"{path}[{i}]")
+    else:
+        assert a == b, (path, a, b)
+
+
+def clip_features(pipe, n_clips, chunk_s, seed0=0):
+    fe = pipe.feature_extractor
+    kinds = ["speechlike", "noise", "sine", "speechlike", "zeros"]
+    lens = [chunk_s * 16000, 7 * 1600 * chunk_s, 16000 * chunk_s // 3, chunk_s * 16000 - 4321, chunk_s * 8000]
+    pcm = [wo.synth_audio(lens[i % len(lens)], seed0 + i, kinds[i % len(kinds)]) for i in range(n_clips)]
+    return fe(pcm, sampling_rate=16000, return_tensors="pt", return_attention_mask=True)
+
+
+@pytest.mark.parametrize("mode", ["word", "segments", "none"])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_generate_equals_hf_control_flow(mode, seed):
+    pipe = build(seed=seed)
+    model = pipe.model
+    feats = clip_features(pipe, 4, 10, seed0=10 * seed)
+    kw = dict(GK)
+    if mode == "word":
+        kw.update(return_timestamps=True, return_token_timestamps=True, return_segments=True)
+    elif mode == "segments":
+        kw.update(return_timestamps=True)
+    else:
+        kw.update(return_timestamps=False)
+    call = lambda: model.generate(input_features=feats.input_features, attention_mask=feats.attention_mask,  # noqa: E731
+                                  generation_config=pipe.generation_config, **kw)
+    model.fast_generate = False
+    ref = call()                       # HF's WhisperGenerationMixin.generate, every time
+    passes_ref = model.engine.calls["generate"]
+    model.fast_generate = True
+    first = call()                     # learns the plan (still HF's flow)
+    assert model.last_plan is not None, "the call should have been eligible for the short-form plan"
+    n0 = model.engine.calls["generate"]
+    fast = call()                      # the restated loop
+    assert model.engine.calls["generate"] - n0 == passes_ref, "same number of engine passes as HF's loop"
+    same(ref, first, "learn")
+    same(ref, fast, "fast")
+    if mode != "none":
+        assert passes_ref > 1, "fixture should need several seek passes (otherwise the loop is not exercised)"
+
+
+def test_pipeline_outputs_identical_with_and_without_the_fast_path():
+    pipe = build(batch_size=3)
+    audios = [wo.synth_audio(n, s, k) for n, s, k in [(160000, 5, "speechlike"), (250000, 6, "noise"), (52000, 7, "sine"),
+                                                       (400000, 8, "speechlike")]]
+    for rt in (False, True, "word"):
+        outs = {}
+        for fast in (False, True, True):
+            pipe.model.fast_generate = fast
+            outs.setdefault(fast, []).append(pipe([a.copy() for a in audios], generate_kwargs=dict(GK), chunk_length_s=9,
+                                                  return_timestamps=rt, batch_size=3))
+        assert outs[False][0] == outs[True][0] == outs[True][1], rt
+
+
+def test_ineligible_calls_keep_hf_flow():
+    pipe = build()
+    model = pipe.model
+    feats = clip_features(pipe, 2, 10)
+    base = dict(input_features=feats.input_features, attention_mask=feats.attention_mask, generation_config=pipe.generation_config)
+    for extra in (dict(prompt_ids=torch.tensor([50362, 300, 301])), dict(temperature=(0.0, 0.2), logprob_threshold=-1.0),
+                  dict(condition_on_prev_tokens=True)):
+        kw = {**GK, "return_timestamps": True, **extra}
+        assert model._plan_key({**base, **kw}) is None, extra
+    assert model._plan_key({**base, **GK, "return_timestamps": True}) is not None
+    # language detection (no language given on a multilingual model) is per-row: not eligible
+    kw = {k: v for k, v in GK.items() if k != "language"}
+    assert model._plan_key({**base, **kw, "return_timestamps": True}) is None
+
+
+def test_run_pass_accepts_chunks_from_different_calls():
+    """The property the serving hub relies on: chunks at different seek positions (and from different buffers) share one pass,
+    and each ends with exactly what it gets when decoded alone."""
+    from thewhisper_amd import shortform
+
+    pipe = build(batch_size=4)
+    model = pipe.model
+    feats = clip_features(pipe, 4, 10, seed0=40)
+    kw = dict(GK, return_timestamps=True, return_token_timestamps=True, return_segments=True)
+    call = lambda f, m: model.generate(input_features=f, attention_mask=m, generation_config=pipe.generation_config, **kw)  # noqa: E731
+    call(feats.input_features, feats.attention_mask)                 # learn
+    plan = model.last_plan
+    alone = [call(feats.input_features[i : i + 1], feats.attention_mask[i : i + 1]) for i in range(4)]
+    nf = [int(x) for x in feats.attention_mask.sum(-1)]
+    works = [shortform.ChunkWork(feats.input_features[i], nf[i], tag=i) for i in range(4)]
+    eng = model.engine
+    shortform.run_pass(eng, plan, works[:2])                         # two chunks get a head start ...
+    pending = [w for w in works if not w.done]
+    while pending:                                                   # ... then everything unfinished shares the passes
+        shortform.run_pass(eng, plan, pending)
+        pending = [w for w in works if not w.done]
+    for i, w in enumerate(works):
+        seq, raw, seg = shortform.work_tokens(plan, w)
+        same(seq, alone[i]["sequences"][0], f"ids[{i}]")
+        same(raw, alone[i]["token_timestamps"][0], f"ts[{i}]")
+        same(seg, torch.cat([s["token_timestamps"] for s in alone[i]["segments"][0]]), f"segment ts[{i}]")

@@ -20,7 +20,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 constexpr int ACT_WORDS = 10240;   // 40 KB activation block (16 streams x 1280 bf16)
-constexpr int SPIN_MAX = 200000;   // bounded spin: give up (and flag the error) rather than hang the box
+constexpr int SPIN_MAX = 20000;   // bounded spin: give up (and flag the error) rather than hang the box
 
 struct OpArgs {
   const u32x4* w;            // this op's weight slice base
@@ -37,6 +37,7 @@ struct OpArgs {
 template <int U, bool RA>
 __global__ __launch_bounds__(512) void k_op(OpArgs a) {
   __shared__ unsigned part[8][64];
+  __shared__ unsigned first[8][64];
   __shared__ unsigned go;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long t0 = wall_clock64();
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(512) void k_op(OpArgs a) {
         for (int spin = 0; spin < SPIN_MAX && !ok; ++spin) {
           bool mine = true;
           for (int i = lane; i < a.dep_g; i += 64)
-            mine &= __hip_atomic_load(a.dep_flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.epoch;
+            mine &= __hip_atomic_load(a.dep_flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.epoch - 1u;   // the producer's epoch
           ok = __all(mine);
           if (!ok) __builtin_amdgcn_s_sleep(2);
         }
@@ -70,25 +71,29 @@ __global__ __launch_bounds__(512) void k_op(OpArgs a) {
 #pragma unroll
   for (int i = 0; i < 5; ++i)
     xv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (unsigned)(((wave * 5 + i) * 64 + lane) * 16), 0, RA ? 16 : 0));
-  unsigned acc = 0;
+  unsigned acc = 0;   // words of this lane that differ from the block's (uniform) value as ITS first word shows it
 #pragma unroll
-  for (int i = 0; i < 5; ++i) acc += xv[i][0] + xv[i][1] + xv[i][2] + xv[i][3];
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc += xv[i][q] != xv[0][0] ? 1u : 0u;
+  if (tid == 0) go = xv[0][0];
   unsigned wsum = 0;
 #pragma unroll
   for (int u = 0; u < U; ++u) wsum ^= v[u][0] ^ v[u][1] ^ v[u][2] ^ v[u][3];
   part[wave][lane] = acc + (wsum == 0x12345678u ? 1u : 0u);
+  first[wave][lane] = xv[0][0];
   const unsigned long long t2 = wall_clock64();
   __syncthreads();
   // ---- epilogue: wave 0 writes this workgroup's slice (ACT_WORDS / G words) of the next block: value = x[idx] + 1 ----
   if (wave == 0) {
     unsigned s = 0;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) s += part[w][lane];
+    for (int w = 0; w < 8; ++w) s += part[w][lane] + (first[w][lane] != go ? 1u : 0u);
     const int per = ACT_WORDS / gridDim.x;          // words per workgroup (G divides ACT_WORDS)
     const int base = blockIdx.x * per;
     // every lane recomputes "its" outputs from the block it read: out = in + 1 (in is uniform, so in = s-derived check value)
-    const unsigned in0 = xv[0][0];                   // all words of the block are equal by construction
-    if (s != in0 * (unsigned)ACT_WORDS && lane == 0) atomicAdd(a.err + 1, 1u);   // some word of the block was stale
+    const unsigned in0 = go;                         // all words of the block are equal by construction
+    if (__any(s != 0u || xv[0][0] != in0) && lane == 0) atomicAdd(a.err + 1, 1u);   // some word of the block was stale
     const unsigned outv = in0 + 1u + (s == 0xdeadbeefu ? 1u : 0u);
     for (int i = lane * 2; i < per; i += 128) {
       u32x2 o2 = {outv, outv};
