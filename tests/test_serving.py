@@ -149,3 +149,61 @@ def test_hub_isolates_a_failing_request_and_fails_parked_requests_on_close():
     t.join(20)
     assert f1.result(5)[0]["text"] == "n=100"
     assert f2.done() and (f2.exception() is not None or f2.result()[0]["text"] == "n=101")
+
+
+def test_continuous_hub_fills_passes_across_requests_and_answers_early():
+    """Scheduling unit = one seek pass of one chunk: with 30 s chunks the random-weight model needs 1 or 2 passes per chunk;
+    the hub must (a) return exactly the per-request results, (b) run fewer engine passes than per-request decoding would,
+    (c) answer a one-pass request without waiting for the two-pass requests submitted with it."""
+    import time
+
+    from tests.test_shortform import build
+    from thewhisper_amd import AMDWhisperBackend
+    from thewhisper_amd.serving import BatchingHub
+
+    pipe = build(batch_size=4, chunk_s=30)
+    backend = AMDWhisperBackend(None, chunk_length_s=30, asr_pipeline=pipe)
+    backend._generate_kwargs = lambda: {"use_cache": True, "num_beams": 1, "do_sample": False, "max_new_tokens": 24, "language": "en"}
+    lens = [480000, 336000, 160000, 475679, 240000, 480000]
+    bufs = [(wo.synth_audio(n, 40 + i, ["speechlike", "noise", "sine", "speechlike", "zeros", "noise"][i]), 1.5 * i, 16000)
+            for i, n in enumerate(lens)]
+    eng = pipe.model.engine
+    single, passes_single = [], []
+    for a, t0, sr in bufs:
+        n0 = eng.calls["generate"]
+        single.append(backend.transcribe(a.copy(), t0, sr))
+        passes_single.append(eng.calls["generate"] - n0)
+    assert max(passes_single) > 1, passes_single
+    hub = BatchingHub(backend, max_batch=4, max_wait_s=0.3)
+    done_at = {}
+    futs = [hub.submit(a.copy(), t0, sr) for a, t0, sr in bufs[:2]]
+    t_end = time.monotonic() + 120
+    while hub.passes < 1 and time.monotonic() < t_end:     # the first two are one pass ahead ...
+        time.sleep(0.01)
+    futs += [hub.submit(a.copy(), t0, sr) for a, t0, sr in bufs[2:]]   # ... when four more arrive: passes mix seek positions
+    for i, f in enumerate(futs):
+        f.add_done_callback(lambda _f, i=i: done_at.setdefault(i, time.monotonic()))
+    got = [f.result(timeout=600) for f in futs]
+    assert hub._codec is not None and hub.passes > 0, "the continuous scheduler should have been used"
+    batches = list(hub.batches)
+    hub.close()
+    assert normalise(got) == normalise(single)
+    assert len(batches) == hub.passes < sum(passes_single), (batches, passes_single)
+    assert sum(batches) == sum(passes_single) and max(batches) == 4, batches   # every chunk-pass ran exactly once, rows shared
+    assert max(done_at[0], done_at[1]) <= min(done_at[i] for i in range(2, 6))  # answered when THEIR chunks were done
+
+
+def test_hub_falls_back_to_whole_call_batches_when_the_call_is_not_eligible():
+    from thewhisper_amd import AMDWhisperBackend
+    from thewhisper_amd.serving import BatchingHub
+
+    pipe = build_amd_pipeline("micro", 10, 2)
+    pipe.model.fast_generate = False      # e.g. THEWHISPER_FAST_GENERATE=0: no plan can be learned
+    backend = AMDWhisperBackend(None, chunk_length_s=10, asr_pipeline=pipe)
+    hub = BatchingHub(backend, max_batch=2, max_wait_s=0.2)
+    a = wo.synth_audio(64000, 3, "speechlike")
+    want = backend.transcribe(a.copy(), 2.0, 16000)
+    f1, f2 = hub.submit(a.copy(), 2.0, 16000), hub.submit(a.copy(), 2.0, 16000)
+    assert normalise(f1.result(300)) == normalise(want) == normalise(f2.result(300))
+    assert hub._codec is None and hub.passes == 0
+    hub.close()

@@ -57,9 +57,9 @@ def clip_features(pipe, n_clips, chunk_s, seed0=0):
 @pytest.mark.parametrize("mode", ["word", "segments", "none"])
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_generate_equals_hf_control_flow(mode, seed):
-    pipe = build(seed=seed)
+    pipe = build(seed=seed, chunk_s=30)     # 30 s chunks: the random-weight model's timestamps leave room for a second seek pass
     model = pipe.model
-    feats = clip_features(pipe, 4, 10, seed0=10 * seed)
+    feats = clip_features(pipe, 4, 30, seed0=10 * seed)
     kw = dict(GK)
     if mode == "word":
         kw.update(return_timestamps=True, return_token_timestamps=True, return_segments=True)
@@ -70,8 +70,9 @@ def test_generate_equals_hf_control_flow(mode, seed):
     call = lambda: model.generate(input_features=feats.input_features, attention_mask=feats.attention_mask,  # noqa: E731
                                   generation_config=pipe.generation_config, **kw)
     model.fast_generate = False
+    n0 = model.engine.calls["generate"]
     ref = call()                       # HF's WhisperGenerationMixin.generate, every time
-    passes_ref = model.engine.calls["generate"]
+    passes_ref = model.engine.calls["generate"] - n0
     model.fast_generate = True
     first = call()                     # learns the plan (still HF's flow)
     assert model.last_plan is not None, "the call should have been eligible for the short-form plan"
@@ -117,9 +118,9 @@ def test_run_pass_accepts_chunks_from_different_calls():
     and each ends with exactly what it gets when decoded alone."""
     from thewhisper_amd import shortform
 
-    pipe = build(batch_size=4)
+    pipe = build(batch_size=4, chunk_s=30)
     model = pipe.model
-    feats = clip_features(pipe, 4, 10, seed0=40)
+    feats = clip_features(pipe, 4, 30, seed0=40)
     kw = dict(GK, return_timestamps=True, return_token_timestamps=True, return_segments=True)
     call = lambda f, m: model.generate(input_features=f, attention_mask=m, generation_config=pipe.generation_config, **kw)  # noqa: E731
     call(feats.input_features, feats.attention_mask)                 # learn
@@ -133,6 +134,7 @@ def test_run_pass_accepts_chunks_from_different_calls():
     while pending:                                                   # ... then everything unfinished shares the passes
         shortform.run_pass(eng, plan, pending)
         pending = [w for w in works if not w.done]
+    assert max(w.passes for w in works) > 1
     for i, w in enumerate(works):
         seq, raw, seg = shortform.work_tokens(plan, w)
         same(seq, alone[i]["sequences"][0], f"ids[{i}]")

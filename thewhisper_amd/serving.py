@@ -5,14 +5,20 @@ The reference's demo server shares ONE StreamingPipeline across sessions and can
 ``StreamingPipeline`` (per-stream scheduler state), and all sessions of a GPU share one
 ``BatchingHub``: each session's backend proxy implements the reference's
 ``TranscriptionBackend.transcribe`` contract (R:thestage_speechkit/streaming/streaming_pipeline.py:51-64),
-but instead of running the pipeline itself it parks the request; a single worker thread drains up to
-``max_batch`` parked requests and runs them as ONE ``ASRPipeline`` call on a list of buffers - HF's chunk
-iterator then collates the 10 s chunks of different streams into one batched encoder/decoder pass
-(HF:pipelines/base.py:1319-1340), i.e. one ``tw_encode`` / ``tw_generate_greedy`` over <=16 streams.
-Results are identical to per-stream calls (each stream's tokens depend only on its own buffer).
+but instead of running the pipeline itself it parks the request; a single worker thread owns the engine.
+
+Scheduling unit = one *seek pass of one chunk* (``thewhisper_amd.shortform``): a request is pre-processed into its
+chunks' decoding states, every engine pass takes up to ``max_batch`` unfinished chunks - new ones and ones that
+need a further seek iteration alike, whichever session they belong to - and a request is post-processed and answered
+as soon as ITS chunks are done.  (Until round 3 a batch of requests went through one ``ASRPipeline`` call: HF's seek
+loop then runs its later iterations with ever fewer rows while the finished sessions wait for the slowest one - a
+quarter of the engine's throughput on the synthetic streams, profiles/r02_SUMMARY.md.)  Backends whose call is not
+eligible for the restated loop (``AMDWhisperBackend.job_codec() is None``) are served in whole-call batches as before.
+Results are identical to per-stream calls either way (each stream's tokens depend only on its own buffer).
 """
 from __future__ import annotations
 
+import collections
 import queue
 import threading
 import time
@@ -37,7 +43,7 @@ class _StreamBackend:
 
 class BatchingHub:
     def __init__(self, backend: AMDWhisperBackend, max_batch: Optional[int] = None, max_wait_s: float = 0.004,
-                 max_pending: int = 1024):
+                 max_pending: int = 1024, continuous: bool = True):
         self.backend = backend
         eng = backend.asr_pipeline.model.engine
         self.max_batch = int(max_batch or eng.max_batch)
@@ -48,7 +54,17 @@ class BatchingHub:
         self._closed = False
         self._lock = threading.Lock()
         self._next_id = 0
-        self.batches: List[int] = []          # sizes of the batches that were run (introspection / tests)
+        self.batches: "collections.deque[int]" = collections.deque(maxlen=4096)   # sizes of the passes / batches that were run
+        self.passes = 0
+        self.latencies: "collections.deque[float]" = collections.deque(maxlen=4096)  # submit -> answer, seconds
+        self._codec = None
+        if continuous and hasattr(backend, "job_codec"):
+            self._codec = backend.job_codec()
+        self._post_q: "queue.Queue" = queue.Queue()
+        self._poster = None
+        if self._codec is not None:
+            self._poster = threading.Thread(target=self._post_loop, name="thewhisper-postprocess", daemon=True)
+            self._poster.start()
         self._worker = threading.Thread(target=self._run, name="thewhisper-batcher", daemon=True)
         self._worker.start()
 
@@ -60,6 +76,7 @@ class BatchingHub:
     def submit(self, audio: np.ndarray, buffer_start_time: float, sample_rate: int) -> Future:
         """Parks one request; raises ``RuntimeError`` after ``close()`` and ``queue.Full`` when ``max_pending`` requests wait."""
         fut: Future = Future()
+        fut.t_submit = time.monotonic()  # type: ignore[attr-defined]
         with self._lock:
             if self._closed:
                 raise RuntimeError("BatchingHub is closed")
@@ -74,6 +91,9 @@ class BatchingHub:
             self._closed = True
         self._q.put(None)
         self._worker.join(timeout=30)
+        if self._poster is not None:
+            self._post_q.put(None)
+            self._poster.join(timeout=30)
         self._fail_pending(RuntimeError("BatchingHub closed before the request was served"))
 
     def _fail_pending(self, exc: Exception):
@@ -85,6 +105,15 @@ class BatchingHub:
             if item is not None and not item[3].done():
                 item[3].set_exception(exc)
 
+    def _answer(self, fut: Future, result=None, exc: Optional[BaseException] = None):
+        if fut.done():
+            return
+        self.latencies.append(time.monotonic() - getattr(fut, "t_submit", time.monotonic()))
+        if exc is not None:
+            fut.set_exception(exc)
+        else:
+            fut.set_result(result)
+
     # -- worker --------------------------------------------------------------------------------------
     def _run(self):
         try:   # the batcher owns a GPU context: pin this thread's torch device to it
@@ -95,6 +124,95 @@ class BatchingHub:
                 torch.cuda.set_device(dev)
         except Exception:  # noqa: BLE001
             pass
+        if self._codec is not None:
+            try:
+                ok = self._codec.learn()
+            except Exception:  # noqa: BLE001  (the warm-up request failed: serve whole-call batches, errors surface per request)
+                ok = False
+            if ok:
+                self._run_continuous()
+                return
+            self._codec = None
+        self._run_classic()
+
+    # .. continuous: the unit is one seek pass of one chunk ..........................................
+    def _run_continuous(self):
+        from . import shortform
+
+        codec = self._codec
+        eng = self.backend.asr_pipeline.model.engine
+        jobs: List[Any] = []          # requests in flight, oldest first
+        stop = False
+        while True:
+            # 1. take in what has arrived; block only when there is nothing to decode, linger max_wait_s when a pass would
+            #    otherwise leave rows empty (the sessions answered after the last pass are about to ask again)
+            ready = sum(1 for j in jobs for w in j.works if not w.done)
+            deadline = time.monotonic() + self.max_wait_s
+            while not stop:
+                try:
+                    if not jobs:
+                        item = self._q.get()
+                    elif ready < self.max_batch:
+                        item = self._q.get(timeout=max(0.0, deadline - time.monotonic()))
+                    else:
+                        item = self._q.get_nowait()
+                except queue.Empty:
+                    break
+                if item is None:
+                    stop = True
+                    break
+                audio, t0, sr, fut = item
+                try:
+                    job = codec.open(audio, t0, sr)
+                except Exception as e:  # noqa: BLE001  (a malformed buffer fails its own session only)
+                    self._answer(fut, exc=e)
+                    continue
+                job.future = fut
+                jobs.append(job)
+                ready += len(job.works)
+            if stop:
+                for j in jobs:
+                    self._answer(j.future, exc=RuntimeError("BatchingHub closed before the request was served"))
+                return
+            # 2. one pass over the oldest unfinished chunks
+            works = [w for j in jobs for w in j.works if not w.done][: self.max_batch]
+            if not works:
+                continue
+            self.batches.append(len(works))
+            self.passes += 1
+            try:
+                shortform.run_pass(eng, codec.plan, works)
+                for w in works:
+                    if w.passes > 64:
+                        raise RuntimeError("a chunk needed more than 64 seek passes (the decoder keeps seeking to frame 0)")
+            except Exception as e:  # noqa: BLE001  (engine failure: every request that had a chunk in this pass fails)
+                hit = [j for j in jobs if any(w in works for w in j.works)]
+                for j in hit:
+                    self._answer(j.future, exc=e)
+                jobs = [j for j in jobs if j not in hit]
+                continue
+            # 3. finished requests leave for post-processing (tokenizer state machine, word merge: host Python that overlaps
+            #    the next pass - the engine call releases the GIL)
+            still = []
+            for j in jobs:
+                if j.done:
+                    self._post_q.put(j)
+                else:
+                    still.append(j)
+            jobs = still
+
+    def _post_loop(self):
+        while True:
+            job = self._post_q.get()
+            if job is None:
+                return
+            try:
+                self._answer(job.future, result=self._codec.close(job))
+            except Exception as e:  # noqa: BLE001
+                self._answer(job.future, exc=e)
+
+    # .. classic: the unit is one pipeline call over a batch of requests .............................
+    def _run_classic(self):
         while True:
             item = self._q.get()
             if item is None:
@@ -117,18 +235,20 @@ class BatchingHub:
         try:
             results = self.backend.transcribe_many([(a, t0, sr) for a, t0, sr, _ in batch], batch_size=self.max_batch)
             for (_, _, _, fut), res in zip(batch, results):
-                fut.set_result(res)
-        except Exception as e:  # noqa: BLE001
+                self._answer(fut, result=res)
+        except (ValueError, TypeError) as e:
             if len(batch) == 1:
-                if not batch[0][3].done():
-                    batch[0][3].set_exception(e)   # as the reference would raise in that session
+                self._answer(batch[0][3], exc=e)   # as the reference would raise in that session
                 return
             # one malformed buffer must not fail its neighbours: run the members of the batch one by one, so that only
-            # the offending session sees the exception
+            # the offending session sees the exception (input errors only - an engine fault is not retried B more times)
             for a, t0, sr, fut in batch:
                 if fut.done():
                     continue
                 try:
-                    fut.set_result(self.backend.transcribe_many([(a, t0, sr)], batch_size=self.max_batch)[0])
+                    self._answer(fut, result=self.backend.transcribe_many([(a, t0, sr)], batch_size=self.max_batch)[0])
                 except Exception as e1:  # noqa: BLE001
-                    fut.set_exception(e1)
+                    self._answer(fut, exc=e1)
+        except Exception as e:  # noqa: BLE001
+            for _, _, _, fut in batch:
+                self._answer(fut, exc=e)

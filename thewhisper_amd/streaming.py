@@ -81,6 +81,14 @@ class AMDWhisperBackend:
         )
         return [self._to_tokens(res, len(a) / sr, t0) for res, (a, t0, sr) in zip(results, requests)]
 
+    def job_codec(self) -> "Optional[JobCodec]":
+        """Per-request pre/post-processing around ``shortform.run_pass`` (what ``serving.BatchingHub`` schedules), or None
+        when this backend's call cannot run the restated short-form loop (it then serves whole-call batches)."""
+        try:
+            return JobCodec(self)
+        except _NotEligible:
+            return None
+
     @staticmethod
     def _to_tokens(result: Dict[str, Any], audio_duration: float, buffer_start_time: float) -> List[Dict[str, Any]]:
         if _compression_ratio(result["text"]) > 2.2:
@@ -101,3 +109,88 @@ class AMDWhisperBackend:
                 }
             )
         return generated_tokens
+
+
+class _NotEligible(Exception):
+    pass
+
+
+class BufferJob:
+    """One ``transcribe`` request on its way through the hub: its chunks' decoding states and what post-processing needs."""
+
+    __slots__ = ("works", "meta", "audio_duration", "buffer_start_time", "future", "t_submit")
+
+    def __init__(self, works, meta, audio_duration, buffer_start_time):
+        self.works = works                        # [shortform.ChunkWork] - one per <= chunk_length_s piece of the buffer
+        self.meta = meta                          # [(is_last, stride)] as HF's chunk iterator produced them
+        self.audio_duration = audio_duration
+        self.buffer_start_time = buffer_start_time
+        self.future = None
+        self.t_submit = 0.0
+
+    @property
+    def done(self) -> bool:
+        return all(w.done for w in self.works)
+
+
+class JobCodec:
+    """Splits ``AMDWhisperBackend.transcribe`` into the three stages HF's pipeline runs per call - ``preprocess`` (chunking +
+    log-mel), the model, ``postprocess`` (tokenizer state machine, word timestamps, LCS merge) - so that a scheduler can put
+    the model stage of MANY requests into shared passes (``shortform.run_pass``).  Stages 1 and 3 are HF's own methods on
+    the backend's pipeline object, called with exactly the parameters ``pipeline.__call__`` would derive; the model stage's
+    output dictionaries have the shape HF's un-batching hands to ``postprocess`` for a batch of one."""
+
+    def __init__(self, backend: AMDWhisperBackend):
+        pipe = backend.asr_pipeline
+        model = getattr(pipe, "model", None)
+        if model is None or not hasattr(model, "last_plan") or not hasattr(pipe, "_sanitize_parameters"):
+            raise _NotEligible()
+        self.backend = backend
+        self.pipe = pipe
+        pre, _fwd, post = pipe._sanitize_parameters(return_timestamps="word", generate_kwargs=backend._generate_kwargs(),
+                                                     chunk_length_s=backend.chunk_length_s)
+        self.pre = {**pipe._preprocess_params, **pre}
+        self.post = {**pipe._postprocess_params, **post}
+        self.plan = None
+
+    def learn(self) -> bool:
+        """One short request through the ordinary pipeline call: HF's ``generate`` runs once with this backend's options and
+        the model object records the short-form plan (model.py).  False if the call turned out not to be eligible."""
+        model = self.pipe.model
+        model.last_plan = None
+        self.backend.transcribe(np.zeros(self.backend.sample_rate, dtype=np.float32), 0.0, self.backend.sample_rate)
+        plan = model.last_plan
+        if plan is None or not plan.return_token_timestamps or not plan.return_segments:
+            return False
+        self.plan = plan
+        return True
+
+    def open(self, audio: np.ndarray, buffer_start_time: float, sample_rate: int) -> BufferJob:
+        """Stage 1 (HF:pipelines/automatic_speech_recognition.py:346-482 via ``pipe.preprocess``)."""
+        from .shortform import ChunkWork
+
+        audio = np.asarray(audio)
+        works, meta = [], []
+        for item in self.pipe.preprocess(audio, **self.pre):
+            feats = item["input_features"]
+            am = item.get("attention_mask")
+            nf = int(am.sum()) if am is not None else None
+            works.append(ChunkWork(feats[0], nf))
+            meta.append((item["is_last"], item.get("stride")))
+        if not works:
+            raise ValueError("empty audio buffer")
+        return BufferJob(works, meta, len(audio) / sample_rate, buffer_start_time)
+
+    def close(self, job: BufferJob) -> List[Dict[str, Any]]:
+        """Stage 3 (``pipe.postprocess`` + the reference backend's word fix-ups, R:...:412-433)."""
+        from .shortform import work_tokens
+
+        outs = []
+        for w, (is_last, stride) in zip(job.works, job.meta):
+            seq, _raw, seg = work_tokens(self.plan, w)
+            o = {"is_last": is_last, "tokens": seq.unsqueeze(0), "token_timestamps": seg.unsqueeze(0)}
+            if stride is not None:
+                o["stride"] = stride
+            outs.append(o)
+        result = self.pipe.postprocess(outs, **self.post)
+        return AMDWhisperBackend._to_tokens(result, job.audio_duration, job.buffer_start_time)
