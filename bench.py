@@ -159,11 +159,15 @@ def cpu_baseline(model_name, chunk_s, new_tokens, calls, budget_s=240):
         if not line:
             raise RuntimeError((r.stderr or r.stdout)[-300:])
         d = json.loads(line[-1][len("CPU_BASELINE "):])
-        return {"value": round(d["tok"] / d["dt"], 3), "unit": "tok/s", "cores": d["cores"], "kind": "reference",
+        # "reference" only when the reference tree's own class ran; on the GPU box (no /root/reference) it is the class that one
+        # subclasses without touching its arithmetic: HF's pipeline, labelled as such
+        kind = "reference" if d["which"].startswith("thestage_speechkit") else "hf-pipeline"
+        return {"value": round(d["tok"] / d["dt"], 3), "unit": "tok/s", "cores": d["cores"], "kind": kind,
                 "sample": f"{d['which']}: {what}; {d['dt']:.1f} s wall ({', '.join(f'{x:.1f}' for x in d['calls'])} s per call; "
                           f"+{d['init']:.0f} s untimed model init)"}
     except subprocess.TimeoutExpired:
-        return {"value": round(new_tokens * calls / budget_s, 3), "unit": "tok/s", "cores": cores, "kind": "reference",
+        return {"value": round(new_tokens * calls / budget_s, 3), "unit": "tok/s", "cores": cores,
+                "kind": "reference" if os.path.isdir(os.path.join(os.environ.get("TW_REFERENCE_DIR", "/root/reference"), "thestage_speechkit")) else "hf-pipeline",
                 "sample": what + f": did NOT finish within the {budget_s} s budget - value is an upper bound"}
 
 
@@ -220,30 +224,60 @@ def pipeline_leg(eng, dims, args, device_index, heads, latency_calls, hub_rounds
             backend.transcribe(buf, 0.0, 16000)
             rag.append((time.perf_counter() - t0) * 1e3)
         rag.sort()
-        hub = BatchingHub(backend, max_batch=B, max_wait_s=0.05)
-        gate = threading.Barrier(B)
+        # (a) lock-step rounds (continuity with rounds 1-2: all sessions ask at once and wait for the slowest), classic whole-call
+        #     batches: what the hub did until round 3
+        def lockstep(hub, rounds):
+            gate = threading.Barrier(B)
 
-        def session(k, rounds):
-            be = hub.stream_backend()
-            for _ in range(rounds):
-                gate.wait()
-                be.transcribe(clips[k], 0.0, 16000)
+            def session(k):
+                be = hub.stream_backend()
+                for _ in range(rounds):
+                    gate.wait()
+                    be.transcribe(clips[k], 0.0, 16000)
 
-        def run(rounds):
-            th = [threading.Thread(target=session, args=(k, rounds)) for k in range(B)]
+            th = [threading.Thread(target=session, args=(k,)) for k in range(B)]
             [t.start() for t in th]
             [t.join() for t in th]
 
-        run(1)                                   # warm-up round (graph capture for this batch size)
-        counted["tok"] = 0
-        hub.batches.clear()
+        # (b) free-running sessions (what B independent streaming schedulers are): every session asks again as soon as it has
+        #     its answer; the hub fills each pass with whatever chunks need one (serving.py)
+        def free_running(hub, per_session):
+            def session(k):
+                be = hub.stream_backend()
+                for i in range(per_session):
+                    be.transcribe(clips[(k + i) % B], 0.0, 16000)
+
+            th = [threading.Thread(target=session, args=(k,)) for k in range(B)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+
+        out = {}
+        hub = BatchingHub(backend, max_batch=B, max_wait_s=0.004)
+        free_running(hub, 1)                       # warm-up: plan learning + graph capture for this batch size
+        hub.latencies.clear(); hub.batches.clear(); counted["tok"] = 0
         t0 = time.perf_counter()
-        run(hub_rounds)
+        free_running(hub, hub_rounds)
+        dt = time.perf_counter() - t0
+        lats = sorted(hub.latencies)
+        sizes = list(hub.batches)
+        out.update({
+            "hub_tok_per_s": round(counted["tok"] / dt, 1), "hub_sessions": B, "hub_requests": B * hub_rounds,
+            "hub_mode": "continuous (seek passes of chunks)" if hub.passes else "whole-call batches",
+            "hub_request_p50_ms": round(lats[len(lats) // 2] * 1e3, 2) if lats else None,
+            "hub_request_p90_ms": round(lats[min(len(lats) - 1, (len(lats) * 9) // 10)] * 1e3, 2) if lats else None,
+            "hub_mean_rows_per_pass": round(sum(sizes) / max(1, len(sizes)), 2), "hub_passes": len(sizes),
+            "hub_tokens": counted["tok"],
+        })
+        hub.close()
+        hub = BatchingHub(backend, max_batch=B, max_wait_s=0.05, continuous=False)
+        lockstep(hub, 1)
+        counted["tok"] = 0
+        t0 = time.perf_counter()
+        lockstep(hub, hub_rounds)
         dt = time.perf_counter() - t0
         hub.close()
-        return {
-            "hub_tok_per_s": round(counted["tok"] / dt, 1), "hub_sessions": B, "hub_rounds": hub_rounds,
-            "hub_ms_per_round": round(dt / hub_rounds * 1e3, 2), "hub_batch_sizes": sorted(set(hub.batches)),
+        out.update({"hub_lockstep_tok_per_s": round(counted["tok"] / dt, 1), "hub_lockstep_ms_per_round": round(dt / hub_rounds * 1e3, 2)})
+        out.update({
             "backend_transcribe_p50_ms": round(lat[len(lat) // 2], 2) if lat else None,
             "backend_transcribe_p90_ms": round(lat[min(len(lat) - 1, (len(lat) * 9) // 10)], 2) if lat else None,
             "backend_transcribe_calls": len(lat),
@@ -252,11 +286,70 @@ def pipeline_leg(eng, dims, args, device_index, heads, latency_calls, hub_rounds
             "scheduler_pattern_calls": len(rag),
             "note": f"host float32 {args.chunk_s} s buffers through thewhisper_amd.AMDWhisperBackend.transcribe (reference contract "
                     f"R:thestage_speechkit/streaming/streaming_pipeline.py:388-435: word timestamps on, max_new_tokens=128, natural eos); "
-                    f"{B} session threads share one engine through BatchingHub; scheduler_pattern_* = the ragged 2-10.5 s rolling "
-                    f"buffers the reference scheduler sends for one stream (clips longer than the chunk are cut to it)",
-        }
+                    f"hub_*: {B} free-running session threads share one engine through BatchingHub, {hub_rounds} requests each, tokens "
+                    f"counted over every seek pass (a random-weight model needs ~3 passes per 10 s buffer); hub_lockstep_*: all "
+                    f"sessions ask at once and the round ends with the slowest (whole-call batches, as in rounds 1-2); "
+                    f"scheduler_pattern_* = the ragged 2-10.5 s rolling buffers the reference scheduler sends for one stream",
+        })
+        return out
     finally:
         eng.generate_greedy = inner
+
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE.json's other single-GPU configurations, compact, in the same run (rank 0, N = 1)
+# ------------------------------------------------------------------------------------------------------------------
+def secondary_leg(label, model, chunk_s, B, dtype, steps, new_tokens, device_index, use_graph=True):
+    """One more configuration through the same C ABI, stages back to back on the whole chip (no encoder overlap): tokens/s of
+    the whole hot path, the decode step and its roofline fraction (same algorithmic-bytes rule as the headline)."""
+    from thewhisper_amd.engine import WhisperEngine
+
+    dims = DIMS[model]
+    T = 50 * chunk_s
+    heads = alignment_heads(dims)
+    dev = torch.device("cuda", device_index)
+    eng = WhisperEngine(dims, T, max_batch=B, dtype=dtype, alignment_heads=heads, device=device_index, use_graph=use_graph)
+    try:
+        eng.load_state_dict(random_state_dict(dims, dev, seed=0))
+        torch.cuda.empty_cache()
+        g = torch.Generator(device=dev)
+        g.manual_seed(2000)
+        pcm = (torch.randn((B, chunk_s * 16000), device=dev, generator=g, dtype=torch.float32) * 0.1).clamp_(-1, 1)
+        prompt = np.tile(np.array([[50258, 50259, 50360]], dtype=np.int32), (B, 1))
+
+        def one():
+            eng.encode(eng.logmel(pcm))
+            eng.cross_kv(B)
+            out = eng.generate_greedy(prompt, max_new_tokens=new_tokens, min_new_tokens=new_tokens, timestamps=True, want_alignment=True)
+            eng.token_timestamps(B, 3, out["length"], [2 * T] * B)
+            return out["length"] - 3, eng.last_timings()
+
+        one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tok, greedy_ms, enc_ms, dsteps = 0, 0.0, 0.0, 0
+        for _ in range(steps):
+            n, tm = one()
+            tok += n * B
+            greedy_ms += tm["greedy_ms"]
+            enc_ms += tm["encode_ms"] + tm["cross_kv_ms"] + tm["logmel_ms"]
+            dsteps += tm["decode_steps"]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        esz = 2
+        wsz = 1.0 + 1.0 / 32 if dtype == "fp8" else None
+        spc = dsteps // steps
+        alg, _W = algorithmic_decode_bytes(dims, B, T, 3, spc, esz, wsz)
+        ach = alg / (greedy_ms / steps * 1e-3) / 1e9
+        return {"config": label, "workload": f"whisper-{model}, {chunk_s} s chunk(s), {B} stream(s), {new_tokens} forced tokens + DTW, dtype {dtype}, "
+                                            f"stages back to back on the whole chip",
+                "tok_per_s": round(tok / dt, 1), "ms_per_step": round(dt / steps * 1e3, 2), "steps": steps,
+                "encoder_stage_ms": round(enc_ms / steps, 2), "decode_step_ms": round(greedy_ms / max(1, dsteps), 4),
+                "roofline_frac": round(ach / HBM_PEAK_GBS, 4), "achieved_GBs": round(ach, 1),
+                "algorithmic_bytes_per_step": int(alg / max(1, spc))}
+    finally:
+        eng.close()
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -278,13 +371,18 @@ def spawn_ranks(n: int, argv) -> int:
 def load_pmc_traffic(args):
     """HBM bytes per decode step from the committed rocprofv3 PMC passes of the same command line
     (tools/profile_round.sh -> profiles/*_pmc_step_traffic.json); None when no summary matches this configuration."""
+    from thewhisper_amd.build import source_digest
+
     best = None
+    sha = source_digest()
     for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_step_traffic.json"))):
         try:
             d = json.load(open(p))
         except Exception:  # noqa: BLE001
             continue
         c = d.get("config", {})
+        if d.get("kernel_source_sha256") != sha:
+            continue      # counters of OTHER kernels (an older round's build): not this run's traffic
         if (c.get("model"), c.get("streams"), c.get("chunk_s"), c.get("dtype"), c.get("new_tokens")) == \
                 (args.model, args.streams, args.chunk_s, args.dtype, args.new_tokens):
             best = (d, os.path.basename(p))
@@ -314,7 +412,8 @@ def main(argv=None):
                          "(same box: 10 436 vs 10 340 tok/s with 64)")
     ap.add_argument("--latency-iters", type=int, default=100, help="single-stream chunk calls timed for the p50 (after 10 warm-ups; SURVEY.md section 8d)")
     ap.add_argument("--no-pipeline-leg", action="store_true", help="skip the measurement through ASRPipeline / BatchingHub")
-    ap.add_argument("--hub-rounds", type=int, default=4)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the compact legs for BASELINE configs 2 (turbo, 30 s, 1 stream) and 5 (fp8, 15 s)")
+    ap.add_argument("--hub-rounds", type=int, default=6, help="requests per session in the hub measurement")
     args = ap.parse_args(argv)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -485,8 +584,9 @@ def main(argv=None):
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 4), "copy_ceiling": HBM_COPY_CEILING_GBS,
                 "traffic": (round(pmc[0]["hbm_bytes_per_step"]) if pmc else None),
-                "traffic_source": (f"profiles/{pmc[1]}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command line, FETCH_SIZE x2 "
-                                   f"(gfx950 correction, MI355X_MICROARCH.md)" if pmc else None),
+                "traffic_source": (f"profiles/{pmc[1]}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command line with THESE kernels "
+                                   f"(kernel_source_sha256 matches the running build), FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md)"
+                                   if pmc else "no PMC summary under profiles/ was taken with this build's kernel sources (tools/profile_round.sh)"),
                 "algorithmic_bytes_per_step": int(alg_bytes / max(1, steps_per_call)),
                 "algorithmic_bytes_per_call": alg_bytes, "weight_bytes_per_step": W, "decode_steps_per_call": steps_per_call,
                 "avg_step_ms": round(avg_step_ms, 4),
@@ -503,6 +603,21 @@ def main(argv=None):
                 result["pipeline"] = pipeline_leg(eng, dims, args, local, heads, args.latency_iters, args.hub_rounds)
             except Exception as e:  # noqa: BLE001
                 result["pipeline"] = {"error": repr(e)}
+        result["value_definition"] = ("value = tokens/s of the hot path driven through the C ABI with the PCM resident in HBM (what a host written "
+                                      "against include/thewhisper.h gets; the contract's definition). value_api = SURVEY.md section 8d's "
+                                      "definition: generated tokens over wall-clock from transcribe() entry to return, host buffers in, word "
+                                      "dictionaries out, through AMDWhisperBackend / BatchingHub (pipeline.hub_tok_per_s)")
+        result["value_api"] = (result.get("pipeline") or {}).get("hub_tok_per_s")
+        if world == 1 and not stub and not args.no_secondary:
+            legs = []
+            for label, model, chunk_s, nb, dt_, k in (("configs[1]: large-v3-turbo, 30 s chunk, batch 1, bf16", "large-v3-turbo", 30, 1, "bf16", 5),
+                                                        ("configs[4]: large-v3, MXFP8 decoder weights + fp8 cross-K/V, 15 s chunks, word timestamps", "large-v3", 15, B, "fp8", 3),
+                                                        ("configs[4] shape in bf16 (for the fp8 / bf16 ratio)", "large-v3", 15, B, "bf16", 3)):
+                try:
+                    legs.append(secondary_leg(label, model, chunk_s, nb, dt_, k, args.new_tokens, local, use_graph=not args.no_graph))
+                except Exception as e:  # noqa: BLE001
+                    legs.append({"config": label, "error": repr(e)})
+            result["other_configs"] = legs
         if world == 1 and not stub and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(args.model, args.chunk_s, args.cpu_tokens, args.cpu_calls)

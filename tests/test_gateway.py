@@ -110,7 +110,7 @@ def test_concurrent_requests_share_batches(served):
     [t.start() for t in th]
     [t.join(300) for t in th]
     assert all(o is not None and "metadata" in o for o in out)
-    assert max(hub.batches[before:]) > 1            # different HTTP requests were decoded in one batched pass
+    assert max(list(hub.batches)[before:]) > 1            # different HTTP requests were decoded in one batched pass
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference checkout not present")

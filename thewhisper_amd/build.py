@@ -37,6 +37,13 @@ def _digest(paths: List[str]) -> str:
     return h.hexdigest()
 
 
+def source_digest() -> str:
+    """sha256 over every kernel source + header + the flags: identifies WHICH kernels a measurement belongs to (bench.py
+    refuses a PMC traffic summary taken with other kernels)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    return _digest(srcs + [os.path.join(CSRC, "tw_common.h"), os.path.join(HERE, "..", "include", "thewhisper.h")])
+
+
 def library_path() -> str:
     return os.path.join(LIBDIR, LIBNAME)
 

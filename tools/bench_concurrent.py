@@ -25,11 +25,16 @@ for groups in (1, 2, 4):
     prompt = np.tile(np.array([[50258, 50259, 50360]], dtype=np.int32), (bs, 1))
     for e in engs:
         e.encode(e.logmel(pcm[:bs])); e.cross_kv(bs)
-        e.generate_greedy(prompt, max_new_tokens=8, min_new_tokens=8, timestamps=True, want_alignment=True)
+        s_ = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(s_):   # warm-up on a non-default stream too (graph capture)
+            e.generate_greedy(prompt, max_new_tokens=TOK, min_new_tokens=TOK, timestamps=True, want_alignment=True)
     torch.cuda.synchronize()
     def work(e):
-        for _ in range(3):
-            e.generate_greedy(prompt, max_new_tokens=TOK, min_new_tokens=TOK, timestamps=True, want_alignment=True)
+        # every chain on ITS OWN HIP stream (a thread's torch "current stream" is the default stream otherwise, which would
+        # serialise the groups on one queue and say nothing about concurrency)
+        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+            for _ in range(3):
+                e.generate_greedy(prompt, max_new_tokens=TOK, min_new_tokens=TOK, timestamps=True, want_alignment=True)
     t0 = time.perf_counter()
     th = [threading.Thread(target=work, args=(e,)) for e in engs]
     [t.start() for t in th]; [t.join() for t in th]

@@ -40,6 +40,10 @@ for k in sorted(set(fetch) | set(write)):
     wb = write[k][1] * 1024 / max(1, steps)
     rows[k] = {"launches_per_step": round(fetch[k][0] / max(1, steps), 2), "fetch_bytes_per_step": round(fb), "write_bytes_per_step": round(wb)}
     tot += fb + wb
-print(json.dumps({"config": json.loads(sys.argv[3]), "decode_steps": steps, "hbm_bytes_per_step": round(tot),
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from thewhisper_amd.build import source_digest  # noqa: E402
+
+print(json.dumps({"config": json.loads(sys.argv[3]), "kernel_source_sha256": source_digest(), "decode_steps": steps, "hbm_bytes_per_step": round(tot),
                   "correction": "FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read correction) + WRITE_SIZE KiB x 1024",
                   "per_kernel": rows}, indent=1))
