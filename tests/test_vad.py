@@ -124,3 +124,141 @@ def test_vad_kernel_matches_the_restatement():
     host = types.SimpleNamespace(vad_model=None, use_vad=False)
     attach_vad(host)
     assert host.use_vad and isinstance(host.vad_model, EnergyVAD)
+
+
+# ---- VadService: all sessions' detectors behind one worker, frames of an add_chunk in one request --------------------------
+def _np_kernel(pcm, state):
+    return wo.energy_vad(pcm, state)
+
+
+def test_vad_service_batches_sessions_and_equals_sequential_detectors():
+    import threading
+
+    from thewhisper_amd.vad import VadService
+
+    svc = VadService(max_streams=8, window_s=0.05, kernel=_np_kernel)
+    xs = [_talk_silence(s)[: 512 * 40] for s in range(4)]
+    streams = [svc.open_stream() for _ in range(4)]
+    got = [[] for _ in range(4)]
+    gate = threading.Barrier(4)
+
+    def session(k):
+        for i in range(0, len(xs[k]), 512 * 2):            # a tick = two frames, asked for in ONE request
+            gate.wait()
+            n = streams[k].prefetch(xs[k][i : i + 1024])
+            assert n == 2
+            for f in range(2):                             # the scheduler's frame-by-frame calls replay the prefetched frames
+                got[k].append(streams[k](torch.from_numpy(xs[k][i + 512 * f : i + 512 * (f + 1)]), 16000).item())
+
+    th = [threading.Thread(target=session, args=(k,)) for k in range(4)]
+    [t.start() for t in th]
+    [t.join(60) for t in th]
+    for k in range(4):
+        ref, _ = wo.energy_vad(xs[k][None])
+        assert np.array_equal(np.array(got[k], np.float32), ref[0])
+    assert svc.requests == 4 * 20 and svc.launches < svc.requests / 2      # sessions of a tick shared launches
+    assert all(s.launch_requests == 20 for s in streams)                  # one request per tick, not one per frame
+    # a frame that was not prefetched is evaluated directly; reset clears the slot's state
+    streams[0].reset_states()
+    p0 = streams[0](xs[0][:512], 16000).item()
+    assert p0 == wo.energy_vad(xs[0][None, :512])[0][0, 0]
+    # slots are recycled
+    for s in streams:
+        s.close()
+    assert len(svc._free) == 8
+    svc.close()
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+def test_gateway_sessions_are_gated_by_the_shared_vad_service():
+    """SessionHost + VadService under the reference's unmodified StreamingPipeline: the add_chunk route asks for all frames of a
+    chunk at once (one service request per chunk), the scheduler's state machine sees exactly the per-frame decisions of a
+    sequential detector, and silence does not reach the backend."""
+    from oracle.make_golden import _import_reference
+    from thewhisper_amd.gateway import SessionHost
+    from thewhisper_amd.vad import VadService
+
+    _, sp = _import_reference()
+    sent = {0: [], 1: []}
+
+    class Spy:
+        sample_rate, chunk_length_s = 16000, 10
+
+        def __init__(self, k=None):
+            self.k = k
+
+        def transcribe(self, audio, buffer_start_time, sample_rate):
+            sent[self.k].append(len(audio))
+            return []
+
+    made = []
+
+    def factory(backend, chunk_length_s):
+        k = len(made)
+        s = sp.StreamingPipeline(backend=Spy(k), chunk_length_s=chunk_length_s, min_process_chunk_s=0.5, use_vad=False)
+        made.append(s)
+        return s
+
+    svc = VadService(max_streams=4, window_s=0.002, kernel=_np_kernel)
+    host = SessionHost(Spy(), scheduler_factory=factory, vad=svc)
+    a, b = host.create(), host.create()
+    xa, xb = _talk_silence(3, (1.5, 2.5, 6.0)), _talk_silence(4, (0.5, 1.0, 3.0))
+    for i in range(0, max(len(xa), len(xb)), 800):
+        for sid, x in ((a, xa), (b, xb)):
+            if i < len(x):
+                host.add_chunk(sid, x[i : i + 800])
+                host.process(sid)
+    # reference run of the same state machine with a sequential detector
+    want = []
+    class RefSpy:
+        def transcribe(self, audio, buffer_start_time, sample_rate):
+            want.append(len(audio))
+            return []
+
+    s_ref = sp.StreamingPipeline(backend=RefSpy(), chunk_length_s=10, min_process_chunk_s=0.5, use_vad=False)
+    s_ref.vad_model, s_ref.use_vad = _OracleVad(), True
+    for i in range(0, len(xa), 800):
+        s_ref(xa[i : i + 800])
+    assert sent[0] == want and sent[0], "the gated session must send exactly what the sequentially gated scheduler sends"
+    assert max(sent[0]) < 16000 * 5.5
+    streams = [host.sessions[a]["vad"], host.sessions[b]["vad"]]
+    assert streams[0].launch_requests <= len(range(0, len(xa), 800))      # <= one request per add_chunk
+    host.end(a); host.end(b)
+    assert len(svc._free) == 4
+    svc.close()
+
+
+@pytest.mark.gpu
+def test_vad_service_on_gpu_equals_per_stream_detectors():
+    """The serving form on the MI355X: requests of several sessions merged into shared tw_vad_energy launches (state gathered and
+    scattered by slot) give every session exactly what its own sequential detector gives."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    import threading
+
+    from thewhisper_amd.vad import BatchedVAD, VadService
+
+    xs = [_talk_silence(s)[: 512 * 60] for s in range(6)]
+    want = []
+    for x in xs:
+        want.append(BatchedVAD(1).probs(x[None]).cpu().numpy()[0])
+    svc = VadService(max_streams=16, window_s=0.02)
+    streams = [svc.open_stream() for _ in range(6)]
+    got = [[] for _ in range(6)]
+    gate = threading.Barrier(6)
+
+    def session(k):
+        step = 512 * (1 + k % 3)                             # sessions tick with different chunk sizes: 1, 2 or 3 frames
+        for i in range(0, len(xs[k]), step):
+            gate.wait() if i == 0 else None
+            n = streams[k].prefetch(xs[k][i : i + step])
+            for f in range(n):
+                got[k].append(streams[k](xs[k][i + 512 * f : i + 512 * (f + 1)], 16000).item())
+
+    th = [threading.Thread(target=session, args=(k,)) for k in range(6)]
+    [t.start() for t in th]
+    [t.join(120) for t in th]
+    for k in range(6):
+        assert np.array_equal(np.array(got[k], np.float32), want[k]), k
+    assert svc.launches < svc.requests                        # requests shared launches
+    svc.close()

@@ -21,7 +21,7 @@ import numpy as np
 from .serving import BatchingHub
 from .streaming import AMDWhisperBackend
 
-__all__ = ["create_app", "decode_wav", "words_to_response", "multipart_file"]
+__all__ = ["create_app", "decode_wav", "words_to_response", "multipart_file", "SessionHost", "HostBusy"]
 
 
 def multipart_file(body: bytes, content_type: str, field: str = "file") -> bytes:
@@ -88,110 +88,228 @@ def _default_scheduler_factory(session_backend, chunk_length_s):
     return StreamingPipeline(backend=session_backend, chunk_length_s=chunk_length_s, min_process_chunk_s=0.5, use_vad=False)
 
 
-def create_app(backend: Union[BatchingHub, AMDWhisperBackend], auth_token: str = "", model_name: str = "",
-               lang_id: Optional[str] = None, path: str = "/transcribe", scheduler_factory=None, max_sessions: int = 1024):
-    """FastAPI application.  ``backend``: a ``BatchingHub`` (concurrent requests share batches) or a bare
-    ``AMDWhisperBackend``.  ``auth_token``: when set, requests must carry ``Authorization: Bearer <token>``.
-    ``lang_id``: when set, a request's ``X-Lang-Id`` must equal it (the engine is built for one language prompt).
+class HostBusy(Exception):
+    """The host cannot take the request now (session table or request queue full, hub closed): HTTP 503 + Retry-After."""
+
+
+class SessionHost:
+    """Everything behind the routes for ONE GPU: the session table (per-session reference scheduler + lock + last use), the
+    shared ``BatchingHub`` and, optionally, the shared voice-activity service.  ``thewhisper_amd.node.NodeRouter`` exposes
+    the same methods over N such hosts in N processes (one per MI355X)."""
+
+    def __init__(self, backend: Union[BatchingHub, AMDWhisperBackend], scheduler_factory=None, max_sessions: int = 1024,
+                 session_ttl_s: float = 900.0, vad=None):
+        import threading
+
+        self.hub = backend if isinstance(backend, BatchingHub) else None
+        self.base_backend = backend.backend if self.hub is not None else backend
+        self.sample_rate = self.base_backend.sample_rate
+        self.make_scheduler = scheduler_factory or _default_scheduler_factory
+        self.max_sessions = int(max_sessions)
+        self.session_ttl_s = float(session_ttl_s)
+        self.vad = vad                      # thewhisper_amd.vad.VadService or None (sessions then run with use_vad=False)
+        self.sessions: Dict[str, Dict[str, Any]] = {}
+        self._lock = threading.Lock()
+        # a bare backend has ONE tw_ctx, which is not thread-safe (include/thewhisper.h): serialise the engine calls of the
+        # request threads.  Behind a hub the worker thread is the only caller.
+        self._engine_lock = threading.Lock()
+
+    # -- sessions ------------------------------------------------------------------------------------
+    def _evict_idle(self, now: float) -> int:
+        """Sessions nobody ended (a client that went away): dropped after ``session_ttl_s`` without a request."""
+        dead = [k for k, v in self.sessions.items() if now - v["last_used"] > self.session_ttl_s and not v["lock"].locked()]
+        for k in dead:
+            self._drop(self.sessions.pop(k))
+        return len(dead)
+
+    @staticmethod
+    def _drop(sess: Dict[str, Any]):
+        vs = sess.get("vad")
+        if vs is not None:
+            vs.close()
+
+    def create(self, session_id: Optional[str] = None) -> str:
+        import base64
+        import os
+        import threading
+        import time
+
+        sid = session_id or base64.urlsafe_b64encode(os.urandom(16)).decode("ascii")     # as R:examples/server.py:122
+        now = time.monotonic()
+        with self._lock:
+            self._evict_idle(now)
+            if len(self.sessions) >= self.max_sessions:
+                raise HostBusy("too many sessions")
+        session_backend = self.hub.stream_backend() if self.hub is not None else _LockedBackend(self.base_backend, self._engine_lock)
+        sched = self.make_scheduler(session_backend, self.base_backend.chunk_length_s)
+        vs = None
+        if self.vad is not None:
+            from .vad import attach_vad
+
+            vs = self.vad.open_stream()
+            attach_vad(sched, vs)
+        with self._lock:
+            self.sessions[sid] = {"scheduler": sched, "lock": threading.Lock(), "last_used": now, "vad": vs}
+        return sid
+
+    def _get(self, sid: str) -> Dict[str, Any]:
+        import time
+
+        with self._lock:
+            s = self.sessions.get(sid)
+            if s is not None:
+                s["last_used"] = time.monotonic()
+        if s is None:
+            raise KeyError(sid)
+        return s
+
+    def add_chunk(self, sid: str, audio_np: np.ndarray) -> None:
+        s = self._get(sid)
+        with s["lock"]:
+            sched, vs = s["scheduler"], s["vad"]
+            if vs is not None and getattr(sched, "use_vad", False):
+                # the reference evaluates its detector frame by frame on (left-over samples + this chunk)
+                # (R:...streaming_pipeline.py:589-622): ask for all of those frames in ONE request, which the VadService merges
+                # with the other sessions' into one launch; the scheduler's per-frame calls are then answered from it
+                left = getattr(sched, "_vad_buffer", np.zeros(0, np.float32))
+                vs.prefetch(np.concatenate([np.asarray(left, np.float32), np.asarray(audio_np, np.float32)]))
+            sched.add_new_chunk(audio_np)
+
+    def process(self, sid: str):
+        s = self._get(sid)
+        with s["lock"]:
+            return s["scheduler"].process_new_chunk()    # blocks in the hub while the shared passes decode
+
+    def clear(self, sid: str) -> None:
+        s = self._get(sid)
+        with s["lock"]:
+            if hasattr(s["scheduler"], "clear"):
+                s["scheduler"].clear()   # per-session state: clearing is safe here (the reference's shared pipeline leaves it commented out)
+            if s["vad"] is not None:
+                s["vad"].reset_states()
+
+    def end(self, sid: str) -> None:
+        with self._lock:
+            s = self.sessions.pop(sid, None)
+        if s is not None:
+            self._drop(s)
+
+    # -- stateless -----------------------------------------------------------------------------------
+    def transcribe(self, audio: np.ndarray, sr: int) -> List[Dict[str, Any]]:
+        import queue as _queue
+
+        if self.hub is not None:
+            try:
+                fut = self.hub.submit(audio, 0.0, sr)
+            except _queue.Full as e:
+                raise HostBusy("request queue full") from e
+            except RuntimeError as e:
+                raise HostBusy(str(e)) from e
+            return fut.result()
+        with self._engine_lock:
+            return self.base_backend.transcribe(audio, 0.0, sr)
+
+    def health(self) -> Dict[str, Any]:
+        return {"passes": (len(self.hub.batches) if self.hub is not None else None), "sessions": len(self.sessions),
+                "vad_launches": (self.vad.launches if self.vad is not None else None)}
+
+
+class _LockedBackend:
+    """``TranscriptionBackend`` view of a bare backend for request threads: one engine call at a time."""
+
+    def __init__(self, backend, lock):
+        self._b, self._lock = backend, lock
+
+    def transcribe(self, audio, buffer_start_time, sample_rate):
+        with self._lock:
+            return self._b.transcribe(audio, buffer_start_time, sample_rate)
+
+
+def create_app(backend, auth_token: str = "", model_name: str = "", lang_id: Optional[str] = None, path: str = "/transcribe",
+               scheduler_factory=None, max_sessions: int = 1024, session_ttl_s: float = 900.0, vad=None):
+    """FastAPI application.  ``backend``: a ``BatchingHub`` (concurrent requests share passes), a bare ``AMDWhisperBackend``, a
+    ready ``SessionHost`` or a ``thewhisper_amd.node.NodeRouter`` (one host process per GPU).  ``auth_token``: when set,
+    requests must carry ``Authorization: Bearer <token>``.  ``lang_id``: when set, a request's ``X-Lang-Id`` must equal it
+    (the engine is built for one language prompt).  ``vad``: a ``thewhisper_amd.vad.VadService`` - sessions are then gated
+    like the reference's default ``use_vad=True`` (energy rule, not silero - vad.py), all sessions' frames in shared launches.
 
     Two surfaces:
       * ``POST /transcribe`` - stateless, the wire format of the reference's remote backend (module docstring);
       * ``POST /session/create/``, ``/session/{id}/add_chunk``, ``/process``, ``/clear``, ``/end`` - the routes of the
         reference's demo server (R:examples/server.py:118-163) with the same request / response shapes, except that every
         session owns its scheduler state (the reference shares ONE StreamingPipeline across sessions, :25, :90, :98, and
-        cannot batch) and all sessions of the process share the hub, i.e. one batched engine call per tick.
-        ``scheduler_factory(session_backend, chunk_length_s)`` builds the per-session scheduler (default: the reference's
-        StreamingPipeline)."""
+        cannot batch) and all sessions of a GPU share the hub.  Sessions nobody ends are dropped after ``session_ttl_s``.
+    Every route body runs in the thread pool: a session's lock is held for the whole batched decode of ``/process``, and
+    taking it on the event loop would stall every other session (and defeat the batching the routes exist for)."""
     import base64
-    import os
-    import threading
+    import queue as _queue
 
     from fastapi import FastAPI, Header, HTTPException, Request
     from fastapi.concurrency import run_in_threadpool
 
     app = FastAPI(title="thewhisper-amd gateway")
-    hub = backend if isinstance(backend, BatchingHub) else None
-    base_backend = backend.backend if hub is not None else backend
-    sample_rate = base_backend.sample_rate
-    sessions: Dict[str, Any] = {}
-    sessions_lock = threading.Lock()
-    make_scheduler = scheduler_factory or _default_scheduler_factory
+    if hasattr(backend, "create") and hasattr(backend, "add_chunk"):
+        host = backend                       # SessionHost or NodeRouter
+    else:
+        host = SessionHost(backend, scheduler_factory=scheduler_factory, max_sessions=max_sessions, session_ttl_s=session_ttl_s, vad=vad)
+    app.state.host = host
+    sample_rate = host.sample_rate
 
     def check_auth(authorization: Optional[str]):
         if auth_token and not hmac.compare_digest((authorization or "").encode(), f"Bearer {auth_token}".encode()):
             raise HTTPException(status_code=401, detail="invalid or missing bearer token")
 
-    def get_session(session_id: str):
-        with sessions_lock:
-            s = sessions.get(session_id)
-        if s is None:
-            raise HTTPException(status_code=404, detail=f"Session {session_id} not found")   # R:examples/server.py:86-89
-        return s
+    async def guarded(fn, *a):
+        """Run a host method in the thread pool and map its failures as the reference's server does (:86-89, :128-133)."""
+        try:
+            return await run_in_threadpool(fn, *a)
+        except KeyError as e:
+            raise HTTPException(status_code=404, detail=f"Session {e.args[0]} not found") from e
+        except (HostBusy, _queue.Full) as e:      # session table / request queue full, hub closed
+            raise HTTPException(status_code=503, detail=str(e) or "request queue full", headers={"Retry-After": "1"}) from e
+        except HTTPException:
+            raise
+        except Exception as e:  # noqa: BLE001
+            raise HTTPException(status_code=500, detail=str(e)) from e
 
     @app.post("/session/create/")
     async def session_create(authorization: Optional[str] = Header(default=None)):
         check_auth(authorization)
-        session_id = base64.urlsafe_b64encode(os.urandom(16)).decode("ascii")     # as R:examples/server.py:122
         try:
-            sched = make_scheduler(hub.stream_backend() if hub is not None else base_backend, base_backend.chunk_length_s)
+            return {"session_id": await run_in_threadpool(host.create)}
+        except HostBusy as e:
+            raise HTTPException(status_code=503, detail=str(e), headers={"Retry-After": "1"}) from e
         except RuntimeError as e:
             raise HTTPException(status_code=500, detail=f"Failed to initialize model: {e}") from e
-        with sessions_lock:
-            if len(sessions) >= max_sessions:
-                raise HTTPException(status_code=503, detail="too many sessions")
-            sessions[session_id] = {"scheduler": sched, "lock": threading.Lock()}
-        return {"session_id": session_id}
 
     @app.post("/session/{session_id}/end")
     async def session_end(session_id: str, authorization: Optional[str] = Header(default=None)):
         check_auth(authorization)
-        with sessions_lock:
-            sessions.pop(session_id, None)
+        await guarded(host.end, session_id)
         return {"status": "success"}
 
     @app.post("/session/{session_id}/add_chunk")
     async def session_add_chunk(session_id: str, audio_data: str, authorization: Optional[str] = Header(default=None)):
         """``audio_data``: base64 of float32 PCM, a query parameter exactly as in the reference (R:examples/server.py:135-144)."""
         check_auth(authorization)
-        s = get_session(session_id)
         try:
             audio_np = np.frombuffer(base64.b64decode(audio_data), dtype=np.float32)
-            with s["lock"]:
-                s["scheduler"].add_new_chunk(audio_np)
-            return {"status": "success"}
-        except HTTPException:
-            raise
         except Exception as e:  # noqa: BLE001
             raise HTTPException(status_code=500, detail=str(e)) from e
+        await guarded(host.add_chunk, session_id, audio_np)
+        return {"status": "success"}
 
     @app.post("/session/{session_id}/process")
     async def session_process(session_id: str, authorization: Optional[str] = Header(default=None)):
         check_auth(authorization)
-        s = get_session(session_id)
-
-        def work():
-            with s["lock"]:
-                return s["scheduler"].process_new_chunk()    # blocks in the hub while the shared batch is decoded
-
-        try:
-            words, uncommited_words = await run_in_threadpool(work)
-            return {"words": words, "uncommited_words": uncommited_words}   # key spelling as in the reference (:153)
-        except Exception as e:  # noqa: BLE001
-            raise HTTPException(status_code=500, detail=str(e)) from e
+        words, uncommited_words = await guarded(host.process, session_id)
+        return {"words": words, "uncommited_words": uncommited_words}   # key spelling as in the reference (:153)
 
     @app.post("/session/{session_id}/clear")
     async def session_clear(session_id: str, authorization: Optional[str] = Header(default=None)):
         check_auth(authorization)
-        s = get_session(session_id)
-        with s["lock"]:
-            if hasattr(s["scheduler"], "clear"):
-                s["scheduler"].clear()   # per-session state: clearing is safe here (the reference's shared pipeline leaves it commented out)
+        await guarded(host.clear, session_id)
         return {"status": "success"}
-
-    def transcribe(audio: np.ndarray, sr: int) -> List[Dict[str, Any]]:
-        if hub is not None:
-            return hub.submit(audio, 0.0, sr).result()
-        return backend.transcribe(audio, 0.0, sr)
 
     @app.post(path)
     async def post_transcribe(request: Request, authorization: Optional[str] = Header(default=None),
@@ -212,13 +330,13 @@ def create_app(backend: Union[BatchingHub, AMDWhisperBackend], auth_token: str =
             raise HTTPException(status_code=400, detail=f"expected {sample_rate} Hz audio, got {sr} Hz")
         if len(audio) == 0:
             return words_to_response([], model_name)
-        words = await run_in_threadpool(transcribe, audio, sr)   # blocks until the (shared) batch has been decoded
+        words = await guarded(host.transcribe, audio, sr)   # blocks until the (shared) passes have decoded it
         return words_to_response(words, model_name)
 
     @app.get("/health")
     async def health():
-        return {"status": "ready", "model": model_name, "batches": (len(hub.batches) if hub is not None else None),
-                "sessions": len(sessions)}
+        h = await run_in_threadpool(host.health)
+        return {"status": "ready", "model": model_name, "batches": h.get("passes"), **h}
 
     return app
 
@@ -232,14 +350,28 @@ def main(argv: Optional[List[str]] = None):  # pragma: no cover - needs weights 
     ap.add_argument("--model", required=True, help="HF checkpoint name or path (e.g. TheStageAI/thewhisper-large-v3)")
     ap.add_argument("--chunk-length-s", type=int, default=10)
     ap.add_argument("--max-batch", type=int, default=16)
+    ap.add_argument("--gpus", type=int, default=1, help="serving processes, one per MI355X (sessions sticky by index %% gpus; thewhisper_amd/node.py)")
+    ap.add_argument("--vad", action="store_true", help="gate sessions with the on-device energy VAD (the reference's default use_vad=True; vad.py)")
     ap.add_argument("--host", default="0.0.0.0")
     ap.add_argument("--port", type=int, default=8000)
     ap.add_argument("--auth-token", default="")
     ap.add_argument("--language", default="en")
     args = ap.parse_args(argv)
-    backend = AMDWhisperBackend(args.model, chunk_length_s=args.chunk_length_s, language=args.language, batch_size=args.max_batch)
-    hub = BatchingHub(backend, max_batch=args.max_batch)
-    uvicorn.run(create_app(hub, auth_token=args.auth_token, model_name=args.model, lang_id=args.language), host=args.host, port=args.port)
+    if args.gpus > 1:
+        from .node import NodeRouter
+
+        host = NodeRouter(args.gpus, "thewhisper_amd.node:default_host_factory",
+                          dict(model=args.model, chunk_length_s=args.chunk_length_s, max_batch=args.max_batch, language=args.language,
+                               use_vad=args.vad))
+    else:
+        backend = AMDWhisperBackend(args.model, chunk_length_s=args.chunk_length_s, language=args.language, batch_size=args.max_batch)
+        vad = None
+        if args.vad:
+            from .vad import VadService
+
+            vad = VadService(max_streams=1024)
+        host = SessionHost(BatchingHub(backend, max_batch=args.max_batch), vad=vad)
+    uvicorn.run(create_app(host, auth_token=args.auth_token, model_name=args.model, lang_id=args.language), host=args.host, port=args.port)
 
 
 if __name__ == "__main__":  # pragma: no cover

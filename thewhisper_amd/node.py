@@ -1,0 +1,233 @@
+"""Node-level front end: one serving process per MI355X, sessions sticky to a GPU (BASELINE config 4: 128 streaming
+sessions on the 8 GPUs of a node, 16 per GPU).
+
+Replaces the process layout of the reference's demo server (R:examples/server.py:22-115: ONE process, ONE shared
+pipeline, one request at a time).  Streams are independent and the model fits a GPU ninety times over, so the layout is
+SURVEY.md section 8e's: a full replica per GPU, ``session -> rank = session_index % world`` (``dist.shard_streams``; the
+per-session scheduler state and the session's place in the hub's passes stay local to that rank), no collective anywhere -
+the ranks never talk to each other.  The HTTP process (``gateway.create_app(NodeRouter(...))``) only routes:
+
+    front process (FastAPI)  --pipe-->  worker rank r  =  SessionHost(BatchingHub(AMDWhisperBackend on cuda:r))
+
+Each worker serves its pipe from a small thread pool so that the requests of its sessions meet in the hub's passes exactly
+as they do in the single-GPU gateway.  ``python -m thewhisper_amd.gateway --gpus N ...`` builds this.
+"""
+from __future__ import annotations
+
+import importlib
+import itertools
+import multiprocessing as mp
+import os
+import threading
+from concurrent.futures import Future, ThreadPoolExecutor
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+
+__all__ = ["NodeRouter", "worker_main"]
+
+
+def _resolve(spec: str):
+    mod, fn = spec.split(":")
+    return getattr(importlib.import_module(mod), fn)
+
+
+def worker_main(rank: int, world: int, conn, host_factory: str, factory_kwargs: Dict[str, Any], threads: int = 32):
+    """Entry point of one worker process.  ``host_factory`` = "module:function"; called as ``f(rank=, world=, **kwargs)`` it
+    returns the rank's ``gateway.SessionHost`` (building the backend on ITS GPU).  Protocol on ``conn``: requests
+    ``(req_id, op, args)``, replies ``(req_id, ok, payload)``; ``op`` = a ``SessionHost`` method name, or "stop"."""
+    os.environ["THEWHISPER_RANK"] = str(rank)
+    try:
+        host = _resolve(host_factory)(rank=rank, world=world, **factory_kwargs)
+        conn.send((0, True, {"rank": rank, "sample_rate": host.sample_rate}))
+    except BaseException as e:  # noqa: BLE001
+        conn.send((0, False, f"worker {rank} failed to start: {e!r}"))
+        return
+    send_lock = threading.Lock()
+
+    def reply(req_id, ok, payload):
+        with send_lock:
+            conn.send((req_id, ok, payload))
+
+    def serve(req_id, op, args):
+        try:
+            reply(req_id, True, getattr(host, op)(*args))
+        except BaseException as e:  # noqa: BLE001
+            reply(req_id, False, (type(e).__name__, e.args[0] if e.args else ""))
+
+    pool = ThreadPoolExecutor(max_workers=threads, thread_name_prefix=f"tw-rank{rank}")
+    while True:
+        try:
+            req_id, op, args = conn.recv()
+        except EOFError:
+            break
+        if op == "stop":
+            reply(req_id, True, None)
+            break
+        pool.submit(serve, req_id, op, args)
+    pool.shutdown(wait=False)
+    hub = getattr(host, "hub", None)
+    if hub is not None:
+        hub.close()
+
+
+class _Worker:
+    def __init__(self, ctx, rank: int, world: int, host_factory: str, factory_kwargs: Dict[str, Any]):
+        self.rank = rank
+        self.conn, child = ctx.Pipe()
+        self.proc = ctx.Process(target=worker_main, args=(rank, world, child, host_factory, factory_kwargs), daemon=True,
+                                name=f"thewhisper-rank{rank}")
+        self.proc.start()
+        child.close()
+        self.send_lock = threading.Lock()
+        self.pending: Dict[int, Future] = {}
+        self.pending_lock = threading.Lock()
+        self.hello: Future = Future()
+        self.reader = threading.Thread(target=self._read, name=f"tw-router-rank{rank}", daemon=True)
+        self.reader.start()
+
+    def _read(self):
+        while True:
+            try:
+                req_id, ok, payload = self.conn.recv()
+            except (EOFError, OSError):
+                err = RuntimeError(f"worker {self.rank} went away")
+                with self.pending_lock:
+                    futs, self.pending = list(self.pending.values()), {}
+                for f in futs:
+                    if not f.done():
+                        f.set_exception(err)
+                if not self.hello.done():
+                    self.hello.set_exception(err)
+                return
+            if req_id == 0:
+                (self.hello.set_result if ok else lambda m: self.hello.set_exception(RuntimeError(m)))(payload)
+                continue
+            with self.pending_lock:
+                fut = self.pending.pop(req_id, None)
+            if fut is None:
+                continue
+            if ok:
+                fut.set_result(payload)
+            else:
+                fut.set_exception(_rebuild_error(payload))
+
+
+def _rebuild_error(payload: Tuple[str, Any]) -> BaseException:
+    from .gateway import HostBusy
+
+    name, arg = payload
+    if name == "KeyError":
+        return KeyError(arg)
+    if name == "HostBusy":
+        return HostBusy(arg)
+    if name == "ValueError":
+        return ValueError(arg)
+    return RuntimeError(f"{name}: {arg}")
+
+
+class NodeRouter:
+    """The ``SessionHost`` interface over ``world`` worker processes (one per GPU).  Sessions are assigned round-robin at
+    creation (``index % world``, the rule of ``dist.shard_streams``) and never move; stateless ``transcribe`` requests are
+    spread round-robin."""
+
+    def __init__(self, world: int, host_factory: str, factory_kwargs: Optional[Dict[str, Any]] = None, start_timeout_s: float = 600.0):
+        if world < 1:
+            raise ValueError("world must be >= 1")
+        ctx = mp.get_context("spawn")      # a forked child would inherit the parent's HIP state
+        self.world = world
+        self.workers = [_Worker(ctx, r, world, host_factory, dict(factory_kwargs or {})) for r in range(world)]
+        hellos = [w.hello.result(timeout=start_timeout_s) for w in self.workers]
+        self.sample_rate = hellos[0]["sample_rate"]
+        self._ids = itertools.count(1)
+        self._id_lock = threading.Lock()
+        self._session_rank: Dict[str, int] = {}
+        self._created = 0
+        self._rr = 0
+        self._lock = threading.Lock()
+
+    # -- plumbing ------------------------------------------------------------------------------------
+    def call(self, rank: int, op: str, *args, timeout: Optional[float] = None):
+        w = self.workers[rank]
+        with self._id_lock:
+            req_id = next(self._ids)
+        fut: Future = Future()
+        with w.pending_lock:
+            w.pending[req_id] = fut
+        with w.send_lock:
+            w.conn.send((req_id, op, args))
+        return fut.result(timeout=timeout)
+
+    def rank_of(self, sid: str) -> int:
+        with self._lock:
+            r = self._session_rank.get(sid)
+        if r is None:
+            raise KeyError(sid)
+        return r
+
+    # -- SessionHost interface -------------------------------------------------------------------------
+    def create(self) -> str:
+        import base64
+
+        sid = base64.urlsafe_b64encode(os.urandom(16)).decode("ascii")
+        with self._lock:
+            rank = self._created % self.world          # dist.shard_streams: stream_id % world
+            self._created += 1
+        self.call(rank, "create", sid)
+        with self._lock:
+            self._session_rank[sid] = rank
+        return sid
+
+    def add_chunk(self, sid: str, audio_np: np.ndarray) -> None:
+        return self.call(self.rank_of(sid), "add_chunk", sid, np.ascontiguousarray(audio_np))
+
+    def process(self, sid: str):
+        return self.call(self.rank_of(sid), "process", sid)
+
+    def clear(self, sid: str) -> None:
+        return self.call(self.rank_of(sid), "clear", sid)
+
+    def end(self, sid: str) -> None:
+        with self._lock:
+            rank = self._session_rank.pop(sid, None)
+        if rank is not None:
+            self.call(rank, "end", sid)
+
+    def transcribe(self, audio: np.ndarray, sr: int):
+        with self._lock:
+            rank = self._rr % self.world
+            self._rr += 1
+        return self.call(rank, "transcribe", np.ascontiguousarray(audio), sr)
+
+    def health(self) -> Dict[str, Any]:
+        per = [self.call(r, "health", timeout=30) for r in range(self.world)]
+        return {"passes": sum(p["passes"] or 0 for p in per), "sessions": sum(p["sessions"] for p in per),
+                "ranks": per, "world": self.world}
+
+    def close(self):
+        for w in self.workers:
+            try:
+                self.call(w.rank, "stop", timeout=10)
+            except Exception:  # noqa: BLE001
+                pass
+        for w in self.workers:
+            w.proc.join(timeout=20)
+            if w.proc.is_alive():
+                w.proc.terminate()
+
+
+def default_host_factory(rank: int, world: int, model: str, chunk_length_s: int = 10, max_batch: int = 16, language: str = "en",
+                         use_vad: bool = False, **_):  # pragma: no cover - needs weights and GPUs
+    """What ``python -m thewhisper_amd.gateway --gpus N`` runs in every worker: the backend of GPU ``rank`` behind a hub."""
+    os.environ["THEWHISPER_DEVICE"] = f"cuda:{rank}"
+    from .gateway import SessionHost
+    from .serving import BatchingHub
+    from .streaming import AMDWhisperBackend
+
+    backend = AMDWhisperBackend(model, chunk_length_s=chunk_length_s, language=language, batch_size=max_batch)
+    vad = None
+    if use_vad:
+        from .vad import VadService
+
+        vad = VadService(max_streams=1024, device=rank)
+    return SessionHost(BatchingHub(backend, max_batch=max_batch), vad=vad)

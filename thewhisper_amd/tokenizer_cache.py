@@ -18,10 +18,19 @@ from __future__ import annotations
 _MEMO_MAX = 1 << 18
 
 
+def _frozen(v):
+    # list-valued table entries are COPIED into the key (a list mutated in place would otherwise compare equal to itself)
+    return tuple(_frozen(x) for x in v) if isinstance(v, (list, tuple)) else v
+
+
 def _key(tok):
-    # the table entries themselves (compared by value; the tuple keeps them alive, so a replaced entry can never be mistaken
-    # for its predecessor): replacing or adding a special token -> new key -> the caches are rebuilt
-    return (len(tok._extra_special_tokens), tuple(tok._special_tokens_map.values()))
+    # everything a cached value depends on, by value: the special-token tables (replacing, adding or mutating an entry -> new
+    # key -> the caches are rebuilt), a counter the cached subclass bumps whenever tokens are added through the tokenizer's API
+    # (add_tokens() with ordinary tokens changes decode results too; asking the Rust tokenizer for its vocabulary size costs
+    # 6 ms per call - 250 x the memoised decode - so the mutation is caught where it happens instead) and the one decode option
+    # that is read from the tokenizer instead of the call
+    return (len(tok._extra_special_tokens), _frozen(list(tok._extra_special_tokens)), _frozen(list(tok._special_tokens_map.values())),
+            tok.__dict__.get("_tw_vocab_version", 0), getattr(tok, "clean_up_tokenization_spaces", None))
 
 
 def cache_special_ids(tokenizer):
@@ -74,8 +83,15 @@ def cache_special_ids(tokenizer):
                 memo[1][mk] = text
         return text
 
-    cached = type(cls.__name__, (cls,), {"all_special_ids": property(all_special_ids), "decode": decode,
-                                         "_tw_special_id_cache": True})
+    members = {"all_special_ids": property(all_special_ids), "decode": decode, "_tw_special_id_cache": True}
+    base_add = getattr(cls, "_add_tokens", None)
+    if base_add is not None:
+        def _add_tokens(self, *a, **k):   # add_tokens() and add_special_tokens() both end here: new vocabulary -> new cache key
+            self.__dict__["_tw_vocab_version"] = self.__dict__.get("_tw_vocab_version", 0) + 1
+            return base_add(self, *a, **k)
+
+        members["_add_tokens"] = _add_tokens
+    cached = type(cls.__name__, (cls,), members)
     try:
         tokenizer.__class__ = cached
     except TypeError:   # exotic tokenizer classes that cannot be re-classed keep HF's behaviour
