@@ -535,12 +535,16 @@ def main(argv=None):
     if rank == 0 and args.latency_iters > 0 and not stub:
         for _ in range(min(10, args.latency_iters)):   # warm-ups
             step(1)
+        tick = {"logmel_ms": 0.0, "encode_ms": 0.0, "cross_kv_ms": 0.0, "greedy_ms": 0.0, "token_timestamps_ms": 0.0}
         for _ in range(args.latency_iters):
             torch.cuda.synchronize()
             a = time.perf_counter()
             step(1)
             torch.cuda.synchronize()
             lat.append((time.perf_counter() - a) * 1e3)
+            tm = eng.last_timings()
+            for k in tick:
+                tick[k] += tm[k] / args.latency_iters
 
     if rank == 0:
         esz = 4 if args.dtype == "f32" else 2
@@ -596,6 +600,15 @@ def main(argv=None):
             lat.sort()
             result["p50_chunk_latency_ms"] = round(lat[len(lat) // 2], 2)
             result["p90_chunk_latency_ms"] = round(lat[min(len(lat) - 1, (len(lat) * 9) // 10)], 2)
+            # SURVEY.md section 8f-3 (incremental streaming = reuse work between the 0.5 s ticks of one stream's rolling buffer): what a
+            # tick costs, stage by stage.  Re-encoding the whole buffer - what an approximate encoder reuse could save, at the price
+            # of different results - is the encode + cross-K/V share; the rest is the autoregressive loop over up to 128 tokens.
+            enc_share = (tick["logmel_ms"] + tick["encode_ms"] + tick["cross_kv_ms"]) / max(1e-9, sum(tick.values()))
+            result["streaming_tick_breakdown"] = {**{k: round(v, 3) for k, v in tick.items()},
+                                                  "encoder_side_share": round(enc_share, 4),
+                                                  "note": "one stream, one tick = one backend call on the rolling buffer (engine level); "
+                                                          "8f-3 closed on this number: encoder reuse could remove at most encoder_side_share "
+                                                          "of a tick while changing results (non-causal encoder), DESIGN.md section 7"}
             result["chunk_latency_note"] = (f"raw engine, 1 stream, {args.chunk_s} s chunk resident in HBM, {args.new_tokens} tokens + DTW, "
                                             f"{len(lat)} calls; the API-level latency is pipeline.backend_transcribe_p50_ms")
         if world == 1 and not stub and not args.no_pipeline_leg:

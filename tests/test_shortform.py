@@ -55,7 +55,7 @@ def clip_features(pipe, n_clips, chunk_s, seed0=0):
 
 
 @pytest.mark.parametrize("mode", ["word", "segments", "none"])
-@pytest.mark.parametrize("seed", [0, 1, 2])
+@pytest.mark.parametrize("seed", [0, 1])
 def test_generate_equals_hf_control_flow(mode, seed):
     pipe = build(seed=seed, chunk_s=30)     # 30 s chunks: the random-weight model's timestamps leave room for a second seek pass
     model = pipe.model
