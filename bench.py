@@ -631,6 +631,17 @@ def main(argv=None):
                 except Exception as e:  # noqa: BLE001
                     legs.append({"config": label, "error": repr(e)})
             result["other_configs"] = legs
+            try:   # the reference's own headline unit (RTFx of the turbo engines), its definitions, this backend's pipeline
+                sys.path.insert(0, os.path.join(ROOT, "benchmark"))
+                import run_rtfx
+
+                r = run_rtfx.measure("large-v3-turbo", minutes=4.0, batch_sizes=(1, 32), device_index=local)
+                result["rtfx"] = {"definition": "audio seconds / wall seconds of ASRPipeline(audio, batch_size=bs) on one long clip "
+                                                "(R:benchmark/eval_utils.py:149-154); TTFT = inference start -> first token",
+                                  "model": r["model"], "audio_s": r["audio_s"], "forced_new_tokens_per_30s_window": r["forced_new_tokens_per_window"],
+                                  "runs": r["runs"]}
+            except Exception as e:  # noqa: BLE001
+                result["rtfx"] = {"error": repr(e)}
         if world == 1 and not stub and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(args.model, args.chunk_s, args.cpu_tokens, args.cpu_calls)

@@ -30,43 +30,37 @@ from thewhisper_amd import ASRPipeline, synthetic  # noqa: E402
 from thewhisper_amd.engine import WhisperEngine  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--model", default="large-v3-turbo")
-    ap.add_argument("--minutes", type=float, default=10.0)
-    ap.add_argument("--batch-sizes", default="1,32")
-    ap.add_argument("--chunk-s", type=int, default=30)
-    ap.add_argument("--tokens", type=int, default=100)
-    ap.add_argument("--dtype", default="bf16")
-    args = ap.parse_args()
+def measure(model_name="large-v3-turbo", minutes=10.0, batch_sizes=(1, 32), chunk_s=30, tokens=100, dtype="bf16", device_index=0):
+    """The reference's RTFx / TTFT definitions on this backend's ASRPipeline (module docstring); returns the result dict."""
     if not torch.cuda.is_available():
-        raise SystemExit("needs an MI355X")
-    dims = synthetic.DIMS[args.model]
-    dev = torch.device("cuda", 0)
+        raise RuntimeError("needs an MI355X")
+    dims = synthetic.DIMS[model_name]
+    dev = torch.device("cuda", device_index)
     heads = [tuple(h) for h in synthetic.default_alignment_heads(dims["dec_layers"], dims["heads"])]
     rng = np.random.default_rng(0)
-    audio = (rng.standard_normal(int(args.minutes * 60 * 16000)) * 0.1).clip(-1, 1).astype(np.float32)
-    res = {"metric": "RTFx (audio s / wall s) and TTFT, reference definitions", "model": args.model, "audio_s": len(audio) / 16000,
-           "chunk_s": args.chunk_s, "forced_new_tokens_per_window": args.tokens, "dtype": args.dtype,
+    audio = (rng.standard_normal(int(minutes * 60 * 16000)) * 0.1).clip(-1, 1).astype(np.float32)
+    res = {"metric": "RTFx (audio s / wall s) and TTFT, reference definitions", "model": model_name, "audio_s": len(audio) / 16000,
+           "chunk_s": chunk_s, "forced_new_tokens_per_window": tokens, "dtype": dtype,
            "data": "synthetic gaussian audio, random-init weights", "runs": []}
     sd = synthetic.random_state_dict(dims, dev, 0)
-    for bs in [int(x) for x in args.batch_sizes.split(",")]:
-        eng = WhisperEngine(dims, 50 * args.chunk_s, max_batch=bs, dtype=args.dtype, alignment_heads=heads)
+    for bs in [int(x) for x in batch_sizes]:
+        eng = WhisperEngine(dims, 50 * chunk_s, max_batch=bs, dtype=dtype, alignment_heads=heads, device=device_index)
         eng.load_state_dict(sd)
-        model = synthetic.skeleton_model(dims, device="cuda:0", dtype=torch.bfloat16, alignment_heads=heads)
-        pipe = ASRPipeline(model, feature_extractor=WhisperFeatureExtractor(feature_size=dims["n_mels"], chunk_length=args.chunk_s),
-                           tokenizer=synthetic.build_tokenizer(dims["vocab"]), chunk_length_s=args.chunk_s, device="cuda:0",
+        model = synthetic.skeleton_model(dims, device=f"cuda:{device_index}", dtype=torch.bfloat16, alignment_heads=heads)
+        pipe = ASRPipeline(model, feature_extractor=WhisperFeatureExtractor(feature_size=dims["n_mels"], chunk_length=chunk_s),
+                           tokenizer=synthetic.build_tokenizer(dims["vocab"]), chunk_length_s=chunk_s, device=f"cuda:{device_index}",
                            torch_dtype=torch.bfloat16, batch_size=bs, engine=eng)
-        gk = {"num_beams": 1, "do_sample": False, "use_cache": True, "language": "en", "max_new_tokens": args.tokens,
-              "min_new_tokens": args.tokens}
-        pipe(audio[: 16000 * args.chunk_s * min(bs, 2)].copy(), batch_size=bs, generate_kwargs=dict(gk))   # warm-up (graph capture)
+        gk = {"num_beams": 1, "do_sample": False, "use_cache": True, "language": "en", "max_new_tokens": tokens,
+              "min_new_tokens": tokens}
+        for _ in range(2):   # warm-up: graph capture, and the second call runs the learned short-form plan (model.py)
+            pipe(audio[: 16000 * chunk_s * min(bs, 2)].copy(), batch_size=bs, generate_kwargs=dict(gk))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         out = pipe(audio.copy(), batch_size=bs, generate_kwargs=dict(gk))
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         # TTFT at this batch size: log-mel + encoder + cross-K/V + the first decode step for one batch of windows
-        pcm = torch.from_numpy(audio[: 16000 * args.chunk_s]).to(dev).repeat(bs, 1)
+        pcm = torch.from_numpy(audio[: 16000 * chunk_s]).to(dev).repeat(bs, 1)
         prompt = np.tile(np.array([[50258, 50259, 50360, 50364]], dtype=np.int32), (bs, 1))
         ttft = []
         for _ in range(5):
@@ -81,7 +75,22 @@ def main():
         eng.close()
         del eng, pipe, model
         torch.cuda.empty_cache()
-    print(json.dumps(res), flush=True)
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="large-v3-turbo")
+    ap.add_argument("--minutes", type=float, default=10.0)
+    ap.add_argument("--batch-sizes", default="1,32")
+    ap.add_argument("--chunk-s", type=int, default=30)
+    ap.add_argument("--tokens", type=int, default=100)
+    ap.add_argument("--dtype", default="bf16")
+    args = ap.parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit("needs an MI355X")
+    print(json.dumps(measure(args.model, args.minutes, [int(x) for x in args.batch_sizes.split(",")], args.chunk_s, args.tokens,
+                             args.dtype)), flush=True)
 
 
 if __name__ == "__main__":

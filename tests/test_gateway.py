@@ -183,3 +183,35 @@ def test_session_routes_mirror_the_reference_server(served):
     assert client.post("/session/nope/add_chunk", params={"audio_data": ""}, headers=H).status_code == 404
     client.post(f"/session/{sids[1]}/end", headers=H)
     assert client.get("/health").json()["sessions"] == 0
+
+
+def test_websocket_session_streams_chunks_and_answers_like_the_process_route():
+    from fastapi.testclient import TestClient
+
+    from tests.node_factory import TinyScheduler
+    from thewhisper_amd import AMDWhisperBackend
+    from thewhisper_amd.gateway import create_app
+    from thewhisper_amd.serving import BatchingHub
+
+    pipe = build_amd_pipeline("micro", 10, 2)
+    backend = AMDWhisperBackend(None, chunk_length_s=10, asr_pipeline=pipe)
+    hub = BatchingHub(backend, max_batch=2, max_wait_s=0.05)
+    app = create_app(hub, auth_token="tok", scheduler_factory=TinyScheduler)
+    client = TestClient(app)
+    clip = wo.synth_audio(32000, 9, "speechlike")
+    with client.websocket_connect("/ws/stream?token=tok") as ws:
+        replies = []
+        for i in range(0, len(clip), 8000):
+            ws.send_bytes(clip[i : i + 8000].astype(np.float32).tobytes())
+            replies.append(ws.receive_json())
+        assert client.get("/health").json()["sessions"] == 1
+        ws.send_text("clear")
+        assert ws.receive_json() == {"status": "success"}
+        ws.send_text("end")
+    assert normalise(replies[-1]["uncommited_words"]) == normalise(backend.transcribe(clip, 0.0, 16000))
+    assert normalise(replies[0]["uncommited_words"]) == normalise(backend.transcribe(clip[:8000], 0.0, 16000))   # one reply per chunk
+    assert client.get("/health").json()["sessions"] == 0                 # closing ended the session
+    with pytest.raises(Exception):
+        with client.websocket_connect("/ws/stream?token=wrong"):
+            pass
+    hub.close()

@@ -103,3 +103,31 @@ def test_thestage_speechkit_amd_package_as_shipped():
     feats = pipe.feature_extractor(audio[:160000], sampling_rate=16000, return_tensors="pt", return_attention_mask=True)
     assert feats["input_features"].is_cuda and feats["input_features"].shape == (1, dims.n_mels, 1000)
     assert isinstance(pipe.feature_extractor(audio[:160000], sampling_rate=16000, return_tensors="np")["input_features"], np.ndarray)
+
+
+def test_eval_harness_drives_the_gpu_pipeline():
+    """the eval port (benchmark/eval_utils.py, the metric definitions of R:benchmark/eval_utils.py:112-154) through
+    thewhisper_amd.ASRPipeline on the MI355X, called exactly as benchmark/run_evaluation.py calls it.  No transcribed corpus
+    exists offline, so the references are built from the pipeline's own output: identical text -> WER = CER = 0; one word
+    dropped from every reference -> the corpus WER that edit implies; RTFx = audio seconds / generation wall seconds."""
+    sys.path.insert(0, os.path.join(ROOT, "benchmark"))
+    try:
+        from eval_utils import evaluate_dataset, get_normalizer, mean_over_tasks
+    finally:
+        sys.path.pop(0)
+    from tests.test_pipeline_glue import build_amd_pipeline
+
+    pipe = build_amd_pipeline("micro", 10, 4, device="cuda", engine_factory=None)
+    audio = [wo.synth_audio(16000 * (4 + k), 70 + k, ["speechlike", "noise"][k % 2]) for k in range(6)]
+    gk = {"num_beams": 1, "task": "transcribe", "do_sample": False, "max_new_tokens": 24}
+    gen = lambda x, generate_kwargs: pipe(x, generate_kwargs=generate_kwargs, batch_size=4)  # noqa: E731  (run_evaluation.py:62)
+    texts = [o["text"] for o in pipe([a.copy() for a in audio], generate_kwargs={**gk, "language": "en"}, batch_size=4)]
+    norm = get_normalizer("en")
+    assert all(len(norm(t).split()) >= 2 for t in texts), texts
+    exact = evaluate_dataset(gen, [a.copy() for a in audio], texts, language="en", generate_kwargs=gk, batch_size=4)
+    assert exact["wer"] == 0.0 and exact["cer"] == 0.0
+    assert exact["rtfx"] > 1.0 and abs(exact["dataset_duration_hours"] * 3600 - sum(len(a) for a in audio) / 16000) < 1e-6
+    refs = [" ".join(norm(t).split()[1:]) for t in texts]        # the hypothesis now has one inserted word per utterance
+    ins = evaluate_dataset(gen, [a.copy() for a in audio], refs, language="en", generate_kwargs=gk, batch_size=4)
+    assert abs(ins["wer"] - len(refs) / sum(len(r.split()) for r in refs)) < 1e-12
+    assert mean_over_tasks({"a": exact, "b": ins})["wer"] == ins["wer"] / 2

@@ -244,7 +244,7 @@ def create_app(backend, auth_token: str = "", model_name: str = "", lang_id: Opt
     import base64
     import queue as _queue
 
-    from fastapi import FastAPI, Header, HTTPException, Request
+    from fastapi import FastAPI, Header, HTTPException, Request, WebSocket
     from fastapi.concurrency import run_in_threadpool
 
     app = FastAPI(title="thewhisper-amd gateway")
@@ -332,6 +332,49 @@ def create_app(backend, auth_token: str = "", model_name: str = "", lang_id: Opt
             return words_to_response([], model_name)
         words = await guarded(host.transcribe, audio, sr)   # blocks until the (shared) passes have decoded it
         return words_to_response(words, model_name)
+
+    @app.websocket("/ws/stream")
+    async def ws_stream(ws: WebSocket):
+        """One streaming session over a WebSocket (SURVEY.md section 8f rank 1 names the surface; the reference's server imports
+        ``WebSocket`` without using it, R:examples/server.py:1).  Binary message = float32 PCM chunk at 16 kHz: it is added to
+        the session (``add_chunk``) and processed (``process``); every message is answered with the JSON of the ``/process``
+        route.  Text message "clear" / "end" as the routes.  ``?token=`` carries the bearer token.  Closing ends the session."""
+        if auth_token and not hmac.compare_digest((ws.query_params.get("token") or "").encode(), auth_token.encode()):
+            await ws.close(code=4401)
+            return
+        await ws.accept()
+        try:
+            sid = await run_in_threadpool(host.create)
+        except Exception as e:  # noqa: BLE001
+            await ws.send_json({"error": str(e)})
+            await ws.close(code=1013)
+            return
+        try:
+            while True:
+                msg = await ws.receive()
+                if msg["type"] == "websocket.disconnect":
+                    break
+                if msg.get("bytes") is not None:
+                    audio_np = np.frombuffer(msg["bytes"], dtype=np.float32)
+                    await run_in_threadpool(host.add_chunk, sid, audio_np)
+                    words, uncommited_words = await run_in_threadpool(host.process, sid)
+                    await ws.send_json({"words": words, "uncommited_words": uncommited_words})
+                elif msg.get("text") == "clear":
+                    await run_in_threadpool(host.clear, sid)
+                    await ws.send_json({"status": "success"})
+                elif msg.get("text") == "end":
+                    break
+        except Exception as e:  # noqa: BLE001
+            try:
+                await ws.send_json({"error": str(e)})
+            except Exception:  # noqa: BLE001
+                pass
+        finally:
+            await run_in_threadpool(host.end, sid)
+            try:
+                await ws.close()
+            except Exception:  # noqa: BLE001
+                pass
 
     @app.get("/health")
     async def health():
