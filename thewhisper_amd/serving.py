@@ -58,6 +58,7 @@ class BatchingHub:
         self.passes = 0
         self.latencies: "collections.deque[float]" = collections.deque(maxlen=4096)  # submit -> answer, seconds
         self._codec = None
+        self._carry = None
         if continuous and hasattr(backend, "job_codec"):
             self._codec = backend.job_codec()
         self._post_q: "queue.Queue" = queue.Queue()
@@ -125,6 +126,12 @@ class BatchingHub:
         except Exception:  # noqa: BLE001
             pass
         if self._codec is not None:
+            # the plan is learned when the FIRST request arrives, not in the constructor: until then this thread does not touch
+            # the engine (whoever built the hub may still be using the backend directly, and a context is not thread-safe)
+            first = self._q.get()
+            if first is None:
+                return
+            self._carry = first
             try:
                 ok = self._codec.learn()
             except Exception:  # noqa: BLE001  (the warm-up request failed: serve whole-call batches, errors surface per request)
@@ -134,6 +141,15 @@ class BatchingHub:
                 return
             self._codec = None
         self._run_classic()
+
+    def _take(self, block: bool = True, timeout: Optional[float] = None):
+        """Next parked request: the one taken off the queue before the plan was learned first, then the queue."""
+        if self._carry is not None:
+            item, self._carry = self._carry, None
+            return item
+        if not block:
+            return self._q.get_nowait()
+        return self._q.get(timeout=timeout)
 
     # .. continuous: the unit is one seek pass of one chunk ..........................................
     def _run_continuous(self):
@@ -151,11 +167,11 @@ class BatchingHub:
             while not stop:
                 try:
                     if not jobs:
-                        item = self._q.get()
+                        item = self._take()
                     elif ready < self.max_batch:
-                        item = self._q.get(timeout=max(0.0, deadline - time.monotonic()))
+                        item = self._take(timeout=max(0.0, deadline - time.monotonic()))
                     else:
-                        item = self._q.get_nowait()
+                        item = self._take(block=False)
                 except queue.Empty:
                     break
                 if item is None:
@@ -214,7 +230,7 @@ class BatchingHub:
     # .. classic: the unit is one pipeline call over a batch of requests .............................
     def _run_classic(self):
         while True:
-            item = self._q.get()
+            item = self._take()
             if item is None:
                 return
             batch = [item]
