@@ -496,13 +496,24 @@ def main(argv=None):
         e.cross_kv(pc.shape[0])
         return mel                # kept alive until the batch is decoded: the launches above are still reading it
 
+    host = {"greedy_call_ms": 0.0, "timestamps_call_ms": 0.0, "timings_call_ms": 0.0, "calls": 0}
+
     def decode_stage(e, pc, _enc):
         nb = pc.shape[0]
+        t_a = time.perf_counter()
         out = e.generate_greedy(prompt[:nb], max_new_tokens=args.new_tokens, min_new_tokens=args.new_tokens,
                                 timestamps=True, want_alignment=True)
+        t_b = time.perf_counter()
         L = out["length"]
         e.token_timestamps(nb, n_prompt, L, [2 * T] * nb)
-        return (L - n_prompt) * nb, e.last_timings()
+        t_c = time.perf_counter()
+        tm = e.last_timings()
+        t_d = time.perf_counter()
+        host["greedy_call_ms"] += (t_b - t_a) * 1e3
+        host["timestamps_call_ms"] += (t_c - t_b) * 1e3
+        host["timings_call_ms"] += (t_d - t_c) * 1e3
+        host["calls"] += 1
+        return (L - n_prompt) * nb, tm
 
     def run_steps(n):
         """n passes of the hot path over one batch each; with the overlap the encoder stage of pass i+1 runs on its own CUs
@@ -518,6 +529,7 @@ def main(argv=None):
     if args.warmup > 0:  # with the overlap at least two passes, so that both contexts capture their step graph untimed
         run_steps(max(args.warmup, 2) if overlap is not None else args.warmup)
     rep.barrier()                          # dist.barrier() + torch.cuda.synchronize()
+    host.update(greedy_call_ms=0.0, timestamps_call_ms=0.0, timings_call_ms=0.0, calls=0)
     t0 = time.perf_counter()
     for ntok, tm in run_steps(args.steps):
         new_tok += ntok
@@ -581,6 +593,9 @@ def main(argv=None):
             "per_rank_tok_per_s": [round(x, 1) for x in per_rank],
             "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage.items()},
             "decode_tok_per_s": round(B * args.new_tokens / (greedy_ms * 1e-3), 1) if greedy_ms > 0 else None,
+            # wall time of the host calls per step, beside the HIP-event time of the loop inside tw_generate_greedy (greedy_ms):
+            # what ms_per_step holds besides the decode loop (call set-up / tear-down, DTW call, pipeline fill of the first batch)
+            "host_call_ms_per_step": {k: round(v / max(1, host["calls"]), 3) for k, v in host.items() if k != "calls"},
             "roofline": {
                 "kernel": "decode step (the captured graph replays two at a time; weight-streaming projections + single-query attention "
                           "over the K/V caches + sampler); averaged over all steps of a greedy call",
