@@ -207,3 +207,42 @@ def test_hub_falls_back_to_whole_call_batches_when_the_call_is_not_eligible():
     assert normalise(f1.result(300)) == normalise(want) == normalise(f2.result(300))
     assert hub._codec is None and hub.passes == 0
     hub.close()
+
+
+def test_continuous_hub_isolates_bad_requests_and_survives_an_engine_fault():
+    from thewhisper_amd import AMDWhisperBackend
+    from thewhisper_amd.serving import BatchingHub
+
+    pipe = build_amd_pipeline("micro", 10, 2)
+    backend = AMDWhisperBackend(None, chunk_length_s=10, asr_pipeline=pipe)
+    good = wo.synth_audio(48000, 4, "speechlike")
+    want = backend.transcribe(good.copy(), 0.0, 16000)
+    hub = BatchingHub(backend, max_batch=2, max_wait_s=0.2)
+    # a malformed buffer (not audio at all) fails its own future; its neighbour is served
+    f_bad = hub.submit(np.array(["not audio"]), 0.0, 16000)
+    f_ok = hub.submit(good.copy(), 0.0, 16000)
+    assert normalise(f_ok.result(300)) == normalise(want)
+    with pytest.raises(Exception):
+        f_bad.result(300)
+    assert hub._codec is not None and hub.passes >= 1
+    # an engine fault fails exactly the requests that had a chunk in that pass; the hub keeps serving
+    eng = pipe.model.engine
+    inner, state = eng.generate_greedy, {"n": 0}
+
+    def flaky(prompt, **kw):
+        state["n"] += 1
+        if state["n"] == 1:
+            raise RuntimeError("injected device fault")
+        return inner(prompt, **kw)
+
+    eng.generate_greedy = flaky
+    try:
+        f1, f2 = hub.submit(good.copy(), 0.0, 16000), hub.submit(good.copy(), 1.0, 16000)
+        for f in (f1, f2):
+            with pytest.raises(RuntimeError, match="injected device fault"):
+                f.result(300)
+        f3 = hub.submit(good.copy(), 0.0, 16000)
+        assert normalise(f3.result(300)) == normalise(want)
+    finally:
+        eng.generate_greedy = inner
+        hub.close()
