@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round profile on the GPU box (run through gpurun from the repo root):  bash tools/profile_round.sh r02 [quick]
-# Produces in gpurun_out/: bench lines (default, fp8 15 s, turbo 30 s B=1, 30 s B=8), rocprofv3 kernel stats + per-shape split
+# Produces in gpurun_out/: bench lines (default with every BASELINE config as a leg, turbo 30 s B=1 with overlap), rocprofv3 kernel stats + per-shape split
 # of the default bench, PMC passes (FETCH_SIZE, WRITE_SIZE -> HBM bytes per decode step; MFMA busy of the encoder kernels;
 # each in its own --pmc + --kernel-trace pass).  Raw traces stay in /tmp.
 set -u
@@ -10,20 +10,18 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python $ROOT/bench.py > $OUT/${R}_bench_default.json 2> $OUT/${R}_bench_default.err
+# the default line carries every BASELINE configuration since round 3 (other_configs: turbo 30 s x 1, fp8 / bf16 15 s x 16; rtfx)
+python $ROOT/bench.py --steps 20 > $OUT/${R}_bench_default.json 2> $OUT/${R}_bench_default.err
 if [ -z "$QUICK" ]; then
-python $ROOT/bench.py --dtype fp8 --chunk-s 15 --no-cpu-baseline --no-pipeline-leg --latency-iters 30 > $OUT/${R}_bench_fp8_15s.json 2>/dev/null
-python $ROOT/bench.py --chunk-s 15 --no-cpu-baseline --no-pipeline-leg --latency-iters 30 > $OUT/${R}_bench_bf16_15s.json 2>/dev/null
-python $ROOT/bench.py --model large-v3-turbo --chunk-s 30 --streams 1 --no-cpu-baseline --latency-iters 30 > $OUT/${R}_bench_turbo_30s_b1.json 2>/dev/null
-python $ROOT/bench.py --chunk-s 30 --streams 8 --no-cpu-baseline --no-pipeline-leg --latency-iters 0 > $OUT/${R}_bench_30s_b8.json 2>/dev/null
+python $ROOT/bench.py --model large-v3-turbo --chunk-s 30 --streams 1 --no-cpu-baseline --no-secondary --latency-iters 30 > $OUT/${R}_bench_turbo_30s_b1.json 2>/dev/null
 fi
 rm -rf /tmp/prof_stats
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o p -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline-leg --latency-iters 3 > $OUT/${R}_bench_profiled_run.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o p -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline-leg --no-secondary --latency-iters 0 > $OUT/${R}_bench_profiled_run.json 2>/dev/null
 f=$(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1)
 t=$(find /tmp/prof_stats -name "*kernel_trace.csv" | head -1)
 cp $f $OUT/${R}_large-v3_b16_kernel_stats.csv
 (cd $ROOT && python tools/summarize_rocprof.py $f > $OUT/${R}_kernel_table.md; python tools/trace_by_shape.py $t 30 > $OUT/${R}_large-v3_b16_by_shape.txt)
-PMCARGS="--steps 1 --warmup 0 --no-graph --encoder-cus 0 --no-cpu-baseline --no-pipeline-leg --latency-iters 0"
+PMCARGS="--steps 1 --warmup 0 --no-graph --encoder-cus 0 --no-cpu-baseline --no-pipeline-leg --no-secondary --latency-iters 0"
 for C in FETCH_SIZE WRITE_SIZE; do
   d=/tmp/prof_$C; rm -rf $d
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $d -o p -- python $ROOT/bench.py $PMCARGS > /dev/null 2>&1
@@ -38,3 +36,5 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output
 c=$(find $d -name "*counter_collection.csv" | head -1)
 (cd $ROOT && python tools/pmc_mfma_busy.py $c > $OUT/${R}_large-v3_b16_pmc_mfma_busy.txt 2>> $OUT/${R}_pmc_mfma.err)
 ls -la $OUT | tail -20
+# the floors the projection launches are compared with (same box): a launch that only streams the same bytes
+if [ -x $ROOT/tools/dbg/stream_floor ]; then $ROOT/tools/dbg/stream_floor > $OUT/${R}_stream_floor.txt 2>&1; fi
