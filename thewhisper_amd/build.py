@@ -29,9 +29,9 @@ def _hipcc() -> str:
 
 def _digest(paths: List[str]) -> str:
     h = hashlib.sha256()
-    for p in sorted(paths):
+    for p in sorted(paths, key=os.path.basename):
         with open(p, "rb") as f:
-            h.update(p.encode())
+            h.update(os.path.basename(p).encode())   # names, not paths: the digest must be the same wherever the tree is checked out
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()
