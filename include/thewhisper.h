@@ -133,6 +133,14 @@ int tw_encode(tw_ctx* ctx, const void* mel_dev, int32_t mel_dtype, int32_t B, vo
  * 0..B-1 into the per-layer cross K/V arenas, once per chunk. */
 int tw_cross_kv(tw_ctx* ctx, int32_t B, void* stream);
 
+/* The same two stages for slots slot0 .. slot0+B-1 of the context, leaving the other slots as they are: a serving pass is
+ * then assembled from several groups of chunks (the ones that need a further Whisper seek iteration first, late arrivals
+ * while those are being encoded), and ONE tw_generate_greedy runs over all of them.  There is no reference counterpart
+ * (HF's generate() encodes a fixed batch, HF:models/whisper/generation_whisper.py:785-903); results per slot are
+ * independent of the grouping.  tw_encode / tw_cross_kv are the slot0 = 0 forms and reset the number of filled slots. */
+int tw_encode_at(tw_ctx* ctx, const void* mel_dev, int32_t mel_dtype, int32_t B, int32_t slot0, void* stream);
+int tw_cross_kv_at(tw_ctx* ctx, int32_t B, int32_t slot0, void* stream);
+
 /* A6-A8.  Replaces: WhisperDecoder.forward + proj_out for ONE new token per stream
  * (HF:models/whisper/modeling_whisper.py:649-795, :1080).  tw_decoder_reset rewinds the self-attention
  * cache to position 0.  ids_host: int32 [B].  logits_dev: float32 [B, vocab] or NULL. */

@@ -40,16 +40,21 @@ class OracleEngine:
             x = np.stack([np.where(np.arange(x.shape[1]) < nv, x[i], 0) for i, nv in enumerate(n_valid)])
         return torch.from_numpy(wo.log_mel(x, self.n_mels, n_samples))
 
-    def encode(self, mel: torch.Tensor, return_hidden=False, hidden_dtype=torch.float32):
+    def encode(self, mel: torch.Tensor, return_hidden=False, hidden_dtype=torch.float32, slot0=0):
         self.calls["encode"] += 1
         m = mel.detach().float().cpu().numpy()
         if m.shape[1:] != (self.n_mels, 2 * self.T):
             raise ValueError(f"Whisper expects the mel input features to be of length {2 * self.T}, but found {m.shape[-1]}")
-        self._enc = self.model.encode(m)
+        enc = self.model.encode(m)
+        if slot0:      # tw_encode_at: the slots before slot0 keep what this pass put there
+            assert slot0 <= self._enc.shape[0] and slot0 + enc.shape[0] <= self.max_batch
+            self._enc = np.concatenate([self._enc[:slot0], enc], axis=0)
+        else:
+            self._enc = enc
         return torch.from_numpy(self._enc) if return_hidden else None
 
-    def cross_kv(self, B: int):
-        assert self._enc.shape[0] >= B
+    def cross_kv(self, B: int, slot0=0):
+        assert self._enc.shape[0] >= slot0 + B
 
     def decoder_reset(self, B: int):
         self._cache = self.model.new_cache(self._enc[:B])

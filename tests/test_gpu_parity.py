@@ -504,3 +504,46 @@ def test_encoder_overlap_gives_the_sequential_results():
     assert not np.array_equal(seq[0][0], seq[1][0])          # the two kinds of batch do differ
     for e in engs:
         e.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "fp8"])
+def test_slots_filled_in_groups_give_the_one_group_results(dtype):
+    """tw_encode_at / tw_cross_kv_at (a serving pass assembled from a group of chunks that need a further seek iteration plus
+    late arrivals): per slot the encoder output, the greedy ids and the token timestamps are bit-identical to encoding all
+    clips in one call - in every context dtype (fp8: the e4m3 cross-K/V arenas and their scale bytes take the slot offset too)."""
+    dims = dims_variant("micro", enc_layers=2, dec_layers=2)
+    w = wo.make_weights(dims, 3)
+    heads = [(1, 0), (1, 1)]
+    T, B = 100, 5
+    eng = make_engine(dims, w, T=T, max_batch=8, dtype=dtype, heads=heads, use_graph=True)
+    try:
+        pcm = clips(32000, ["speechlike", "noise", "sine", "speechlike", "noise"])
+        mel = eng.logmel(torch.from_numpy(pcm).cuda())
+        prompt = np.tile(np.array(PROMPT, dtype=np.int32), (B, 1))
+
+        def decode():
+            out = eng.generate_greedy(prompt, max_new_tokens=20, timestamps=True, want_alignment=True)
+            ts = eng.token_timestamps(B, 3, out["sequences"].shape[1], [2 * T] * B)
+            return out["sequences"], ts, eng.get_alignment(B, out["sequences"].shape[1] - 1)
+
+        hidden = eng.encode(mel, return_hidden=True).cpu().numpy()
+        eng.cross_kv(B)
+        ids0, ts0, al0 = decode()
+        # the same five clips in three groups: slots 0-1, 2, 3-4 (a different pass shape was in the context before)
+        eng.encode(mel[:2])
+        eng.cross_kv(2)
+        eng.encode(mel[2:3], slot0=2)
+        eng.cross_kv(1, slot0=2)
+        eng.encode(mel[3:5], slot0=3)
+        eng.cross_kv(2, slot0=3)
+        ids1, ts1, al1 = decode()
+        assert np.array_equal(ids0, ids1) and np.array_equal(ts0, ts1) and np.array_equal(al0, al1)
+        # the first group alone reproduces its rows of the one-call encoder output (row results do not depend on the batch)
+        assert np.array_equal(eng.encode(mel[:2], return_hidden=True).cpu().numpy(), hidden[:2])
+        # misuse is refused: a gap before slot0, or slots beyond the context capacity
+        with pytest.raises(RuntimeError):
+            eng.encode(mel[:1], slot0=4)
+        with pytest.raises(RuntimeError):
+            eng.encode(mel[:5], slot0=4)
+    finally:
+        eng.close()

@@ -49,6 +49,8 @@ SYMBOLS = [
     ("tw_logmel", C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int32), C.c_int32, C.c_int32, _P, C.c_int32, _P]),
     ("tw_encode", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P]),
     ("tw_cross_kv", C.c_int, [_P, C.c_int32, _P]),
+    ("tw_encode_at", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
+    ("tw_cross_kv_at", C.c_int, [_P, C.c_int32, C.c_int32, _P]),
     ("tw_decoder_reset", C.c_int, [_P, C.c_int32, _P]),
     ("tw_decode_step", C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), _P, _P]),
     ("tw_generate_greedy", C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(tw_greedy_opts),

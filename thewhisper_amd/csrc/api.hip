@@ -644,11 +644,18 @@ int tw_logmel(tw_ctx* c, const float* pcm, int64_t pcm_stride, const int32_t* n_
 // ---------------------------------------------------------------------------------------------
 // A2-A4 encoder
 // ---------------------------------------------------------------------------------------------
-int tw_encode(tw_ctx* c, const void* mel, int32_t mel_dtype, int32_t B, void* out_hidden, int32_t out_dtype, void* stream) {
+}  // extern "C"
+
+namespace {
+
+// encoder for B clips whose output goes to slots slot0 .. slot0+B-1 of enc_out (all other buffers are scratch from row 0)
+int encode_core(tw_ctx* c, const void* mel, int32_t mel_dtype, int32_t B, int32_t slot0, void* out_hidden, int32_t out_dtype,
+                void* stream) {
   if (!c || !mel) return fail(c, TW_EINVAL, "tw_encode: null argument");
   TW_ON_DEVICE(c);
   if (!c->finalized) return fail(c, TW_ESTATE, "tw_encode before tw_finalize_weights");
-  if (B < 1 || B > c->Bmax) return fail(c, TW_EINVAL, "tw_encode: B=%d outside [1,%d]", B, c->Bmax);
+  if (B < 1 || slot0 < 0 || slot0 + B > c->Bmax) return fail(c, TW_EINVAL, "tw_encode: slots [%d, %d) outside [0,%d)", slot0, slot0 + B, c->Bmax);
+  if (slot0 > c->encoded_B) return fail(c, TW_ESTATE, "tw_encode_at: slot0=%d but only %d slots are filled", slot0, c->encoded_B);
   hipStream_t st = pick_stream(c, stream);
   const int d = c->d, T = c->T, C = c->C, H = c->H, F = c->ffn, dt = c->dtype;
   const size_t e = c->esz;
@@ -699,38 +706,66 @@ int tw_encode(tw_ctx* c, const void* mel, int32_t mel_dtype, int32_t B, void* ou
       HIPCHK(c, launch_gemm(dt, c->ffnh, plain_rows(F), L.w2, M, d, F, ep, st));
     }
   }
-  HIPCHK(c, launch_layernorm(dt, c->xa, c->enc_ln_g, c->enc_ln_b, c->enc_out, M, d, st));
+  void* enc_dst = at(c->enc_out, (size_t)slot0 * T * d, e);
+  HIPCHK(c, launch_layernorm(dt, c->xa, c->enc_ln_g, c->enc_ln_b, enc_dst, M, d, st));
   toc(c, 1, st);
-  if (out_hidden) HIPCHK(c, launch_convert(out_dtype, dt, c->enc_out, out_hidden, (long long)M * d, 1.f, st));
-  c->encoded_B = B;
-  c->cross_B = 0;
+  if (out_hidden) HIPCHK(c, launch_convert(out_dtype, dt, enc_dst, out_hidden, (long long)M * d, 1.f, st));
+  c->encoded_B = slot0 + B;
+  c->cross_B = slot0 < c->cross_B ? slot0 : c->cross_B;   // cross K/V of the re-encoded slots (and everything after) is stale
   return TW_OK;
 }
 
-int tw_cross_kv(tw_ctx* c, int32_t B, void* stream) {
+// cross K/V of slots slot0 .. slot0+B-1: the per-(stream, head) blocks of a layer are contiguous per stream, so a slot offset is
+// a pointer offset on the GEMM's input rows and on its head-split outputs
+int cross_kv_core(tw_ctx* c, int32_t B, int32_t slot0, void* stream) {
   if (!c) return TW_EINVAL;
   TW_ON_DEVICE(c);
-  if (B < 1 || B > c->encoded_B) return fail(c, TW_ESTATE, "tw_cross_kv: B=%d but %d clips encoded", B, c->encoded_B);
+  if (B < 1 || slot0 < 0 || slot0 + B > c->encoded_B)
+    return fail(c, TW_ESTATE, "tw_cross_kv: slots [%d, %d) but %d clips encoded", slot0, slot0 + B, c->encoded_B);
+  if (slot0 > c->cross_B) return fail(c, TW_ESTATE, "tw_cross_kv_at: slot0=%d but cross K/V holds %d clips", slot0, c->cross_B);
   hipStream_t st = pick_stream(c, stream);
   const int d = c->d, T = c->T;
   const size_t per_layer = (size_t)c->Bmax * c->Tp * d;
+  const size_t slot_off = (size_t)slot0 * c->Tp * d;             // elements of one layer's K (or V^T) arena before slot0
+  const size_t sc_off = (size_t)slot0 * c->H * c->Tp;            // fp8 contexts: scale bytes before slot0
   tic(c, 2, st);
   for (int l = 0; l < c->Ld; ++l) {
     const LayerW& L = c->dec[l];
     GemmEpilogue ep{};
     ep.bias = L.bkv_c; ep.mode = c->w8 ? EPI_KV_CROSS8 : EPI_KV_CROSS; ep.T = T; ep.Tp = c->Tp; ep.H = c->H;
-    ep.out = at(c->cross_k, per_layer * l, c->w8 ? 1 : c->esz);
-    ep.out2 = at(c->cross_v, per_layer * l, c->w8 ? 1 : c->esz);
+    ep.out = at(c->cross_k, per_layer * l + slot_off, c->w8 ? 1 : c->esz);
+    ep.out2 = at(c->cross_v, per_layer * l + slot_off, c->w8 ? 1 : c->esz);
     if (c->w8) {
-      ep.out3 = c->cross_ksc + (size_t)c->Bmax * c->H * c->Tp * l;
-      ep.out4 = c->cross_vsc + (size_t)c->Bmax * c->H * c->Tp * l;
+      ep.out3 = c->cross_ksc + (size_t)c->Bmax * c->H * c->Tp * l + sc_off;
+      ep.out4 = c->cross_vsc + (size_t)c->Bmax * c->H * c->Tp * l + sc_off;
     }
-    HIPCHK(c, launch_gemm(c->dtype, c->enc_out, plain_rows(d), L.wkv_c, B * T, 2 * d, d, ep, st));
+    HIPCHK(c, launch_gemm(c->dtype, at(c->enc_out, (size_t)slot0 * T * d, c->esz), plain_rows(d), L.wkv_c, B * T, 2 * d, d, ep, st));
   }
   toc(c, 2, st);
-  c->cross_B = B;
+  c->cross_B = slot0 + B;
   return TW_OK;
 }
+
+}  // namespace
+
+extern "C" {
+
+int tw_encode(tw_ctx* c, const void* mel, int32_t mel_dtype, int32_t B, void* out_hidden, int32_t out_dtype, void* stream) {
+  if (c) { c->encoded_B = 0; c->cross_B = 0; }
+  return encode_core(c, mel, mel_dtype, B, 0, out_hidden, out_dtype, stream);
+}
+
+int tw_encode_at(tw_ctx* c, const void* mel, int32_t mel_dtype, int32_t B, int32_t slot0, void* stream) {
+  if (c && slot0 == 0) { c->encoded_B = 0; c->cross_B = 0; }
+  return encode_core(c, mel, mel_dtype, B, slot0, nullptr, 0, stream);
+}
+
+int tw_cross_kv(tw_ctx* c, int32_t B, void* stream) {
+  if (c) c->cross_B = 0;
+  return cross_kv_core(c, B, 0, stream);
+}
+
+int tw_cross_kv_at(tw_ctx* c, int32_t B, int32_t slot0, void* stream) { return cross_kv_core(c, B, slot0, stream); }
 
 }  // extern "C"
 

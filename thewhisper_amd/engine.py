@@ -193,7 +193,9 @@ class WhisperEngine:
         return out
 
     # ---- A2-A5 -------------------------------------------------------------------------------
-    def encode(self, mel: torch.Tensor, return_hidden: bool = False, hidden_dtype: torch.dtype = torch.float32):
+    def encode(self, mel: torch.Tensor, return_hidden: bool = False, hidden_dtype: torch.dtype = torch.float32, slot0: int = 0):
+        """Encoder for the B clips of ``mel`` into slots ``slot0 .. slot0+B-1`` of the context (``slot0 > 0``: the slots
+        before it keep what earlier calls of this pass put there - ``tw_encode_at``)."""
         mel = mel.to(self.device).contiguous()
         if mel.dtype not in _TORCH2TW:
             mel = mel.float()
@@ -207,6 +209,12 @@ class WhisperEngine:
         if return_hidden:
             out = torch.empty((B, self.T, self.d_model), dtype=hidden_dtype, device=self.device)
         self._adopt(mel, out)
+        if slot0:
+            if return_hidden:
+                raise ValueError("return_hidden is only available for slot0 = 0")
+            rc = self.lib.tw_encode_at(self.ctx, C.c_void_p(mel.data_ptr()), _TORCH2TW[mel.dtype], B, int(slot0), self._sp())
+            self._chk(rc, "tw_encode_at")
+            return None
         rc = self.lib.tw_encode(self.ctx, C.c_void_p(mel.data_ptr()), _TORCH2TW[mel.dtype], B,
                                 C.c_void_p(out.data_ptr()) if out is not None else None,
                                 _TORCH2TW[hidden_dtype], self._sp())
@@ -215,8 +223,11 @@ class WhisperEngine:
             self._publish()
         return out
 
-    def cross_kv(self, B: int):
-        self._chk(self.lib.tw_cross_kv(self.ctx, B, self._sp()), "tw_cross_kv")
+    def cross_kv(self, B: int, slot0: int = 0):
+        if slot0:
+            self._chk(self.lib.tw_cross_kv_at(self.ctx, B, int(slot0), self._sp()), "tw_cross_kv_at")
+        else:
+            self._chk(self.lib.tw_cross_kv(self.ctx, B, self._sp()), "tw_cross_kv")
 
     # ---- A6-A8 (teacher-forced stepping, used by the parity tests) ---------------------------
     def decoder_reset(self, B: int):

@@ -159,19 +159,37 @@ class BatchingHub:
         eng = self.backend.asr_pipeline.model.engine
         jobs: List[Any] = []          # requests in flight, oldest first
         stop = False
+
+        def fail_jobs_of(works, exc):
+            nonlocal jobs
+            hit = [j for j in jobs if any(w in works for w in j.works)]
+            for j in hit:
+                self._answer(j.future, exc=exc)
+            jobs = [j for j in jobs if j not in hit]
+
         while True:
-            # 1. take in what has arrived; block only when there is nothing to decode, linger max_wait_s when a pass would
-            #    otherwise leave rows empty (the sessions answered after the last pass are about to ask again)
-            ready = sum(1 for j in jobs for w in j.works if not w.done)
-            deadline = time.monotonic() + self.max_wait_s
-            while not stop:
+            pas = shortform.Pass(eng, codec.plan)
+            # 1. the chunks that need a further seek iteration go first: their encoder stage is enqueued NOW (asynchronous), so
+            #    the GPU is already busy while the sessions answered after the last pass are on their way back
+            left = [w for j in jobs for w in j.works if not w.done][: self.max_batch]
+            if left:
                 try:
-                    if not jobs:
+                    pas.add(left)
+                except Exception as e:  # noqa: BLE001  (engine failure)
+                    fail_jobs_of(left, e)
+                    continue
+            # 2. intake: block when there is nothing to decode; otherwise linger while rows are free - for max_wait_s, or for as
+            #    long as the encoder stage of step 1 keeps the GPU busy anyway (~1.2 ms per chunk), whichever is longer
+            fresh: List[Any] = []
+            linger = max(self.max_wait_s, 0.0012 * len(left))
+            deadline = time.monotonic() + linger if left else None
+            while pas.free - len(fresh) > 0:
+                try:
+                    if deadline is None:
                         item = self._take()
-                    elif ready < self.max_batch:
-                        item = self._take(timeout=max(0.0, deadline - time.monotonic()))
+                        deadline = time.monotonic() + self.max_wait_s
                     else:
-                        item = self._take(block=False)
+                        item = self._take(timeout=max(0.0, deadline - time.monotonic()))
                 except queue.Empty:
                     break
                 if item is None:
@@ -185,29 +203,30 @@ class BatchingHub:
                     continue
                 job.future = fut
                 jobs.append(job)
-                ready += len(job.works)
+                fresh.extend(job.works)
             if stop:
                 for j in jobs:
                     self._answer(j.future, exc=RuntimeError("BatchingHub closed before the request was served"))
                 return
-            # 2. one pass over the oldest unfinished chunks
-            works = [w for j in jobs for w in j.works if not w.done][: self.max_batch]
-            if not works:
-                continue
-            self.batches.append(len(works))
-            self.passes += 1
+            # 3. the late arrivals join the pass as a second group (slots after the first group's), then ONE greedy loop over all
+            works = list(left)
             try:
-                shortform.run_pass(eng, codec.plan, works)
+                take = fresh[: pas.free]
+                if take:
+                    pas.add(take)
+                    works += take
+                if not works:
+                    continue
+                self.batches.append(len(works))
+                self.passes += 1
+                pas.run()
                 for w in works:
                     if w.passes > 64:
                         raise RuntimeError("a chunk needed more than 64 seek passes (the decoder keeps seeking to frame 0)")
             except Exception as e:  # noqa: BLE001  (engine failure: every request that had a chunk in this pass fails)
-                hit = [j for j in jobs if any(w in works for w in j.works)]
-                for j in hit:
-                    self._answer(j.future, exc=e)
-                jobs = [j for j in jobs if j not in hit]
+                fail_jobs_of(works, e)
                 continue
-            # 3. finished requests leave for post-processing (tokenizer state machine, word merge: host Python that overlaps
+            # 4. finished requests leave for post-processing (tokenizer state machine, word merge: host Python that overlaps
             #    the next pass - the engine call releases the GIL)
             still = []
             for j in jobs:

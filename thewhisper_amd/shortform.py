@@ -133,64 +133,103 @@ def retrieve_segment(seek_sequence: torch.Tensor, result: Any, token_timestamps,
     return segments, int(segment_offset)
 
 
+class Pass:
+    """One seek iteration (HF:...:785-903) for up to ``engine.max_batch`` chunks, assembled in GROUPS: ``add(works)`` cuts the
+    groups' segments and enqueues their encoder + cross-K/V stage at the next free slots (asynchronous launches), ``run()``
+    decodes all slots in one greedy loop and advances every chunk.  A serving loop adds the chunks that need a further
+    iteration first and whatever arrives while the GPU is still encoding those; ``run_pass`` is the one-group form."""
+
+    def __init__(self, engine, plan: ShortFormPlan):
+        self.engine, self.plan = engine, plan
+        self.works: List[ChunkWork] = []
+        self.snf: List[int] = []
+        self._keep: List[torch.Tensor] = []       # segment tensors stay alive until the pass has run
+
+    @property
+    def free(self) -> int:
+        return int(self.engine.max_batch) - len(self.works)
+
+    def add(self, works: Sequence[ChunkWork]) -> None:
+        n_new = len(works)
+        if n_new == 0:
+            return
+        if n_new > self.free:
+            raise ValueError(f"a pass takes at most {self.engine.max_batch} chunks")
+        nsf = 2 * int(self.engine.T)                  # num_segment_frames = input_stride * max_source_positions (HF :652-653)
+        rows = []
+        for w in works:
+            if w.done:
+                raise ValueError("finished chunk handed to a pass")
+            n = min(w.max_frames - w.seek, nsf)
+            self.snf.append(n)
+            s = w.feats[:, w.seek : w.seek + n]
+            if n < nsf:
+                s = F.pad(s, pad=(0, nsf - n))        # HF:...:1840-1844
+            rows.append(s)
+        segment_input = torch.stack(rows, dim=0)
+        slot0 = len(self.works)
+        if slot0:
+            self.engine.encode(segment_input, slot0=slot0)
+            self.engine.cross_kv(n_new, slot0=slot0)
+        else:
+            self.engine.encode(segment_input)
+            self.engine.cross_kv(n_new)
+        self._keep.append(segment_input)
+        self.works.extend(works)
+
+    def run(self) -> None:
+        engine, plan, works, snf = self.engine, self.plan, self.works, self.snf
+        B = len(works)
+        if B < 1:
+            raise ValueError("empty pass")
+        n_prompt = plan.n_prompt
+        prompt = np.tile(np.asarray(plan.init_tokens, dtype=np.int32), (B, 1))
+        out = engine.generate_greedy(prompt, **plan.greedy)
+        self._keep.clear()
+        seq = torch.from_numpy(np.ascontiguousarray(out["sequences"])).to(torch.long)
+        L = int(seq.shape[1])
+        ts = None
+        if plan.return_token_timestamps:
+            if L - 1 <= n_prompt:          # one generated token: no cross-attention rows after the prompt (HF :341-344)
+                ts = torch.zeros((B, L), dtype=torch.float32)
+            else:
+                nf = None
+                if works[0].num_frames is not None:
+                    nf = [int(w.num_frames) - int(w.seek) for w in works]     # HF:...:1152-1155
+                ts = torch.from_numpy(engine.token_timestamps(B, n_prompt, L, nf, plan.time_precision))
+        for i, w in enumerate(works):
+            if plan.result_is_dict:
+                result: Any = {"sequences": seq[i]}
+                if ts is not None:
+                    result["token_timestamps"] = ts[i]
+            else:
+                result = seq[i]
+            seek_sequence = seq[i, n_prompt:]
+            # HF:...:1068-1076: drop the padding, keep one eos for the (unused here) log-prob statistics, then drop that eos too
+            if seek_sequence.numel() > 0 and seek_sequence[-1] == plan.pad:
+                num_paddings = int((seek_sequence == plan.pad).sum())
+                if plan.pad == plan.eos:
+                    num_paddings -= 1
+                if num_paddings != 0:
+                    seek_sequence = seek_sequence[:-num_paddings]
+            if seek_sequence.numel() > 0 and seek_sequence[-1] == plan.eos:
+                seek_sequence = seek_sequence[:-1]
+            time_offset = torch.tensor(w.seek, dtype=torch.long).to(torch.float64) * plan.time_precision / plan.input_stride
+            segments, offset = retrieve_segment(seek_sequence, result, ts[i] if ts is not None else [], time_offset,
+                                                plan.timestamp_begin, snf[i], plan, n_prompt)
+            w.seek += offset
+            w.segments += segments
+            w.passes += 1
+
+
 def run_pass(engine, plan: ShortFormPlan, works: Sequence[ChunkWork]) -> None:
-    """One seek iteration (HF:...:785-903) for every work in ``works`` (all unfinished, len <= engine.max_batch): segment
-    cut-out, encoder + cross-K/V + greedy loop (+ token timestamps) on the engine, segment slicing, seek advance."""
-    B = len(works)
-    if B < 1 or B > engine.max_batch:
-        raise ValueError(f"a pass takes 1..{engine.max_batch} chunks, got {B}")
-    nsf = 2 * int(engine.T)                       # num_segment_frames = input_stride * max_source_positions (HF :652-653)
-    n_prompt = plan.n_prompt
-    snf: List[int] = []
-    rows = []
-    for w in works:
-        if w.done:
-            raise ValueError("finished chunk handed to run_pass")
-        n = min(w.max_frames - w.seek, nsf)
-        snf.append(n)
-        s = w.feats[:, w.seek : w.seek + n]
-        if n < nsf:
-            s = F.pad(s, pad=(0, nsf - n))          # HF:...:1840-1844
-        rows.append(s)
-    segment_input = torch.stack(rows, dim=0)
-    engine.encode(segment_input)
-    engine.cross_kv(B)
-    prompt = np.tile(np.asarray(plan.init_tokens, dtype=np.int32), (B, 1))
-    out = engine.generate_greedy(prompt, **plan.greedy)
-    seq = torch.from_numpy(np.ascontiguousarray(out["sequences"])).to(torch.long)
-    L = int(seq.shape[1])
-    ts = None
-    if plan.return_token_timestamps:
-        if L - 1 <= n_prompt:          # one generated token: no cross-attention rows after the prompt (HF :341-344)
-            ts = torch.zeros((B, L), dtype=torch.float32)
-        else:
-            nf = None
-            if works[0].num_frames is not None:
-                nf = [int(w.num_frames) - int(w.seek) for w in works]     # HF:...:1152-1155
-            ts = torch.from_numpy(engine.token_timestamps(B, n_prompt, L, nf, plan.time_precision))
-    for i, w in enumerate(works):
-        if plan.result_is_dict:
-            result: Any = {"sequences": seq[i]}
-            if ts is not None:
-                result["token_timestamps"] = ts[i]
-        else:
-            result = seq[i]
-        seek_sequence = seq[i, n_prompt:]
-        # HF:...:1068-1076: drop the padding, keep one eos for the (unused here) log-prob statistics, then drop that eos too
-        if seek_sequence.numel() > 0 and seek_sequence[-1] == plan.pad:
-            num_paddings = int((seek_sequence == plan.pad).sum())
-            if plan.pad == plan.eos:
-                num_paddings -= 1
-            if num_paddings != 0:
-                seek_sequence = seek_sequence[:-num_paddings]
-        if seek_sequence.numel() > 0 and seek_sequence[-1] == plan.eos:
-            seek_sequence = seek_sequence[:-1]
-        time_offset = torch.tensor(w.seek, dtype=torch.long).to(torch.float64) * plan.time_precision / plan.input_stride
-        segments, offset = retrieve_segment(seek_sequence, result, ts[i] if ts is not None else [], time_offset,
-                                            plan.timestamp_begin, snf[i], plan, n_prompt)
-        w.seek += offset
-        w.segments += segments
-        w.passes += 1
+    """One seek iteration for every work in ``works`` (all unfinished, len <= engine.max_batch): segment cut-out, encoder +
+    cross-K/V + greedy loop (+ token timestamps) on the engine, segment slicing, seek advance."""
+    if len(works) < 1 or len(works) > engine.max_batch:
+        raise ValueError(f"a pass takes 1..{engine.max_batch} chunks, got {len(works)}")
+    p = Pass(engine, plan)
+    p.add(works)
+    p.run()
 
 
 def work_tokens(plan: ShortFormPlan, w: ChunkWork) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]]:
