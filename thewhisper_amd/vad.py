@@ -65,7 +65,8 @@ class BatchedVAD:
         k = x.shape[1] // FRAME
         out = torch.empty((self.n, k), dtype=torch.float32, device=self.device)
         st = torch.cuda.current_stream(self.device).cuda_stream
-        rc = self.lib.tw_vad_energy(self.device.index or 0, C.c_void_p(x.data_ptr()), x.stride(0), self.n, k,
+        stride0 = x.stride(0) if self.n > 1 else x.shape[1]   # a size-1 dimension of a contiguous tensor may carry any stride
+        rc = self.lib.tw_vad_energy(self.device.index or 0, C.c_void_p(x.data_ptr()), stride0, self.n, k,
                                     C.c_void_p(self.state.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(int(st) if st else None))
         if rc != 0:
             raise RuntimeError(f"tw_vad_energy failed ({rc}): {self.lib.tw_last_error(None).decode()}")
