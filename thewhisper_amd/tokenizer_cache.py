@@ -15,7 +15,10 @@ is dropped when the special-token tables change; anything else - other argument 
 """
 from __future__ import annotations
 
+import threading
+
 _MEMO_MAX = 1 << 18
+_tls = threading.local()   # .key = (tokenizer id, table key) while a `_decode_asr` call of this thread is in flight
 
 
 def _frozen(v):
@@ -33,6 +36,15 @@ def _key(tok):
             tok.__dict__.get("_tw_vocab_version", 0), getattr(tok, "clean_up_tokenization_spaces", None))
 
 
+def _cur_key(tok):
+    """The table key, computed once per `_decode_asr` call (the ~2000 memoised decode() calls inside one post-processing pass
+    cannot see the tables change: they run on one thread) and per call otherwise (the by-value key costs ~50 us)."""
+    held = getattr(_tls, "key", None)
+    if held is not None and held[0] == id(tok):
+        return held[1]
+    return _key(tok)
+
+
 def cache_special_ids(tokenizer):
     cls = type(tokenizer)
     if getattr(cls, "_tw_special_id_cache", False) or not hasattr(tokenizer, "_extra_special_tokens") \
@@ -44,7 +56,7 @@ def cache_special_ids(tokenizer):
     base_decode = cls.decode
 
     def all_special_ids(self):
-        k = _key(self)
+        k = _cur_key(self)
         hit = self.__dict__.get("_tw_special_ids")
         if hit is None or hit[0] != k:
             hit = (k, list(base_ids(self)))
@@ -69,7 +81,7 @@ def cache_special_ids(tokenizer):
                                time_precision=time_precision, decode_with_timestamps=decode_with_timestamps,
                                normalize=normalize, basic_normalize=basic_normalize, remove_diacritics=remove_diacritics,
                                **kwargs)
-        k = _key(self)
+        k = _cur_key(self)
         memo = self.__dict__.get("_tw_decode_memo")
         if memo is None or memo[0] != k or len(memo[1]) > _MEMO_MAX:
             memo = (k, {})
@@ -84,6 +96,17 @@ def cache_special_ids(tokenizer):
         return text
 
     members = {"all_special_ids": property(all_special_ids), "decode": decode, "_tw_special_id_cache": True}
+    base_asr = getattr(cls, "_decode_asr", None)
+    if base_asr is not None:
+        def _decode_asr(self, *a, **k):   # the outer call of a pipeline's post-processing: validate the tables once for it
+            prev = getattr(_tls, "key", None)
+            _tls.key = (id(self), _key(self))
+            try:
+                return base_asr(self, *a, **k)
+            finally:
+                _tls.key = prev
+
+        members["_decode_asr"] = _decode_asr
     base_add = getattr(cls, "_add_tokens", None)
     if base_add is not None:
         def _add_tokens(self, *a, **k):   # add_tokens() and add_special_tokens() both end here: new vocabulary -> new cache key
