@@ -17,7 +17,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBNAME = "libthewhisper_gfx950.so"
 SOURCES = ["api.hip", "k_gemm.hip", "k_misc.hip", "k_logmel.hip", "k_attn.hip", "k_decode.hip", "k_dtw.hip", "k_vad.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
+# -amdgpu-kernarg-preload-count: gfx950 hands the leading kernel-argument dwords to every wave in SGPRs (as many as the free user
+# SGPRs allow); the decode kernels order their arguments so that the request addresses need nothing else (k_decode.hip)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result",
+         "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
 def _hipcc() -> str:

@@ -224,7 +224,12 @@ template <> __device__ __forceinline__ void sk_stats<float>(const u32x4_t& v, fl
 // [tile][step][kq * TR + fr][E] (tile_weights_kernel), i.e. a wavefront request is TR * 64 contiguous bytes.
 template <typename T, int NW, int SK_MAXS, bool LN, int EPI, bool MULTI, bool W8, int CG, int TR>
 __global__ __launch_bounds__(NW * 64, (CG > 1 ? (NW >= 16 ? 4 : 2) : (NW >= 16 ? 4 : (W8 ? (SK_MAXS <= 2 ? 4 : 2) : (SK_MAXS <= 5 ? 4 : 2)))))
-void skinny_mfma_kernel(GemvArgs a) {
+void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_arg, int n_arg, int rg_arg,
+                        const unsigned char* wscale_arg, const void* bias_arg, const void* res_arg, const float* gw_arg, GemvArgs a) {
+  // The first arguments repeat what the request addresses are formed from (operands, K, B, N, tiles per workgroup): gfx950
+  // delivers the leading kernel-argument dwords in SGPRs with the wave (kernarg preload, build.py: -amdgpu-kernarg-preload-count),
+  // so the activation and weight requests leave without waiting for a scalar load; everything else (epilogue operands, outputs)
+  // stays in the GemvArgs block behind them - a struct is never preloaded - and arrives while those requests are in flight.
   static_assert(!W8 || sizeof(T) == 2, "MXFP8 weights go with bf16 activations");
   static_assert(TR == 16 || (!MULTI && EPI != SK_KV && EPI != SK_F32), "narrow tiles: plain / residual / GELU projections only");
   static_assert(!W8 || TR == 16 || TR == 8, "MXFP8 weights: 16- or 8-row tiles");
@@ -233,14 +238,14 @@ void skinny_mfma_kernel(GemvArgs a) {
   constexpr int WPS = W8 ? 2 : 1;  // 16-B weight requests per MFMA step
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ float pstat[NW][CG * 16][2];  // per wavefront and stream: (sum, sum of squares) over the wavefront's K slice
-  const T* x = reinterpret_cast<const T*>(a.x);
-  const T* W = reinterpret_cast<const T*>(a.W);
-  const unsigned char* wscale = a.wscale;
-  const T* bias = reinterpret_cast<const T*>(a.bias);
-  const T* res = reinterpret_cast<const T*>(a.res);
-  const float* gw_p = a.ln_gw;
+  const T* x = reinterpret_cast<const T*>(x_arg);
+  const T* W = reinterpret_cast<const T*>(w_arg);
+  const unsigned char* wscale = wscale_arg;
+  const T* bias = reinterpret_cast<const T*>(bias_arg);
+  const T* res = reinterpret_cast<const T*>(res_arg);
+  const float* gw_p = gw_arg;
   const float* cb_p = a.ln_cb;
-  const int K = a.K, N = a.N, B = a.B, ldy = a.ldy, RG = a.rg, d_model = a.d_model;
+  const int K = k_arg, N = n_arg, B = b_arg, ldy = a.ldy, RG = rg_arg, d_model = a.d_model;
   const long long cache_bstride = a.cache_bstride;
   T* y = reinterpret_cast<T*>(a.y);
   float* y_f32 = a.y_f32;
@@ -250,15 +255,9 @@ void skinny_mfma_kernel(GemvArgs a) {
   float* u_p = a.u;              // "cross query ahead" (tw_common.h): float32 [B][d_model] pre-activation, null = off
   float* stats_p = a.stats;
   const int nsplit = a.nsplit;   // SK_RES: rows >= nsplit accumulate into u (the launcher sets N when there is no such half)
-  asm volatile("" ::"s"(x), "s"(W), "s"(bias), "s"(res), "s"(gw_p), "s"(cb_p), "s"(K), "s"(N), "s"(B), "s"(a.gelu), "s"(ldy),
-               "s"(RG), "s"(d_model), "s"(cache_bstride), "s"(y), "s"(y_f32), "s"(kcache), "s"(vcache), "s"(stt), "s"(wscale),
-               "s"(u_p), "s"(nsplit), "s"(stats_p));
+  // (1) what the activation / weight requests need: delivered with the wave (leading arguments), nothing to wait for
+  asm volatile("" ::"s"(x), "s"(W), "s"(K), "s"(N), "s"(B), "s"(RG), "s"(wscale));
   int cur_pos = 0;
-#ifdef TW_PROBE_TS
-  cur_pos = stt->pos;
-#else
-  if (EPI == SK_KV) cur_pos = stt->pos;
-#endif
   TW_TS(0);
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -369,6 +368,16 @@ void skinny_mfma_kernel(GemvArgs a) {
   load_x(s_lo);
   __builtin_amdgcn_sched_barrier(0);  // request order = consumption order: hipcc must not reorder the groups
   load_w(tile0, s_lo);
+  __builtin_amdgcn_sched_barrier(0);
+  // (2) everything else (epilogue operands, outputs, cache geometry): ONE batch of scalar loads from the argument block, waited for
+  // here, behind the operand requests that are already on their way
+  asm volatile("" ::"s"(bias), "s"(res), "s"(gw_p), "s"(cb_p), "s"(a.gelu), "s"(ldy), "s"(d_model), "s"(cache_bstride), "s"(y),
+               "s"(y_f32), "s"(kcache), "s"(vcache), "s"(stt), "s"(u_p), "s"(nsplit), "s"(stats_p));
+#ifdef TW_PROBE_TS
+  cur_pos = stt->pos;
+#else
+  if (EPI == SK_KV) cur_pos = stt->pos;
+#endif
   load_epi(tile0, e_c, e_gw, e_res);
   __builtin_amdgcn_sched_barrier(0);  // ... nor hoist arithmetic between the requests
   TW_TS(1);
@@ -704,6 +713,11 @@ __device__ __forceinline__ float attn_mfma_block(const T* __restrict__ q, const 
 #pragma unroll
     for (int i = 0; i < 4 * DS; ++i) vfr[i] = *reinterpret_cast<const u32x4_t*>(p + (long long)i * 64 * E);
   };
+  // K first: its addresses are formed from the leading (preloaded) kernel arguments alone, so these requests leave at once;
+  // the query side needs the rest of the argument block (one scalar batch, pinned here) and goes out behind them
+  load_k(wave);
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("" ::"s"(q), "s"(fq.u), "s"(fq.stats), "s"(fq.n_part), "s"(fq.gw), "s"(fq.cb), "s"(fq.d));
   QRaw<T> qr;
   if constexpr (FQ) {
     fq_request<T>(qr, fq, fq_b, fq_h, lane);
@@ -711,7 +725,6 @@ __device__ __forceinline__ float attn_mfma_block(const T* __restrict__ q, const 
 #pragma unroll
     for (int ds = 0; ds < DS; ++ds) qf[ds] = *reinterpret_cast<const u32x4_t*>(q + ds * 4 * E + kq * E);
   }
-  load_k(wave);
   if (SINGLE) load_v(wave);
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (FQ) {
@@ -835,13 +848,6 @@ __device__ __forceinline__ float attn_mfma_block_kv8(const bf16_t* __restrict__ 
   const int last64 = n_bound / 64 - 1;
   u32x4_t qf[2], kraw[G][4], vraw[G][4];
   unsigned ks4[G], vsb[G];
-  QRaw<T> qr;
-  if constexpr (FQ) {
-    fq_request<T>(qr, fq, fq_b, fq_h, lane);
-  } else {
-    qf[0] = *reinterpret_cast<const u32x4_t*>(q + kq * 16);
-    qf[1] = *reinterpret_cast<const u32x4_t*>(q + kq * 16 + 8);
-  }
 #pragma unroll
   for (int g = 0; g < G; ++g) {  // 64 keys = 4 tiles of 1 KiB + their 64 scale bytes ([group][key % 16][tile]: one 32-bit load)
     const int gi = min(g * NW + wave, last64);
@@ -849,6 +855,16 @@ __device__ __forceinline__ float attn_mfma_block_kv8(const bf16_t* __restrict__ 
 #pragma unroll
     for (int a = 0; a < 4; ++a) kraw[g][a] = *reinterpret_cast<const u32x4_t*>(p + a * 1024);
     ks4[g] = *reinterpret_cast<const unsigned*>(ksc + gi * 64 + fr * 4);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // the query side behind the K requests (see attn_mfma_block)
+  asm volatile("" ::"s"(q), "s"(fq.u), "s"(fq.stats), "s"(fq.n_part), "s"(fq.gw), "s"(fq.cb), "s"(fq.d));
+  QRaw<T> qr;
+  if constexpr (FQ) {
+    fq_request<T>(qr, fq, fq_b, fq_h, lane);
+  } else {
+    qf[0] = *reinterpret_cast<const u32x4_t*>(q + kq * 16);
+    qf[1] = *reinterpret_cast<const u32x4_t*>(q + kq * 16 + 8);
   }
 #pragma unroll
   for (int g = 0; g < G; ++g) {  // 64 keys x 64 dims = 4 dim tiles of 1 KiB; lane `lane` also fetches the scale of ITS key
@@ -953,11 +969,12 @@ __device__ __forceinline__ float attn_mfma_block_kv8(const bf16_t* __restrict__ 
 // 64-key bucket per step): no idle wavefronts to launch and to meet at the barriers of the cross-wavefront reductions
 template <typename T, bool SINGLE, int NW>
 __global__ __launch_bounds__(NW * 64) void dec_self_attn_kernel(const T* __restrict__ q, const T* __restrict__ kc,
-                                                                 const T* __restrict__ vc, int rows, T* __restrict__ out, int H,
-                                                                 int key_bound, const DecState* __restrict__ stt) {
+                                                                 const T* __restrict__ vc, int rows, int H, int key_bound,
+                                                                 T* __restrict__ out, const DecState* __restrict__ stt) {
+  // argument order: what the K / V^T / q request addresses need comes first (kernarg preload, see skinny_mfma_kernel)
   __shared__ float sc[512];
   __shared__ float red[2 * 4 + 4 * 64];
-  asm volatile("" ::"s"(q), "s"(kc), "s"(vc), "s"(rows), "s"(out), "s"(H), "s"(key_bound), "s"(stt));
+  asm volatile("" ::"s"(q), "s"(kc), "s"(vc), "s"(rows), "s"(H), "s"(key_bound));
   const int h = blockIdx.x, b = blockIdx.y;
   const int n_keys = stt->pos + 1;
   const long long base = ((long long)b * H + h) * rows * 64;
@@ -967,17 +984,15 @@ __global__ __launch_bounds__(NW * 64) void dec_self_attn_kernel(const T* __restr
 }
 
 template <typename T, bool SINGLE, bool FQ>
-__global__ __launch_bounds__(512) void dec_cross_attn_kernel(const T* __restrict__ q, FusedQ fq, const T* __restrict__ ck,
-                                                              const T* __restrict__ cv, T* __restrict__ out, int H,
-                                                              int Tlen, int Tp, const int* __restrict__ align_slot,
-                                                              float* __restrict__ align, int Ha, int P,
-                                                              const DecState* __restrict__ stt) {
+__global__ __launch_bounds__(512) void dec_cross_attn_kernel(const T* __restrict__ ck, const T* __restrict__ cv, int H, int Tp,
+                                                              int Tlen, const T* __restrict__ q, T* __restrict__ out,
+                                                              const int* __restrict__ align_slot, float* __restrict__ align,
+                                                              int Ha, int P, const DecState* __restrict__ stt, FusedQ fq) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* sc = reinterpret_cast<float*>(smem);  // [Tp] scores -> unnormalised probabilities
   __shared__ float red[2 * 8 + 8 * 64];
   __shared__ __attribute__((aligned(16))) T qst[FQ ? 8 * 64 : 8];
-  asm volatile("" ::"s"(q), "s"(ck), "s"(cv), "s"(out), "s"(H), "s"(Tlen), "s"(Tp), "s"(align_slot), "s"(align), "s"(Ha), "s"(P),
-               "s"(stt), "s"(fq.u), "s"(fq.stats), "s"(fq.n_part), "s"(fq.gw), "s"(fq.cb), "s"(fq.d));
+  asm volatile("" ::"s"(ck), "s"(cv), "s"(H), "s"(Tp), "s"(Tlen));
   const int h = blockIdx.x, b = blockIdx.y;
   const long long base = ((long long)b * H + h) * Tp * 64;
   const float inv = attn_mfma_block<T, 8, SINGLE, FQ>(q + ((long long)b * H + h) * 64, ck + base, cv + base, Tlen, Tp, sc, red,
@@ -991,20 +1006,18 @@ __global__ __launch_bounds__(512) void dec_cross_attn_kernel(const T* __restrict
 }
 
 template <int G, bool FQ>
-__global__ __launch_bounds__(512) void dec_cross_attn_kv8_kernel(const bf16_t* __restrict__ q, FusedQ fq, const unsigned char* __restrict__ ck,
-                                                                  const unsigned char* __restrict__ cv,
+__global__ __launch_bounds__(512) void dec_cross_attn_kv8_kernel(const unsigned char* __restrict__ ck, const unsigned char* __restrict__ cv,
                                                                   const unsigned char* __restrict__ ksc,
-                                                                  const unsigned char* __restrict__ vsc, bf16_t* __restrict__ out,
-                                                                  int H, int Tlen, int Tp, const int* __restrict__ align_slot,
-                                                                  float* __restrict__ align, int Ha, int P,
-                                                                  const DecState* __restrict__ stt) {
+                                                                  const unsigned char* __restrict__ vsc, int H, int Tp, int Tlen,
+                                                                  const bf16_t* __restrict__ q, bf16_t* __restrict__ out,
+                                                                  const int* __restrict__ align_slot, float* __restrict__ align,
+                                                                  int Ha, int P, const DecState* __restrict__ stt, FusedQ fq) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* sc = reinterpret_cast<float*>(smem);  // [Tp] scores -> unnormalised probabilities
   float* scv = sc + Tp;                        // [Tp] probabilities x V scale
   __shared__ float red[2 * 8 + 8 * 64];
   __shared__ __attribute__((aligned(16))) bf16_t qst[FQ ? 8 * 64 : 8];
-  asm volatile("" ::"s"(q), "s"(ck), "s"(cv), "s"(ksc), "s"(vsc), "s"(out), "s"(H), "s"(Tlen), "s"(Tp), "s"(align_slot), "s"(align),
-               "s"(Ha), "s"(P), "s"(stt), "s"(fq.u), "s"(fq.stats), "s"(fq.n_part), "s"(fq.gw), "s"(fq.cb), "s"(fq.d));
+  asm volatile("" ::"s"(ck), "s"(cv), "s"(ksc), "s"(vsc), "s"(H), "s"(Tp), "s"(Tlen));
   const int h = blockIdx.x, b = blockIdx.y;
   const long long hb = ((long long)b * H + h) * Tp;
   const float inv = attn_mfma_block_kv8<8, G, FQ>(q + ((long long)b * H + h) * 64, ck + hb * 64, cv + hb * 64, ksc + hb, vsc + hb,
@@ -1248,7 +1261,8 @@ template <typename T, int NW, int SK_MAXS, bool MULTI, bool W8, int CG, int TR>
 static hipError_t skinny_launch_cg(const GemvArgs& a, dim3 grid, size_t lds1, hipStream_t st) {
   const bool ln = a.ln_gw != nullptr;
   const size_t lds = lds1 * CG;
-#define SK_GO(LNV, EPIV) hipLaunchKernelGGL((skinny_mfma_kernel<T, NW, SK_MAXS, LNV, EPIV, MULTI, W8, CG, TR>), grid, dim3(NW * 64), lds, st, a)
+#define SK_GO(LNV, EPIV) hipLaunchKernelGGL((skinny_mfma_kernel<T, NW, SK_MAXS, LNV, EPIV, MULTI, W8, CG, TR>), grid, dim3(NW * 64), lds, st, \
+                                            a.x, a.W, a.K, a.B, a.N, a.rg, a.wscale, a.bias, a.res, a.ln_gw, a)
   if constexpr (TR != 16) {  // narrow tiles: plain / residual / GELU projections, one tile per workgroup
     if (a.y_f32 || a.kcache) return hipErrorInvalidValue;
     if constexpr (MULTI || (W8 && TR != 8)) {
@@ -1398,7 +1412,7 @@ hipError_t launch_dec_self_attn(int dtype, const void* q, const void* kc, const 
   const bool single = kb <= 256;
   const int nw = kb <= 64 ? 1 : (kb <= 128 ? 2 : 4);
 #define SA_GO(TT, SV, NWV) hipLaunchKernelGGL((dec_self_attn_kernel<TT, SV, NWV>), dim3(H, B), dim3(NWV * 64), 0, st, (const TT*)q, \
-                                              (const TT*)kc, (const TT*)vc, rows, (TT*)out, H, kb, stt)
+                                              (const TT*)kc, (const TT*)vc, rows, H, kb, (TT*)out, stt)
 #define SA_PICK(TT) do { if (nw == 1) SA_GO(TT, true, 1); else if (nw == 2) SA_GO(TT, true, 2); else if (single) SA_GO(TT, true, 4); \
                          else SA_GO(TT, false, 4); } while (0)
   if (dtype == 1) SA_PICK(bf16_t); else SA_PICK(float);
@@ -1421,9 +1435,9 @@ hipError_t launch_dec_cross_attn(int dtype, const void* q, const FusedQ& fq, con
   if (ksc || vsc) {  // fp8 K / V^T caches with per-key scales (TW_BF16_MXFP8 contexts)
     if (!ksc || !vsc || dtype != 1) return hipErrorInvalidValue;
     const size_t lds8 = (size_t)Tp * sizeof(float) * 2;
-#define CA8_GO(GV, FV) hipLaunchKernelGGL((dec_cross_attn_kv8_kernel<GV, FV>), dim3(H, B), dim3(512), lds8, st, (const bf16_t*)q, fq, \
-                                          (const unsigned char*)ck, (const unsigned char*)cv, ksc, vsc, (bf16_t*)out, H, T, Tp,       \
-                                          align_slot_for_head, align, Ha, P, stt)
+#define CA8_GO(GV, FV) hipLaunchKernelGGL((dec_cross_attn_kv8_kernel<GV, FV>), dim3(H, B), dim3(512), lds8, st,                        \
+                                          (const unsigned char*)ck, (const unsigned char*)cv, ksc, vsc, H, Tp, T, (const bf16_t*)q,  \
+                                          (bf16_t*)out, align_slot_for_head, align, Ha, P, stt, fq)
 #define CA8_PICK(FV) do { if (Tp <= 512) CA8_GO(1, FV); else if (Tp <= 1024) CA8_GO(2, FV); else if (Tp <= 1536) CA8_GO(3, FV);      \
                           else return hipErrorInvalidValue; } while (0)
     if (f) CA8_PICK(true); else CA8_PICK(false);
@@ -1432,8 +1446,8 @@ hipError_t launch_dec_cross_attn(int dtype, const void* q, const FusedQ& fq, con
     return hipGetLastError();
   }
   const size_t lds = (size_t)Tp * sizeof(float);
-#define CA_GO(TT, SV, FV) hipLaunchKernelGGL((dec_cross_attn_kernel<TT, SV, FV>), dim3(H, B), dim3(512), lds, st, (const TT*)q, fq,   \
-                                             (const TT*)ck, (const TT*)cv, (TT*)out, H, T, Tp, align_slot_for_head, align, Ha, P, stt)
+#define CA_GO(TT, SV, FV) hipLaunchKernelGGL((dec_cross_attn_kernel<TT, SV, FV>), dim3(H, B), dim3(512), lds, st, (const TT*)ck,      \
+                                             (const TT*)cv, H, Tp, T, (const TT*)q, (TT*)out, align_slot_for_head, align, Ha, P, stt, fq)
 #define CA_PICK(TT) do { if (single) { if (f) CA_GO(TT, true, true); else CA_GO(TT, true, false); }                                  \
                          else { if (f) CA_GO(TT, false, true); else CA_GO(TT, false, false); } } while (0)
   if (dtype == 1) CA_PICK(bf16_t); else CA_PICK(float);
