@@ -87,6 +87,8 @@ struct tw_ctx {
   SamplerPartial* sampler_partials = nullptr;
   unsigned* suppress_bits = nullptr;  // [(V+31)/32] static suppress list as a bitmap, rebuilt per generate call
   int* h_pinned = nullptr;  // pinned host scratch: finished ring [8][64] | n_valid [64] | DecState upload [16]
+  int* h_stage = nullptr;   // pinned staging of tw_generate_greedy: token table [Bmax][P] (up and down) | 3 x [Bmax] | suppress lists | DecState
+  size_t h_stage_ints = 0;
   hipEvent_t ring_ev[8]{};
   int last_seq_len = 0, last_n_prompt = 0;
   int dec_key_bound = 0;  // upper bound of decoder positions for the current decode (prompt + max new tokens)
@@ -222,6 +224,7 @@ int tw_destroy(tw_ctx* c) {
   for (auto& kv : c->step_graphs) (void)hipGraphExecDestroy(kv.second);
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
   for (int i = 0; i < 5; ++i) {
     if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
     if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
@@ -279,6 +282,8 @@ int tw_create(const tw_config* cfg, tw_ctx** out) {
   for (int i = 0; i < 5; ++i) { CHIP(hipEventCreate(&c->ev0[i])); CHIP(hipEventCreate(&c->ev1[i])); }
   for (int i = 0; i < 8; ++i) CHIP(hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming));
   CHIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_pinned), sizeof(int) * (8 * 64 + 64 + 16), hipHostMallocDefault));
+  c->h_stage_ints = (size_t)c->Bmax * c->P + 3 * (size_t)c->Bmax + 64 + 1024 + 16;
+  CHIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_stage), sizeof(int) * c->h_stage_ints, hipHostMallocDefault));
 
   const size_t e = c->esz;
   const size_t d = c->d, H = c->H, F = c->ffn, V = c->V, T = c->T, Tp = c->Tp, P = c->P, C = c->C, B = c->Bmax;
@@ -909,8 +914,16 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
   hipStream_t st = pick_stream(c, stream);
   const int P = c->P;
 
-  // ---- initial state ----
-  std::vector<int> hseq((size_t)B * P, o->pad_id), first(B), zeros(B, 0), neg(B, -1);
+  // ---- initial state: staged in PINNED memory, so the uploads are asynchronous and the loop's first launch follows them without a
+  //      host synchronisation (the staging area is not touched again before the stream synchronisation at the end of this call) ----
+  int* hseq = c->h_stage;                                  // [B][P]
+  int* first = hseq + (size_t)c->Bmax * P;                 // [B]
+  int* zeros = first + c->Bmax;
+  int* neg = zeros + c->Bmax;
+  int* bsup = neg + c->Bmax;                               // [64]
+  int* sup = bsup + 64;                                    // [1024]
+  DecState* s0p = reinterpret_cast<DecState*>(sup + 1024);
+  for (size_t i = 0; i < (size_t)B * P; ++i) hseq[i] = o->pad_id;
   for (int b = 0; b < B; ++b) {
     for (int i = 0; i < n_prompt; ++i) {
       const int t = prompt[(size_t)b * n_prompt + i];
@@ -918,19 +931,24 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
       hseq[(size_t)b * P + i] = t;
     }
     first[b] = prompt[(size_t)b * n_prompt];
+    zeros[b] = 0;
+    neg[b] = -1;
   }
-  HIPCHK(c, hipMemcpyAsync(c->seq, hseq.data(), sizeof(int) * hseq.size(), hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(c->cur_ids, first.data(), sizeof(int) * B, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(c->finished, zeros.data(), sizeof(int) * B, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(c->last_ts, neg.data(), sizeof(int) * B, hipMemcpyHostToDevice, st));
-  if (o->n_begin_suppress > 0)
-    HIPCHK(c, hipMemcpyAsync(c->begin_suppress_dev, o->begin_suppress, sizeof(int) * o->n_begin_suppress, hipMemcpyHostToDevice, st));
-  if (o->n_suppress > 0)
-    HIPCHK(c, hipMemcpyAsync(c->suppress_dev, o->suppress, sizeof(int) * o->n_suppress, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->seq, hseq, sizeof(int) * (size_t)B * P, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->cur_ids, first, sizeof(int) * B, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->finished, zeros, sizeof(int) * B, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->last_ts, neg, sizeof(int) * B, hipMemcpyHostToDevice, st));
+  if (o->n_begin_suppress > 0) {
+    memcpy(bsup, o->begin_suppress, sizeof(int) * o->n_begin_suppress);
+    HIPCHK(c, hipMemcpyAsync(c->begin_suppress_dev, bsup, sizeof(int) * o->n_begin_suppress, hipMemcpyHostToDevice, st));
+  }
+  if (o->n_suppress > 0) {
+    memcpy(sup, o->suppress, sizeof(int) * o->n_suppress);
+    HIPCHK(c, hipMemcpyAsync(c->suppress_dev, sup, sizeof(int) * o->n_suppress, hipMemcpyHostToDevice, st));
+  }
   HIPCHK(c, launch_suppress_bitmap(c->suppress_dev, o->n_suppress, c->suppress_bits, c->V, st));
-  DecState s0{0, n_prompt, max_len - 1, B};
-  HIPCHK(c, hipMemcpyAsync(c->stt, &s0, sizeof s0, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipStreamSynchronize(st));  // host staging vectors go out of scope below / pageable copies done
+  *s0p = DecState{0, n_prompt, max_len - 1, B};
+  HIPCHK(c, hipMemcpyAsync(c->stt, s0p, sizeof(DecState), hipMemcpyHostToDevice, st));
 
   SamplerArgs sa{};
   sa.logits = c->logits; sa.V = c->V; sa.B = B; sa.seq = c->seq; sa.seq_ld = P; sa.cur_ids = c->cur_ids;
@@ -985,11 +1003,18 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
   // two steps per graph launch: measured +2 % at one turbo stream, +0.3 % at 16 large-v3 streams (4 per launch: +3 % / +0.8 %, but
   // up to 7 steps past the last <eos> instead of 5); the finished flags are read LAG launches behind so the host never waits
   static const int group = []() { const char* e = getenv("TW_GRAPH_STEPS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
+  // while <eos> is still masked (min_new_tokens not reached) no stream can finish, so nothing is wasted by replaying more steps per
+  // launch: 8 at a time there (forced-length decoding, e.g. RTFx runs with a fixed token budget); the reference backend's calls
+  // set no minimum and always take the small group
+  static const int group_forced = []() { const char* e = getenv("TW_GRAPH_STEPS_FORCED"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
   const int LAG = std::max(1, 4 / group);
   int steps = 0, launches = 0;
   bool all_done = false;
   for (int s = 0; s < max_len - 1 && !all_done;) {
-    const int n = (use_graph && s + group <= max_len - 1) ? group : 1;   // steps in this launch
+    // step s produces the token at position s + 1, which can be <eos> only once s + 1 - n_prompt >= min_new_tokens
+    const bool eos_free = use_graph && group_forced > group && s + group_forced <= max_len - 1 &&
+                          s + group_forced - 1 < n_prompt + o->min_new_tokens - 1;
+    const int n = eos_free ? group_forced : ((use_graph && s + group <= max_len - 1) ? group : 1);   // steps in this launch
     const int last = s + n - 1;
     const int kb = std::min(((last + 64) / 64) * 64, ((max_len + 63) / 64) * 64);   // keys [0, kb) cover positions s .. last
     if (use_graph) {
@@ -1019,7 +1044,7 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
   }
   toc(c, 3, st);
   c->last_steps = steps;
-  HIPCHK(c, hipMemcpyAsync(hseq.data(), c->seq, sizeof(int) * hseq.size(), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(hseq, c->seq, sizeof(int) * (size_t)B * P, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
 
   // common sequence length exactly as HF's loop would have stopped: when the last row hit eos, or at max_len
