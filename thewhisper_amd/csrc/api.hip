@@ -1012,7 +1012,9 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
   bool all_done = false;
   for (int s = 0; s < max_len - 1 && !all_done;) {
     // step s produces the token at position s + 1, which can be <eos> only once s + 1 - n_prompt >= min_new_tokens
-    const bool eos_free = use_graph && group_forced > group && s + group_forced <= max_len - 1 &&
+    // (not for the first launch of a call: submitting a graph costs host time in proportion to its nodes, and the GPU is idle until
+    // the first one is in; a small first launch covers the submission of the big second one)
+    const bool eos_free = use_graph && launches >= 1 && group_forced > group && s + group_forced <= max_len - 1 &&
                           s + group_forced - 1 < n_prompt + o->min_new_tokens - 1;
     const int n = eos_free ? group_forced : ((use_graph && s + group <= max_len - 1) ? group : 1);   // steps in this launch
     const int last = s + n - 1;
