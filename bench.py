@@ -413,7 +413,7 @@ def main(argv=None):
     ap.add_argument("--latency-iters", type=int, default=100, help="single-stream chunk calls timed for the p50 (after 10 warm-ups; SURVEY.md section 8d)")
     ap.add_argument("--no-pipeline-leg", action="store_true", help="skip the measurement through ASRPipeline / BatchingHub")
     ap.add_argument("--no-secondary", action="store_true", help="skip the compact legs for BASELINE configs 2 (turbo, 30 s, 1 stream) and 5 (fp8, 15 s)")
-    ap.add_argument("--hub-rounds", type=int, default=6, help="requests per session in the hub measurement")
+    ap.add_argument("--hub-rounds", type=int, default=12, help="requests per session in the hub measurement")
     args = ap.parse_args(argv)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

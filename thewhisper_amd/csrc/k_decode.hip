@@ -1379,6 +1379,8 @@ static hipError_t skinny_launch(const GemvArgs& a, hipStream_t st) {
     if (a.tr != 0 && a.tr != 16) return hipErrorInvalidValue;
     return big ? skinny_launch_w8<16, 16>(a, st) : skinny_launch_w8<8, 16>(a, st);
   }
+  static const int nw_narrow = env_int("TW_SK_NW_NARROW", 8);  // wavefronts per 8-row tile of the N = 1280, K = 1280 projections (4: A/B)
+  if (a.tr == 8 && !big && nw_narrow == 4 && a.B <= 16) return skinny_launch_nw<T, 4, 8>(a, st);
   if (a.tr == 8) return big ? skinny_launch_nw<T, 16, 8>(a, st) : skinny_launch_nw<T, 8, 8>(a, st);
   if (a.tr == 4) return big ? skinny_launch_nw<T, 16, 4>(a, st) : skinny_launch_nw<T, 8, 4>(a, st);
   if (a.tr != 0 && a.tr != 16) return hipErrorInvalidValue;
