@@ -1068,8 +1068,8 @@ __global__ void suppress_bitmap_kernel(const int* __restrict__ list, int n, unsi
 //    passes.  Output per slice: best text token, best timestamp token, sum of exp(x - slice max) over timestamp tokens.
 //  * sampler_finish_kernel: ONE workgroup, wavefront b merges the slices of stream b (log-sum-exp merge), applies the
 //    "timestamp mass beats every text token" rule, appends the token, and thread 0 advances the position afterwards.
-// 8 slices of <= 13 x 512 logits per stream when many streams decode (8 x B workgroups cover the chip); 32 slices of <= 4 x 512
-// for a few streams (one stream would otherwise put the whole vocabulary on 8 CUs: 10 us of a turbo step's 220)
+// 32 slices of <= 4 x 512 logits per stream (one stream would otherwise put the whole vocabulary on 8 CUs: 10 us of a turbo step's
+// 220; at 16 streams 512 short workgroups also beat 128 long ones, see launch_sampler)
 constexpr int SAMPLER_NS_MAX = 32;
 
 struct SamplerMask {  // dynamic part of the mask: uniform scalars derived from the decoding state
@@ -1461,7 +1461,10 @@ hipError_t launch_dec_cross_attn(int dtype, const void* q, const FusedQ& fq, con
 hipError_t launch_sampler(const SamplerArgs& a0, hipStream_t st) {
   if (a0.B < 1 || a0.B > 64 || !a0.partials || !a0.suppress_bits) return hipErrorInvalidValue;
   SamplerArgs a = a0;
-  a.n_slices = a.B >= 8 ? 8 : 32;
+  // 32 vocabulary slices per stream (<= 4 x 512 logits per workgroup).  Until round 3 launches for >= 8 streams used 8 slices of 13 x 512
+  // ("8 x B workgroups cover the chip"); same-box A/B at 16 streams: 1.3824 -> 1.3759 ms per step with 32 (TW_SAMPLER_SLICES_MANY=8 restores it)
+  static const int many = env_int("TW_SAMPLER_SLICES_MANY", 32);
+  a.n_slices = a.B >= 8 ? (many == 8 ? 8 : 32) : 32;
   if (a.n_slices == 8) hipLaunchKernelGGL((sampler_part_kernel<8, 13>), dim3(8, a.B), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((sampler_part_kernel<32, 4>), dim3(32, a.B), dim3(256), 0, st, a);
   hipError_t e = hipGetLastError();
