@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -32,6 +33,9 @@ struct OpArgs {
   unsigned epoch;
   unsigned* err;
   unsigned long long* ts;    // [G][4] stamps
+  const u32x4* w_next;       // mode 5/6: the NEXT op's weight slice, pulled towards the chip (Infinity Cache) by this op
+  int next_u;                // ... its fragments per thread
+  int nt;                    // own weight loads non-temporal (1) or default policy (0)
 };
 
 template <int U, bool RA>
@@ -44,8 +48,24 @@ __global__ __launch_bounds__(512) void k_op(OpArgs a) {
   // ---- weights: everything in flight at once ----
   const u32x4* p = a.w + ((size_t)blockIdx.x * U) * 512 + tid;
   u32x4 v[U];
+  if (a.nt) {
 #pragma unroll
-  for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(p + (size_t)u * 512);
+    for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(p + (size_t)u * 512);
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = p[(size_t)u * 512];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // prefetch of the next op's slice (same block index, same shape): requested behind this op's own loads with the default cache
+  // policy, consumed (discarded) at the very end.  What is measured: does the next launch start faster when its weights are already
+  // on the chip (Infinity Cache; the per-XCD L2 is invalidated at the kernel boundary)?
+  constexpr int PF = U <= 5 ? U : 1;
+  u32x4 pf[PF] = {};
+  if (a.w_next) {
+    const u32x4* q = a.w_next + ((size_t)blockIdx.x * U) * 512 + tid;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) pf[u] = q[(size_t)u * 512];
+  }
   __builtin_amdgcn_sched_barrier(0);
   // ---- dependency ----
   if (RA) {
@@ -106,6 +126,12 @@ __global__ __launch_bounds__(512) void k_op(OpArgs a) {
       if (lane == 0) __hip_atomic_store(a.my_flags + blockIdx.x, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  if (a.w_next) {
+    unsigned z = 0;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) z ^= pf[u][0] ^ pf[u][3];
+    if (z == 0x0badf00du) a.y[0] = z;   // keeps the prefetch loads alive to the end of the kernel
+  }
   if (tid == 0 && a.ts) {
     unsigned long long* q = a.ts + (size_t)blockIdx.x * 4;
     q[0] = t0; q[1] = t1; q[2] = t2; q[3] = wall_clock64();
@@ -150,11 +176,14 @@ int main(int argc, char** argv) {
 
   for (int ci = 0; ci < n_cfg; ++ci) {
     const bool mixed = ci == n_cfg - 1;
-    for (int mode = 0; mode < 5; ++mode) {
+    for (int mode = 0; mode < 8; ++mode) {
+      if (const char* sel = getenv("RP_MODES")) { char key[3] = {(char)('0' + mode), 0, 0}; if (!strstr(sel, key)) continue; }
+      if (mode >= 5 && (mixed || cfgs[ci].U > 5)) continue;   // prefetch modes: uniform chains of the projection-like shapes
       // mode 0: boundary chain in a graph; 1: run-ahead 2 streams in a graph; 2: run-ahead 3 streams in a graph;
       // 3: run-ahead 2 streams, direct launches (no graph); 4: run-ahead kernels on ONE stream (flags + boundaries: overhead of the protocol)
-      const bool ra = mode != 0;
-      const int NS = mode == 0 ? 1 : (mode == 2 ? 3 : (mode == 4 ? 1 : 2));
+      // 5: boundary chain, every op prefetches the next op's slice, own loads default policy; 6: same, own loads nt; 7: boundary chain, default policy, no prefetch
+      const bool ra = mode >= 1 && mode <= 4;
+      const int NS = (mode == 0 || mode >= 4) ? 1 : (mode == 2 ? 3 : 2);
       const bool graph = mode != 3;
       auto enqueue = [&](bool with_ts) -> int {
         CK(hipMemsetAsync(flags, 0, (size_t)N * 512 * 4, sts[0]));
@@ -173,6 +202,9 @@ int main(int argc, char** argv) {
           o.dep_flags = i > 0 ? flags + (size_t)(i - 1) * 512 : nullptr; o.dep_g = prevG;
           o.my_flags = flags + (size_t)i * 512; o.epoch = (unsigned)(i + 1); o.err = err;
           o.ts = with_ts ? ts + (size_t)i * 512 * 4 : nullptr;
+          o.nt = (mode == 5 || mode == 7) ? 0 : 1;
+          o.next_u = U;
+          o.w_next = ((mode == 5 || mode == 6) && i + 1 < N && woff + (size_t)G * U * 512 * 2 < wbytes / 16) ? w + woff : nullptr;   // woff already points at the next op's slice
           launch_any(U, ra, G, o, sts[i % NS]);
           prevG = G;
         }
@@ -218,7 +250,8 @@ int main(int argc, char** argv) {
         prev_end = e1;
       }
       (void)s2s;
-      const char* mname[] = {"boundary/graph", "runahead2/graph", "runahead3/graph", "runahead2/direct", "flags+boundary/graph"};
+      const char* mname[] = {"boundary/graph", "runahead2/graph", "runahead3/graph", "runahead2/direct", "flags+boundary/graph",
+                             "prefetch-next/graph", "prefetch-next nt/graph", "boundary default-policy"};
       printf("%-22s %-22s: %6.2f us/op | resident span %.2f, entry->go %.2f, go->exit %.2f, end-to-end step %.2f | bad %d timeouts %u stale %u\n",
              mixed ? "mixed layer (7 ops)" : cfgs[ci].name, mname[mode], ms * 1e3 / (R * N), span / N * 0.01, wait / N * 0.01,
              post / N * 0.01, e2e / (N - 1) * 0.01, bad, herr[0], herr[1]);
