@@ -49,6 +49,16 @@ __device__ __forceinline__ f32x4_t mfma16<float>(const u32x4_t& a, const u32x4_t
   return acc;
 }
 
+// exp(x) for x <= 0 in the softmax.  Strict-f32 contexts keep the library expf (parity to 1e-6); bf16 contexts use the hardware
+// 2^x on x*log2(e) - one multiply and one transcendental instead of the library's range handling (the probabilities are rounded to
+// 8 mantissa bits for the P.V operand anyway).  The kernel is VALU-bound: per 64-key tile a wavefront issues ~34 exponentials next
+// to 32 MFMAs.
+template <typename T>
+__device__ __forceinline__ float attn_exp(float x) {
+  if constexpr (sizeof(T) == 4) return expf(x);
+  else return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+}
+
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   bf16x2_t v;
   v[0] = (bf16_t)lo;
@@ -176,14 +186,14 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ q, 
         }
       mx = tw_xor32_max(tw_xor16_max(mx));
       const float mnew = fmaxf(mrun[t], mx);
-      alpha[t] = expf(mrun[t] - mnew);
+      alpha[t] = attn_exp<T>(mrun[t] - mnew);
       mrun[t] = mnew;
       float ps = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = expf(s[t][kt][r] - mnew);
+          const float p = attn_exp<T>(s[t][kt][r] - mnew);
           s[t][kt][r] = p;
           ps += p;
         }
