@@ -608,6 +608,9 @@ def main(argv=None):
                                    if pmc else "no PMC summary under profiles/ was taken with this build's kernel sources (tools/profile_round.sh)"),
                 "algorithmic_bytes_per_step": int(alg_bytes / max(1, steps_per_call)),
                 "algorithmic_bytes_per_call": alg_bytes, "weight_bytes_per_step": W, "decode_steps_per_call": steps_per_call,
+                # what the launches really stream: the "cross query ahead" fusion reads 2 d^2 more weight elements per layer (DESIGN.md
+                # section 4) than SURVEY's 14 d^2; `achieved` / `frac` stay on SURVEY's algorithmic bytes, `traffic` is the counter
+                "weight_bytes_streamed_per_step": int(W + (wsz if wsz is not None else esz) * dims["dec_layers"] * 2 * dims["d_model"] ** 2),
                 "avg_step_ms": round(avg_step_ms, 4),
             },
         }
