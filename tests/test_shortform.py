@@ -140,3 +140,38 @@ def test_run_pass_accepts_chunks_from_different_calls():
         same(seq, alone[i]["sequences"][0], f"ids[{i}]")
         same(raw, alone[i]["token_timestamps"][0], f"ts[{i}]")
         same(seg, torch.cat([s["token_timestamps"] for s in alone[i]["segments"][0]]), f"segment ts[{i}]")
+
+
+def test_pass_assembled_in_groups_equals_one_group():
+    """shortform.Pass: chunks added as two groups (the hub's "leftovers first, late arrivals behind them") end exactly like the same
+    chunks decoded as one group - the engine's slot-offset entry points (tw_encode_at / tw_cross_kv_at) are used for the second group."""
+    from thewhisper_amd import shortform
+
+    pipe = build(batch_size=4)
+    model = pipe.model
+    feats = clip_features(pipe, 4, 10, seed0=70)
+    kw = dict(GK, return_timestamps=True, return_token_timestamps=True, return_segments=True)
+    model.generate(input_features=feats.input_features, attention_mask=feats.attention_mask, generation_config=pipe.generation_config, **kw)
+    plan, eng = model.last_plan, model.engine
+    nf = [int(x) for x in feats.attention_mask.sum(-1)]
+
+    def decode(groups):
+        works = [shortform.ChunkWork(feats.input_features[i], nf[i]) for i in range(4)]
+        p = shortform.Pass(eng, plan)
+        for g in groups:
+            p.add([works[i] for i in g])
+        assert p.free == 0
+        p.run()
+        return [shortform.work_tokens(plan, w) for w in works]
+
+    n0 = eng.calls["encode"]
+    one = decode([[0, 1, 2, 3]])
+    two = decode([[0, 1, 2], [3]])
+    three = decode([[0], [1, 2], [3]])
+    assert eng.calls["encode"] - n0 == 1 + 2 + 3
+    for a, b, c in zip(one, two, three):
+        same(list(a), list(b), "two groups")
+        same(list(a), list(c), "three groups")
+    with pytest.raises(ValueError):
+        p = shortform.Pass(eng, plan)
+        p.add([shortform.ChunkWork(feats.input_features[i % 4], nf[i % 4]) for i in range(5)])
