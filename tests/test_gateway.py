@@ -215,3 +215,96 @@ def test_websocket_session_streams_chunks_and_answers_like_the_process_route():
         with client.websocket_connect("/ws/stream?token=wrong"):
             pass
     hub.close()
+
+
+def test_session_table_limit_ttl_and_end_during_a_request():
+    """SessionHost without an engine: places in the table are taken while a scheduler is still being built (a burst of creates
+    cannot overshoot max_sessions), idle sessions leave after the TTL, and ending a session waits for the request that is
+    running on it before the detector stream is released."""
+    import time
+
+    from thewhisper_amd.gateway import HostBusy, SessionHost
+
+    class Backend:
+        sample_rate, chunk_length_s = 16000, 10
+
+        def transcribe(self, audio, t0, sr):
+            return []
+
+    gate, building = threading.Event(), threading.Event()
+
+    class SlowScheduler:
+        use_vad = True
+        _vad_buffer = np.zeros(0, np.float32)
+
+        def __init__(self, backend, chunk_length_s):
+            building.set()
+            gate.wait(10)
+
+        def add_new_chunk(self, a):
+            pass
+
+        def process_new_chunk(self):
+            in_request.set()
+            release.wait(10)
+            assert not vad.closed, "the detector stream was released under a running request"
+            return [], []
+
+    class VadStreamStub:
+        closed = False
+
+        def prefetch(self, a):
+            pass
+
+        def reset_states(self):
+            pass
+
+        def close(self):
+            VadStreamStub.closed = True
+
+    class VadStub:
+        launches = 0
+
+        def open_stream(self):
+            return vad
+
+    vad = VadStreamStub()
+    in_request, release = threading.Event(), threading.Event()
+    import thewhisper_amd.vad as vadmod
+
+    host = SessionHost(Backend(), scheduler_factory=SlowScheduler, max_sessions=1, session_ttl_s=0.05, vad=VadStub())
+    orig_attach, vadmod.attach_vad = vadmod.attach_vad, (lambda sched, vs: None)
+    try:
+        out = {}
+        t = threading.Thread(target=lambda: out.setdefault("sid", host.create()))
+        t.start()
+        assert building.wait(10)
+        with pytest.raises(HostBusy):      # the first session is not in the table yet, but its place is taken
+            host.create()
+        gate.set()
+        t.join(10)
+        sid = out["sid"]
+        assert host.health()["sessions"] == 1
+        # /end while /process is running: the stream is closed only after the request returned
+        p = threading.Thread(target=lambda: out.setdefault("res", host.process(sid)))
+        p.start()
+        assert in_request.wait(10)
+        e = threading.Thread(target=host.end, args=(sid,))
+        e.start()
+        time.sleep(0.05)
+        assert not vad.closed and host.health()["sessions"] == 0
+        release.set()
+        p.join(10)
+        e.join(10)
+        assert vad.closed and out["res"] == ([], [])
+        # TTL: an idle session makes room for a new one
+        VadStreamStub.closed = False
+        release.set()
+        s2 = host.create()
+        time.sleep(0.1)
+        s3 = host.create()
+        assert s2 != s3 and host.health()["sessions"] == 1 and VadStreamStub.closed
+        with pytest.raises(KeyError):
+            host.process(s2)
+    finally:
+        vadmod.attach_vad = orig_attach

@@ -109,24 +109,27 @@ class SessionHost:
         self.session_ttl_s = float(session_ttl_s)
         self.vad = vad                      # thewhisper_amd.vad.VadService or None (sessions then run with use_vad=False)
         self.sessions: Dict[str, Dict[str, Any]] = {}
+        self._creating = 0                  # sessions being built outside the table lock: they count against max_sessions
         self._lock = threading.Lock()
         # a bare backend has ONE tw_ctx, which is not thread-safe (include/thewhisper.h): serialise the engine calls of the
         # request threads.  Behind a hub the worker thread is the only caller.
         self._engine_lock = threading.Lock()
 
     # -- sessions ------------------------------------------------------------------------------------
-    def _evict_idle(self, now: float) -> int:
-        """Sessions nobody ended (a client that went away): dropped after ``session_ttl_s`` without a request."""
+    def _evict_idle(self, now: float) -> List[Dict[str, Any]]:
+        """Sessions nobody ended (a client that went away) leave the table after ``session_ttl_s`` without a request.  Called
+        with the table lock held; the caller ``_drop``s what is returned after releasing it."""
         dead = [k for k, v in self.sessions.items() if now - v["last_used"] > self.session_ttl_s and not v["lock"].locked()]
-        for k in dead:
-            self._drop(self.sessions.pop(k))
-        return len(dead)
+        return [self.sessions.pop(k) for k in dead]
 
     @staticmethod
     def _drop(sess: Dict[str, Any]):
+        """Releases what a session holds.  The session is already out of the table; a request that is still running on it (an
+        ``/end`` racing a ``/process``) finishes first - its scheduler may be asking the detector stream for frames."""
         vs = sess.get("vad")
         if vs is not None:
-            vs.close()
+            with sess["lock"]:
+                vs.close()
 
     def create(self, session_id: Optional[str] = None) -> str:
         import base64
@@ -137,19 +140,30 @@ class SessionHost:
         sid = session_id or base64.urlsafe_b64encode(os.urandom(16)).decode("ascii")     # as R:examples/server.py:122
         now = time.monotonic()
         with self._lock:
-            self._evict_idle(now)
-            if len(self.sessions) >= self.max_sessions:
-                raise HostBusy("too many sessions")
-        session_backend = self.hub.stream_backend() if self.hub is not None else _LockedBackend(self.base_backend, self._engine_lock)
-        sched = self.make_scheduler(session_backend, self.base_backend.chunk_length_s)
-        vs = None
-        if self.vad is not None:
-            from .vad import attach_vad
+            dead = self._evict_idle(now)
+            full = len(self.sessions) + self._creating >= self.max_sessions
+            if not full:
+                self._creating += 1         # the scheduler is built outside the lock (it may be slow); the place is taken now
+        for d in dead:
+            self._drop(d)
+        if full:
+            raise HostBusy("too many sessions")
+        sess = None
+        try:
+            session_backend = self.hub.stream_backend() if self.hub is not None else _LockedBackend(self.base_backend, self._engine_lock)
+            sched = self.make_scheduler(session_backend, self.base_backend.chunk_length_s)
+            vs = None
+            if self.vad is not None:
+                from .vad import attach_vad
 
-            vs = self.vad.open_stream()
-            attach_vad(sched, vs)
-        with self._lock:
-            self.sessions[sid] = {"scheduler": sched, "lock": threading.Lock(), "last_used": now, "vad": vs}
+                vs = self.vad.open_stream()
+                attach_vad(sched, vs)
+            sess = {"scheduler": sched, "lock": threading.Lock(), "last_used": now, "vad": vs}
+        finally:
+            with self._lock:
+                self._creating -= 1
+                if sess is not None:
+                    self.sessions[sid] = sess
         return sid
 
     def _get(self, sid: str) -> Dict[str, Any]:
