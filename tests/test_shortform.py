@@ -175,3 +175,41 @@ def test_pass_assembled_in_groups_equals_one_group():
     with pytest.raises(ValueError):
         p = shortform.Pass(eng, plan)
         p.add([shortform.ChunkWork(feats.input_features[i % 4], nf[i % 4]) for i in range(5)])
+
+
+def test_call_wider_than_the_engine_and_a_decoder_that_never_advances():
+    """generate_shortform on more rows than the engine holds runs several passes per seek iteration with unchanged results;
+    a decoder that closes every segment at <|0.00|> (seek never advances - HF's loop would spin forever) raises."""
+    from thewhisper_amd import shortform
+
+    pipe = build(batch_size=4)
+    model = pipe.model
+    feats = clip_features(pipe, 4, 10, seed0=90)
+    kw = dict(GK, return_timestamps=True, return_token_timestamps=True, return_segments=True)
+    ref = model.generate(input_features=feats.input_features, attention_mask=feats.attention_mask, generation_config=pipe.generation_config, **kw)
+    plan, eng = model.last_plan, model.engine
+
+    class Narrow:      # the same engine with room for 3 rows
+        max_batch = 3
+
+        def __getattr__(self, k):
+            return getattr(eng, k)
+
+    got = shortform.generate_shortform(Narrow(), plan, feats.input_features, feats.attention_mask)
+    same(got["sequences"], ref["sequences"], "ids")
+    same(got["token_timestamps"], ref["token_timestamps"], "ts")
+
+    tb = plan.timestamp_begin
+
+    class Stuck(Narrow):
+        def generate_greedy(self, prompt, **kw):
+            B = prompt.shape[0]
+            tail = np.tile(np.array([[tb, 7, tb, tb, 9]], dtype=np.int32), (B, 1))   # "<|0.00|> w <|0.00|><|0.00|> w": seek += 0
+            seq = np.concatenate([np.asarray(prompt, np.int32), tail], axis=1)
+            return {"sequences": seq, "length": seq.shape[1]}
+
+        def token_timestamps(self, B, n_prompt, L, nf, tp):
+            return np.zeros((B, L), np.float32)
+
+    with pytest.raises(RuntimeError, match="seek passes"):
+        shortform.generate_shortform(Stuck(), plan, feats.input_features[:2], feats.attention_mask[:2])

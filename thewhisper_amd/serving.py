@@ -221,8 +221,8 @@ class BatchingHub:
                 self.passes += 1
                 pas.run()
                 for w in works:
-                    if w.passes > 64:
-                        raise RuntimeError("a chunk needed more than 64 seek passes (the decoder keeps seeking to frame 0)")
+                    if w.passes > shortform.MAX_SEEK_PASSES:
+                        raise RuntimeError(f"a chunk needed more than {shortform.MAX_SEEK_PASSES} seek passes (the decoder keeps seeking to frame 0)")
             except Exception as e:  # noqa: BLE001  (engine failure: every request that had a chunk in this pass fails)
                 fail_jobs_of(works, e)
                 continue

@@ -33,6 +33,9 @@ import torch
 import torch.nn.functional as F
 
 
+MAX_SEEK_PASSES = 64    # a 30 s chunk advances by >= 1 timestamp step (0.02 s) per useful pass; far more than any real transcript needs
+
+
 @dataclasses.dataclass
 class ShortFormPlan:
     """Everything one pass needs that does not depend on the audio (learned from one HF-driven call)."""
@@ -282,9 +285,14 @@ def generate_shortform(engine, plan: ShortFormPlan, input_features: torch.Tensor
     if plan.return_token_timestamps and attention_mask is not None:
         nf = [int(x) for x in attention_mask.sum(-1).cpu().tolist()]          # HF:...:1694-1695
     works = [ChunkWork(input_features[i], nf[i]) for i in range(B)]
+    cap = int(engine.max_batch)
     while True:
         active = [w for w in works if not w.done]                              # HF:...:790-795 (the batch shrinks)
         if not active:
             break
-        run_pass(engine, plan, active)
+        for i in range(0, len(active), cap):                                   # a call wider than the engine: several passes per iteration
+            run_pass(engine, plan, active[i : i + cap])
+        if any(w.passes > MAX_SEEK_PASSES for w in active):
+            # a decoder that keeps closing its segments at <|0.00|> never advances `seek`; HF's loop spins forever on such a row
+            raise RuntimeError(f"a chunk needed more than {MAX_SEEK_PASSES} seek passes (the decoder keeps seeking to frame 0)")
     return assemble(plan, works, input_features.device)
