@@ -547,6 +547,9 @@ static hipError_t gemm_dispatch(const void* A, RowMap amap, const void* W, int M
   //   1: 128 x 64;  0: 64 x 64  - small M (single stream): enough workgroups to cover the chip
   static const int forced = gemm_env("TW_GEMM_CFG", -1);
   static const int narrow = gemm_env("TW_GEMM_NARROW", 5);   // tile config for N <= 2048 at large M (experiments)
+  // kernel 2 from this many 128 x 128 tiles on: 128 x 256 tiles need >= 256 workgroups to cover the chip.  One 30 s chunk's fc1
+  // (M = 1500, N = 5120: 480 tiles = 240 workgroups) is faster in 128 x 64 tiles (encoder 6.27 -> 6.00 ms, profiles/r03_gemm_tiles.txt)
+  static const int wreg_min = gemm_env("TW_GEMM_WREG_MIN", 512);
   const long long b128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
   int cfg;
   if (ep.mode == EPI_KV_CROSS8) {   // fp8 cross-K/V epilogue: one head per wavefront, i.e. kernel 2 whatever the shape
@@ -554,7 +557,7 @@ static hipError_t gemm_dispatch(const void* A, RowMap amap, const void* W, int M
     return gemm_wreg_go<T, 128, 4, 3>(A, amap, W, M, N, K, ep, st);
   }
   if (forced >= 0) cfg = forced;
-  else if (N % 256 == 0 && b128 >= 384) cfg = (N <= 2048) ? narrow : 5;
+  else if (N % 256 == 0 && b128 >= wreg_min) cfg = (N <= 2048) ? narrow : 5;
   else if (M > 64) cfg = 1;
   else cfg = 0;
   switch (cfg) {
