@@ -261,7 +261,10 @@ GREEDY_CASES = [("micro", 100, 1, 24, False, 0), ("micro", 100, 3, 24, True, 0),
                 ("micro80", 100, 2, 24, False, 0), ("micro", 100, 16, 20, True, 0), ("micro", 750, 2, 24, True, 0),
                 ("micro", 100, 33, 12, True, 0),
                 # 200 positions: the step graphs of the 64 / 128 / 192 / 256-key self-attention buckets (1, 2 and 4 wavefronts)
-                ("micro", 100, 2, 200, True, 200), ("micro", 100, 3, 150, False, 150)]
+                ("micro", 100, 2, 200, True, 200), ("micro", 100, 3, 150, False, 150),
+                # the maxima of the boundary: all 448 decoder positions (every self-attention bucket up to 448 keys; the loop must stop at
+                # max_length whatever max_new_tokens says), and the 64 streams a context can hold
+                ("micro", 100, 2, 500, True, 500), ("micro", 100, 64, 6, True, 0)]
 
 
 @pytest.mark.parametrize("preset,T,B,max_new,graph,min_new", GREEDY_CASES)
