@@ -63,6 +63,8 @@ ENC_CASES = [
     ("micro", 100, 2, "bf16", 2, 3e-2, {}), ("micro", 500, 4, "bf16", 2, 3e-2, {}),
     ("large-v3", 500, 1, "f32", 1, 2e-5, {}), ("large-v3", 500, 4, "bf16", 1, 3e-2, {}),
     ("tiny.en", 1500, 1, "f32", 4, 5e-5, {}), ("micro", 100, 1, "f32", 0, 2e-5, {}),
+    # chunk lengths whose frame count is no multiple of the 64-key tiles: 1 s (less than one tile), 25 s, 29 s
+    ("micro", 50, 2, "f32", 2, 2e-5, {}), ("micro", 1250, 1, "f32", 2, 2e-5, {}), ("micro", 1450, 2, "bf16", 2, 3e-2, {}),
 ]
 
 
@@ -99,6 +101,7 @@ DEC_CASES = [
     ("micro", 750, 2, "f32", 2, 2e-5), ("micro", 750, 3, "bf16", 2, 3e-2),   # 15 s chunks: two key chunks, second one partial
     ("micro", 100, 17, "f32", 2, 2e-5), ("micro", 100, 40, "bf16", 2, 3e-2), ("micro", 100, 64, "f32", 1, 2e-5),  # > 16 streams: groups of 16
     ("large-v3", 500, 32, "bf16", 1, 3e-2),
+    ("micro", 50, 2, "f32", 2, 2e-5), ("micro", 1250, 2, "f32", 2, 2e-5), ("micro", 1450, 3, "bf16", 2, 3e-2),   # ragged last key tile
 ]
 
 
@@ -167,7 +170,8 @@ def test_cross_query_ahead_matches_the_plain_launch_sequence(preset, T, B, dtype
     eng.close()
 
 
-FP8_CASES = [("micro", 100, 3, 0), ("micro", 100, 3, 1), ("micro", 100, 16, 2), ("large-v3", 500, 2, 1), ("tiny.en", 1500, 1, 2)]
+FP8_CASES = [("micro", 100, 3, 0), ("micro", 100, 3, 1), ("micro", 100, 16, 2), ("large-v3", 500, 2, 1), ("tiny.en", 1500, 1, 2),
+             ("micro", 50, 2, 1), ("micro", 1250, 2, 2)]   # fp8 cross-K/V: less than one 64-key group, three groups with a ragged last one
 
 
 @pytest.mark.parametrize("preset,T,B,layers", FP8_CASES)
