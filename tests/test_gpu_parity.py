@@ -268,7 +268,9 @@ GREEDY_CASES = [("micro", 100, 1, 24, False, 0), ("micro", 100, 3, 24, True, 0),
                 ("micro", 100, 2, 200, True, 200), ("micro", 100, 3, 150, False, 150),
                 # the maxima of the boundary: all 448 decoder positions (every self-attention bucket up to 448 keys; the loop must stop at
                 # max_length whatever max_new_tokens says), and the 64 streams a context can hold
-                ("micro", 100, 2, 500, True, 500), ("micro", 100, 64, 6, True, 0)]
+                ("micro", 100, 2, 500, True, 500), ("micro", 100, 64, 6, True, 0),
+                # the largest word-timestamp problem of the path: 445 tokens x 1500 frames (30 s chunk), one row with a negative frame bound
+                ("micro", 1500, 2, 500, True, 500)]
 
 
 @pytest.mark.parametrize("preset,T,B,max_new,graph,min_new", GREEDY_CASES)
