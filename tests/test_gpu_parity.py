@@ -440,6 +440,44 @@ def test_large_v3_full_size_properties():
     eng.close()
 
 
+def test_large_v3_maximum_context_properties():
+    """The largest context the boundary admits - whisper-large-v3, 30 s chunks (T = 1500), 64 streams, bf16: ~16 GB of cross-K/V, four
+    groups of 16 streams per projection launch, three 512-key rounds per cross-attention head.  Properties as above."""
+    import bench
+
+    dims = bench.DIMS["large-v3"]
+    from thewhisper_amd.engine import WhisperEngine
+
+    heads = bench.alignment_heads(dims)
+    eng = WhisperEngine(dims, 1500, max_batch=64, dtype="bf16", alignment_heads=heads)
+    eng.load_state_dict(bench.random_state_dict(dims, torch.device("cuda", 0), seed=0))
+    kinds = ["speechlike", "noise", "sine", "speechlike"]
+    pcm = torch.from_numpy(clips(480000, [kinds[i % 4] for i in range(64)])).cuda()
+    pcm[17] = pcm[0]
+    pcm[63] = pcm[0]
+
+    def run(nb):
+        eng.encode(eng.logmel(pcm[:nb]))
+        eng.cross_kv(nb)
+        prompt = np.tile(np.array(PROMPT, dtype=np.int32), (nb, 1))
+        out = eng.generate_greedy(prompt, max_new_tokens=24, timestamps=True, want_alignment=True)
+        ts = eng.token_timestamps(nb, 3, out["length"], [3000] * nb)
+        return out["sequences"], ts, eng.get_alignment(nb, out["length"] - 1)
+
+    s, t, a = run(64)
+    s2, t2, _ = run(64)
+    assert np.array_equal(s, s2) and np.array_equal(t, t2)
+    for j in (17, 63):                                                     # same audio in another group of 16 streams -> same result
+        assert np.array_equal(s[0], s[j]) and np.array_equal(t[0], t[j])
+    s1, _, _ = run(1)
+    n = min(s1.shape[1], s.shape[1])
+    assert np.array_equal(s1[0, :n], s[0, :n])
+    assert (s >= 0).all() and (s < dims["vocab"]).all()
+    assert a.shape[-1] == 1500 and np.abs(a.sum(-1) - 1.0).max() < 2e-3
+    assert (np.diff(t[:, 3:], axis=1) >= -1e-6).all() and t.min() >= 0 and t.max() <= 30.0
+    eng.close()
+
+
 def test_batching_hub_on_gpu_matches_reference_golden():
     """§8f row 1: four concurrent sessions share one MI355X engine through the BatchingHub; every session still gets the
     reference's per-stream result, and requests from different sessions are executed as one batch."""
