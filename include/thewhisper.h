@@ -123,8 +123,8 @@ int tw_logmel(tw_ctx* ctx, const float* pcm_dev, int64_t pcm_stride, const int32
               int32_t n_samples, void* out_dev, int32_t out_dtype, void* stream);
 
 /* A2-A4.  Replaces: WhisperEncoder.forward (HF:models/whisper/modeling_whisper.py:540-646).
- * mel_dev: [B, n_mels, 2T] of mel_dtype.  The encoder output is kept inside the context (slots
- * 0..B-1); if out_hidden_dev != NULL it is also written there as [B, T, d_model] in out_dtype. */
+ * mel_dev: [B, n_mels, 2T] of mel_dtype (TW_F32 / TW_BF16 / TW_F16).  The encoder output is kept inside the context (slots
+ * 0..B-1); if out_hidden_dev != NULL it is also written there as [B, T, d_model] in out_dtype (TW_F32 / TW_BF16). */
 int tw_encode(tw_ctx* ctx, const void* mel_dev, int32_t mel_dtype, int32_t B, void* out_hidden_dev,
               int32_t out_dtype, void* stream);
 

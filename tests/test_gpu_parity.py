@@ -594,3 +594,75 @@ def test_slots_filled_in_groups_give_the_one_group_results(dtype):
             eng.encode(mel[:5], slot0=4)
     finally:
         eng.close()
+
+
+def test_c_abi_error_behaviour():
+    """include/thewhisper.h: every entry point answers misuse with a negative TW_E* code and a message in tw_last_error - no
+    exception crosses the boundary, nothing is launched - and the context stays usable: the valid call that follows gives the
+    oracle's result."""
+    import ctypes as C
+
+    dims = wo.PRESETS["micro"]
+    w = wo.make_weights(dims, 0)
+    eng = make_engine(dims, w, T=100, max_batch=2, dtype="f32")
+    lib, ctx, sp = eng.lib, eng.ctx, eng._sp()
+    TW_EINVAL, TW_ESTATE = -1, -3
+
+    def refused(rc, codes=(TW_EINVAL, TW_ESTATE)):
+        assert rc in codes, (rc, lib.tw_last_error(ctx).decode())
+        assert len(lib.tw_last_error(ctx)) > 0
+    try:
+        pcm = clips(32000, 2)
+        # call order: decoding before any chunk was encoded
+        ids = (C.c_int32 * 2)(50258, 50258)
+        refused(lib.tw_cross_kv(ctx, 2, sp))
+        refused(lib.tw_decoder_reset(ctx, 2, sp))
+        refused(lib.tw_decode_step(ctx, 2, ids, None, sp))
+        mel = eng.logmel(torch.from_numpy(pcm).cuda(), out_dtype=torch.float32)
+        mp = C.c_void_p(mel.data_ptr())
+        # batch outside 1 .. max_batch, null operands, unknown dtypes
+        refused(lib.tw_encode(ctx, mp, 0, 0, None, 0, sp))
+        refused(lib.tw_encode(ctx, mp, 0, 3, None, 0, sp))
+        refused(lib.tw_encode(ctx, None, 0, 2, None, 0, sp))
+        refused(lib.tw_encode(ctx, mp, 77, 2, None, 0, sp))
+        hid = torch.empty((2, 100, dims.d_model), device="cuda")
+        refused(lib.tw_encode(ctx, mp, 0, 2, C.c_void_p(hid.data_ptr()), 2, sp))                          # hidden states as fp16: not offered
+        refused(lib.tw_logmel(ctx, None, 32000, None, 2, 32000, mp, 0, sp))
+        refused(lib.tw_logmel(ctx, C.c_void_p(mel.data_ptr()), 32000, None, 2, 32001, mp, 0, sp))     # not a whole number of hops
+        eng.encode(mel)
+        refused(lib.tw_cross_kv(ctx, 3, sp))
+        refused(lib.tw_cross_kv_at(ctx, 1, 2, sp))
+        eng.cross_kv(2)
+        # greedy call: prompt that does not fit, null outputs, more streams than were encoded
+        from thewhisper_amd import _cabi
+
+        o = _cabi.tw_greedy_opts()
+        o.eos_id = o.pad_id = 50257
+        o.max_new_tokens, o.min_new_tokens, o.max_length = 4, 0, 448
+        o.no_timestamps_id, o.max_initial_timestamp_index = 50364, 50
+        prompt = np.tile(np.array(PROMPT, dtype=np.int32), (2, 1))
+        pp = prompt.ctypes.data_as(C.POINTER(C.c_int32))
+        out = np.zeros((2, 448), np.int32)
+        op = out.ctypes.data_as(C.POINTER(C.c_int32))
+        n = C.c_int32(0)
+        refused(lib.tw_generate_greedy(ctx, 3, pp, 3, C.byref(o), op, C.byref(n), sp))
+        refused(lib.tw_generate_greedy(ctx, 2, pp, 0, C.byref(o), op, C.byref(n), sp))
+        refused(lib.tw_generate_greedy(ctx, 2, pp, 449, C.byref(o), op, C.byref(n), sp))
+        refused(lib.tw_generate_greedy(ctx, 2, None, 3, C.byref(o), op, C.byref(n), sp))
+        refused(lib.tw_generate_greedy(ctx, 2, pp, 3, None, op, C.byref(n), sp))
+        refused(lib.tw_generate_greedy(ctx, 2, pp, 3, C.byref(o), None, C.byref(n), sp))
+        # word timestamps without recorded alignment rows
+        ts = np.zeros((2, 8), np.float32)
+        refused(lib.tw_token_timestamps(ctx, 2, 3, 8, None, 0.02, ts.ctypes.data_as(C.POINTER(C.c_float)), sp))
+        # unknown weight name / wrong shape after construction
+        t = torch.zeros(4, device="cuda")
+        shape = (C.c_int64 * 1)(4)
+        assert lib.tw_load_weight(ctx, b"model.no.such.tensor", C.c_void_p(t.data_ptr()), 0, 1, shape, sp) < 0
+        assert lib.tw_finalize_weights(ctx, sp) < 0                                                    # "call exactly once"
+        # ... and the context still works
+        got = eng.generate_greedy(prompt, max_new_tokens=12, timestamps=True)
+        om = wo.OracleWhisper(dims, w, T=100)
+        ref = wo.greedy_generate(om, om.encode(wo.log_mel(pcm, dims.n_mels)), prompt, wo.GreedyOptions(max_new_tokens=12, timestamps=True))
+        assert np.array_equal(got["sequences"], ref["sequences"])
+    finally:
+        eng.close()

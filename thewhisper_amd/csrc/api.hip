@@ -661,6 +661,8 @@ int encode_core(tw_ctx* c, const void* mel, int32_t mel_dtype, int32_t B, int32_
   if (!c->finalized) return fail(c, TW_ESTATE, "tw_encode before tw_finalize_weights");
   if (B < 1 || slot0 < 0 || slot0 + B > c->Bmax) return fail(c, TW_EINVAL, "tw_encode: slots [%d, %d) outside [0,%d)", slot0, slot0 + B, c->Bmax);
   if (slot0 > c->encoded_B) return fail(c, TW_ESTATE, "tw_encode_at: slot0=%d but only %d slots are filled", slot0, c->encoded_B);
+  if (mel_dtype != TW_F32 && mel_dtype != TW_BF16 && mel_dtype != TW_F16) return fail(c, TW_EINVAL, "tw_encode: mel_dtype %d is not TW_F32 / TW_BF16 / TW_F16", mel_dtype);
+  if (out_hidden && out_dtype != TW_F32 && out_dtype != TW_BF16) return fail(c, TW_EINVAL, "tw_encode: out_dtype %d is not TW_F32 / TW_BF16", out_dtype);
   hipStream_t st = pick_stream(c, stream);
   const int d = c->d, T = c->T, C = c->C, H = c->H, F = c->ffn, dt = c->dtype;
   const size_t e = c->esz;
