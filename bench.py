@@ -605,7 +605,7 @@ def main(argv=None):
                 "traffic": (round(pmc[0]["hbm_bytes_per_step"]) if pmc else None),
                 "traffic_source": (f"profiles/{pmc[1]}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command line with THESE kernels "
                                    f"(kernel_source_sha256 matches the running build), FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md)"
-                                   if pmc else "no PMC summary under profiles/ was taken with this build's kernel sources (tools/profile_round.sh)"),
+                                   if pmc else "no PMC summary under profiles/ for this workload (model, streams, chunk length, dtype, new tokens) taken with this build's kernel sources (tools/profile_round.sh)"),
                 "algorithmic_bytes_per_step": int(alg_bytes / max(1, steps_per_call)),
                 "algorithmic_bytes_per_call": alg_bytes, "weight_bytes_per_step": W, "decode_steps_per_call": steps_per_call,
                 # what the launches really stream: the "cross query ahead" fusion reads 2 d^2 more weight elements per layer (DESIGN.md
