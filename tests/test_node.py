@@ -62,3 +62,42 @@ def test_sessions_are_sticky_and_batched_per_rank(router):
     w0 = router.transcribe(clips[0], 16000)
     w1 = router.transcribe(clips[0], 16000)
     assert normalise(w0) == normalise(w1) == normalise(direct.transcribe(clips[0], 0.0, 16000))
+
+
+def test_a_dead_worker_takes_only_its_sessions_with_it(router):
+    """Rank 1's process is killed: its sessions answer 404, a request in flight fails with WorkerGone (503 at the HTTP layer), new
+    sessions and stateless requests go to the surviving rank, health says who is alive, close() does not hang."""
+    fastapi = pytest.importorskip("fastapi")
+    from fastapi.testclient import TestClient
+
+    from thewhisper_amd.gateway import create_app
+    from thewhisper_amd.node import WorkerGone
+
+    client = TestClient(create_app(router, model_name="micro"))
+    a, b = router.create(), router.create()
+    ra, rb = router.rank_of(a), router.rank_of(b)
+    assert {ra, rb} == {0, 1}
+    dead_sid, live_sid = (a, b) if ra == 1 else (b, a)
+    router.workers[1].proc.kill()
+    router.workers[1].proc.join(30)
+    for _ in range(200):                      # the reader thread notices the closed pipe
+        if not router.workers[1].alive:
+            break
+        import time
+        time.sleep(0.05)
+    assert not router.workers[1].alive
+    with pytest.raises(WorkerGone):
+        router.call(1, "health")
+    assert client.post(f"/session/{dead_sid}/process").status_code == 404
+    clip = wo.synth_audio(16000, 5, "speechlike")
+    q = base64.b64encode(clip[:8000].astype(np.float32).tobytes()).decode()
+    assert client.post(f"/session/{live_sid}/add_chunk", params={"audio_data": q}).status_code == 200
+    assert client.post(f"/session/{live_sid}/process").status_code == 200
+    h = client.get("/health").json()
+    assert h["alive"] == 1 and [r["alive"] for r in h["ranks"]] == [True, False]
+    new = [client.post("/session/create/").json()["session_id"] for _ in range(3)]
+    assert [router.rank_of(s) for s in new] == [0, 0, 0]
+    assert isinstance(router.transcribe(clip, 16000), list) and isinstance(router.transcribe(clip, 16000), list)
+    assert client.post(f"/session/{dead_sid}/end").json() == {"status": "success"}      # ending a lost session is not an error
+    for s in new + [live_sid]:
+        router.end(s)

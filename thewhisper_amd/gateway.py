@@ -284,6 +284,8 @@ def create_app(backend, auth_token: str = "", model_name: str = "", lang_id: Opt
         except HTTPException:
             raise
         except Exception as e:  # noqa: BLE001
+            if type(e).__name__ == "WorkerGone":   # node.py: the GPU's serving process died under the request; its sessions are gone
+                raise HTTPException(status_code=503, detail=str(e), headers={"Retry-After": "1"}) from e
             raise HTTPException(status_code=500, detail=str(e)) from e
 
     @app.post("/session/create/")

@@ -11,6 +11,10 @@ the ranks never talk to each other.  The HTTP process (``gateway.create_app(Node
 
 Each worker serves its pipe from a small thread pool so that the requests of its sessions meet in the hub's passes exactly
 as they do in the single-GPU gateway.  ``python -m thewhisper_amd.gateway --gpus N ...`` builds this.
+
+A worker that dies (a GPU fault takes its process down) takes its sessions with it - their scheduler state lived there: requests
+in flight fail with ``WorkerGone`` (HTTP 503), the sessions answer 404 from then on, new sessions and stateless requests go to the
+surviving ranks, ``health()`` reports which ranks are alive.  Workers are not respawned here: that is the process supervisor's job.
 """
 from __future__ import annotations
 
@@ -24,7 +28,7 @@ from typing import Any, Dict, Optional, Tuple
 
 import numpy as np
 
-__all__ = ["NodeRouter", "worker_main"]
+__all__ = ["NodeRouter", "WorkerGone", "worker_main"]
 
 
 def _resolve(spec: str):
@@ -83,6 +87,7 @@ class _Worker:
         self.pending: Dict[int, Future] = {}
         self.pending_lock = threading.Lock()
         self.hello: Future = Future()
+        self.alive = True                    # False once the pipe closed (the process died or was stopped)
         self.reader = threading.Thread(target=self._read, name=f"tw-router-rank{rank}", daemon=True)
         self.reader.start()
 
@@ -91,8 +96,9 @@ class _Worker:
             try:
                 req_id, ok, payload = self.conn.recv()
             except (EOFError, OSError):
-                err = RuntimeError(f"worker {self.rank} went away")
+                err = WorkerGone(f"worker {self.rank} went away")
                 with self.pending_lock:
+                    self.alive = False
                     futs, self.pending = list(self.pending.values()), {}
                 for f in futs:
                     if not f.done():
@@ -111,6 +117,10 @@ class _Worker:
                 fut.set_result(payload)
             else:
                 fut.set_exception(_rebuild_error(payload))
+
+
+class WorkerGone(RuntimeError):
+    """The serving process of a GPU is no longer there: its sessions are lost (their state lived in that process)."""
 
 
 def _rebuild_error(payload: Tuple[str, Any]) -> BaseException:
@@ -153,14 +163,27 @@ class NodeRouter:
             req_id = next(self._ids)
         fut: Future = Future()
         with w.pending_lock:
+            if not w.alive:
+                raise WorkerGone(f"worker {rank} went away")
             w.pending[req_id] = fut
-        with w.send_lock:
-            w.conn.send((req_id, op, args))
+        try:
+            with w.send_lock:
+                w.conn.send((req_id, op, args))
+        except (OSError, ValueError) as e:       # the pipe broke between the check and the send
+            with w.pending_lock:
+                w.pending.pop(req_id, None)
+            raise WorkerGone(f"worker {rank} went away") from e
         return fut.result(timeout=timeout)
+
+    def _alive_ranks(self):
+        return [w.rank for w in self.workers if w.alive]
 
     def rank_of(self, sid: str) -> int:
         with self._lock:
             r = self._session_rank.get(sid)
+            if r is not None and not self.workers[r].alive:    # the session's state died with its process
+                del self._session_rank[sid]
+                r = None
         if r is None:
             raise KeyError(sid)
         return r
@@ -169,10 +192,17 @@ class NodeRouter:
     def create(self) -> str:
         import base64
 
+        from .gateway import HostBusy
+
         sid = base64.urlsafe_b64encode(os.urandom(16)).decode("ascii")
         with self._lock:
             rank = self._created % self.world          # dist.shard_streams: stream_id % world
             self._created += 1
+        if not self.workers[rank].alive:               # a GPU's process died: its share of the new sessions goes to the survivors
+            alive = self._alive_ranks()
+            if not alive:
+                raise HostBusy("no serving process is alive")
+            rank = alive[rank % len(alive)]
         self.call(rank, "create", sid)
         with self._lock:
             self._session_rank[sid] = rank
@@ -190,22 +220,39 @@ class NodeRouter:
     def end(self, sid: str) -> None:
         with self._lock:
             rank = self._session_rank.pop(sid, None)
-        if rank is not None:
-            self.call(rank, "end", sid)
+        if rank is not None and self.workers[rank].alive:
+            try:
+                self.call(rank, "end", sid)
+            except WorkerGone:
+                pass
 
     def transcribe(self, audio: np.ndarray, sr: int):
+        from .gateway import HostBusy
+
         with self._lock:
             rank = self._rr % self.world
             self._rr += 1
+        if not self.workers[rank].alive:
+            alive = self._alive_ranks()
+            if not alive:
+                raise HostBusy("no serving process is alive")
+            rank = alive[rank % len(alive)]
         return self.call(rank, "transcribe", np.ascontiguousarray(audio), sr)
 
     def health(self) -> Dict[str, Any]:
-        per = [self.call(r, "health", timeout=30) for r in range(self.world)]
+        per = []
+        for r in range(self.world):
+            try:
+                per.append({**self.call(r, "health", timeout=30), "alive": True})
+            except Exception:  # noqa: BLE001  (gone, or not answering within the timeout)
+                per.append({"passes": None, "sessions": 0, "vad_launches": None, "alive": False})
         return {"passes": sum(p["passes"] or 0 for p in per), "sessions": sum(p["sessions"] for p in per),
-                "ranks": per, "world": self.world}
+                "ranks": per, "world": self.world, "alive": sum(1 for p in per if p["alive"])}
 
     def close(self):
         for w in self.workers:
+            if not w.alive:
+                continue
             try:
                 self.call(w.rank, "stop", timeout=10)
             except Exception:  # noqa: BLE001
