@@ -49,6 +49,14 @@ def _need_gpu():
     _weights_cache.clear()
 
 
+def load_ctrl(name):
+    """Reduced-precision CONTROL of the case (oracle/make_golden_ctrl.py): the reference's own arithmetic (HF on CPU) cast to
+    bf16 / fp16, teacher-forced along the same fp32 greedy path, its surface and token timestamps - the yardstick for what a
+    bf16 engine may lose against the fp32 golden."""
+    p = os.path.join(GOLD, f"ctrl_{name}.npz")
+    return np.load(p) if os.path.exists(p) else None
+
+
 def load_case(name):
     z = np.load(os.path.join(GOLD, f"{name}.npz"))
     dims = wo.PRESETS[str(z["preset"])]
@@ -61,7 +69,34 @@ def load_case(name):
     return z, dims, _weights_cache[key], pcm, heads
 
 
-def check_timestamps(z, eng, ts, streams, dtype, n_rows, bounds, dump=None):
+def check_vs_control(z, ctrl, mats, ts, rep, problems, slack=1.25):
+    """bf16 engine vs the reference's OWN bf16 arithmetic (HF `.to(torch.bfloat16)` on CPU, `ctrl`), both against the fp32
+    golden, on the clips the control covers: the engine's alignment surface and its token timestamps may be no further from
+    the fp32 reference than `slack` x what HF-bf16 itself is (timestamps: tokens outside one frame, + 2 tokens per clip of
+    counting noise - the DTW arg-min moves in whole tokens).  HF-fp16 (the reference's streaming default,
+    R:thestage_speechkit/streaming/streaming_pipeline.py:369-370) is reported beside it."""
+    clips = [int(c) for c in ctrl["clips"]]
+    gts, Mg = z["token_timestamps"], z["dtw_matrix"]
+    e_rel = [rel_l2(mats[c], Mg[c]) for c in clips]
+    h_rel = [rel_l2(ctrl["bf16_dtw_matrix"][i], Mg[c]) for i, c in enumerate(clips)]
+    f_rel = [rel_l2(ctrl["fp16_dtw_matrix"][i], Mg[c]) for i, c in enumerate(clips)]
+    e_out = [int((np.abs(ts[c] - gts[c]) > 0.0201).sum()) for c in clips]
+    h_out = [int((np.abs(ctrl["bf16_token_timestamps"][i] - gts[c]) > 0.0201).sum()) for i, c in enumerate(clips)]
+    f_out = [int((np.abs(ctrl["fp16_token_timestamps"][i] - gts[c]) > 0.0201).sum()) for i, c in enumerate(clips)]
+    n_tok = gts.shape[1]
+    rep.update(ctrl_clips=clips, surface_rel_l2_engine=[round(x, 4) for x in e_rel], surface_rel_l2_hf_bf16=[round(x, 4) for x in h_rel],
+               surface_rel_l2_hf_fp16=[round(x, 4) for x in f_rel], tokens_outside_1_frame_engine=e_out,
+               tokens_outside_1_frame_hf_bf16=h_out, tokens_outside_1_frame_hf_fp16=f_out, tokens_per_clip=n_tok,
+               worst_dev_s_engine=float(max(np.abs(ts[c] - gts[c]).max() for c in clips)),
+               worst_dev_s_hf_bf16=float(max(np.abs(ctrl["bf16_token_timestamps"][i] - gts[c]).max() for i, c in enumerate(clips))))
+    for c, e, h in zip(clips, e_rel, h_rel):
+        if e > slack * h:
+            problems.append(f"clip {c}: engine alignment surface rel-L2 {e:.4f} > {slack} x HF-bf16's own {h:.4f}")
+    if sum(e_out) > slack * sum(h_out) + 2 * len(clips):
+        problems.append(f"engine moves {sum(e_out)} tokens by more than one frame, HF-bf16 itself {sum(h_out)} (of {n_tok * len(clips)})")
+
+
+def check_timestamps(z, eng, ts, streams, dtype, n_rows, bounds, dump=None, ctrl=None):
     """Word-timestamp stage (A11) of `streams` (engine ids == golden ids there) against the reference, in three statements:
       1. STAGE PARITY, exact: the engine's timestamps are the reference algorithm (z-score, median filter, head mean, DTW with
          its tie-breaks: oracle restatement pinned to HF on CPU) applied to the engine's OWN alignment rows - bit for bit;
@@ -109,6 +144,8 @@ def check_timestamps(z, eng, ts, streams, dtype, n_rows, bounds, dump=None):
                worst_path_excess_frac=worst_excess_frac, surface_rel_l2=surf_rel, surface_maxabs=surf_abs)
     if dump is not None:
         dump["matrix"] = np.stack(mats)
+    if ctrl is not None and dtype == "bf16" and all(int(c) in streams for c in ctrl["clips"]):
+        check_vs_control(z, ctrl, {b: m for b, m in zip(streams, mats)}, ts, rep, problems)
     if dtype == "f32" and dev.max() > 0.0201:
         problems.append(f"strict f32: token timestamps deviate by {dev.max():.3f} s")
     if surf_rel > bounds["surface_rel"]:
@@ -169,7 +206,8 @@ def run_case(name, dtype, logit_tol, enc_tol, top_abs, ts_bounds, check_ids=True
         ts_tf = eng.token_timestamps(B, 3, Lg, [2 * T] * B)
         if DUMP:
             dump.update(ts_teacher_forced=ts_tf)
-        ts_rep, problems = check_timestamps(z, eng, ts_tf, list(range(B)), dtype, Lg - 1, ts_bounds, dump if DUMP else None)
+        ts_rep, problems = check_timestamps(z, eng, ts_tf, list(range(B)), dtype, Lg - 1, ts_bounds, dump if DUMP else None,
+                                            ctrl=load_ctrl(name))
         rep.update(ts_rep)
         rep["rand_path_logits_rel_l2"], rep["rand_path_top8_maxabs"], rep["rand_path_subm_flips"] = teacher(
             z["rand_ids"].astype(np.int64), z["rand_logits_top"], z["rand_logits_top_idx"], z["rand_logits_sample"])

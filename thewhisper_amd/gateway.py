@@ -125,10 +125,13 @@ class SessionHost:
     @staticmethod
     def _drop(sess: Dict[str, Any]):
         """Releases what a session holds.  The session is already out of the table; a request that is still running on it (an
-        ``/end`` racing a ``/process``) finishes first - its scheduler may be asking the detector stream for frames."""
-        vs = sess.get("vad")
-        if vs is not None:
-            with sess["lock"]:
+        ``/end`` racing a ``/process``) finishes first - its scheduler may be asking the detector stream for frames.  A request
+        that had looked the session up but not yet taken its lock finds it ``closed`` and answers 404: its detector slot may
+        already belong to another session."""
+        with sess["lock"]:
+            sess["closed"] = True
+            vs = sess.get("vad")
+            if vs is not None:
                 vs.close()
 
     def create(self, session_id: Optional[str] = None) -> str:
@@ -157,8 +160,12 @@ class SessionHost:
                 from .vad import attach_vad
 
                 vs = self.vad.open_stream()
-                attach_vad(sched, vs)
-            sess = {"scheduler": sched, "lock": threading.Lock(), "last_used": now, "vad": vs}
+                try:
+                    attach_vad(sched, vs)
+                except BaseException:
+                    vs.close()          # the detector slot must not outlive a session that was never created
+                    raise
+            sess = {"scheduler": sched, "lock": threading.Lock(), "last_used": now, "vad": vs, "closed": False}
         finally:
             with self._lock:
                 self._creating -= 1
@@ -180,6 +187,8 @@ class SessionHost:
     def add_chunk(self, sid: str, audio_np: np.ndarray) -> None:
         s = self._get(sid)
         with s["lock"]:
+            if s["closed"]:
+                raise KeyError(sid)
             sched, vs = s["scheduler"], s["vad"]
             if vs is not None and getattr(sched, "use_vad", False):
                 # the reference evaluates its detector frame by frame on (left-over samples + this chunk)
@@ -192,11 +201,15 @@ class SessionHost:
     def process(self, sid: str):
         s = self._get(sid)
         with s["lock"]:
+            if s["closed"]:
+                raise KeyError(sid)
             return s["scheduler"].process_new_chunk()    # blocks in the hub while the shared passes decode
 
     def clear(self, sid: str) -> None:
         s = self._get(sid)
         with s["lock"]:
+            if s["closed"]:
+                raise KeyError(sid)
             if hasattr(s["scheduler"], "clear"):
                 s["scheduler"].clear()   # per-session state: clearing is safe here (the reference's shared pipeline leaves it commented out)
             if s["vad"] is not None:
@@ -224,7 +237,7 @@ class SessionHost:
             return self.base_backend.transcribe(audio, 0.0, sr)
 
     def health(self) -> Dict[str, Any]:
-        return {"passes": (len(self.hub.batches) if self.hub is not None else None), "sessions": len(self.sessions),
+        return {"passes": (self.hub.passes if self.hub is not None else None), "sessions": len(self.sessions),
                 "vad_launches": (self.vad.launches if self.vad is not None else None)}
 
 
@@ -240,7 +253,8 @@ class _LockedBackend:
 
 
 def create_app(backend, auth_token: str = "", model_name: str = "", lang_id: Optional[str] = None, path: str = "/transcribe",
-               scheduler_factory=None, max_sessions: int = 1024, session_ttl_s: float = 900.0, vad=None):
+               scheduler_factory=None, max_sessions: int = 1024, session_ttl_s: float = 900.0, vad=None,
+               host_threads: Optional[int] = None):
     """FastAPI application.  ``backend``: a ``BatchingHub`` (concurrent requests share passes), a bare ``AMDWhisperBackend``, a
     ready ``SessionHost`` or a ``thewhisper_amd.node.NodeRouter`` (one host process per GPU).  ``auth_token``: when set,
     requests must carry ``Authorization: Bearer <token>``.  ``lang_id``: when set, a request's ``X-Lang-Id`` must equal it
@@ -253,15 +267,27 @@ def create_app(backend, auth_token: str = "", model_name: str = "", lang_id: Opt
         reference's demo server (R:examples/server.py:118-163) with the same request / response shapes, except that every
         session owns its scheduler state (the reference shares ONE StreamingPipeline across sessions, :25, :90, :98, and
         cannot batch) and all sessions of a GPU share the hub.  Sessions nobody ends are dropped after ``session_ttl_s``.
-    Every route body runs in the thread pool: a session's lock is held for the whole batched decode of ``/process``, and
-    taking it on the event loop would stall every other session (and defeat the batching the routes exist for)."""
+    Every route body runs in a thread pool: a session's lock is held for the whole batched decode of ``/process``, and
+    taking it on the event loop would stall every other session (and defeat the batching the routes exist for).  The pool is
+    this application's OWN (``host_threads`` workers, default ``min(max_sessions, 512)``): a ``/process`` call keeps its thread for
+    a whole pass, so the pool bounds the requests in flight - Starlette's shared default pool has 40 threads, i.e. 5 rows per
+    GPU in an 8-GPU node whose passes take 16."""
+    import asyncio
     import base64
+    import functools
     import queue as _queue
+    from concurrent.futures import ThreadPoolExecutor
 
     from fastapi import FastAPI, Header, HTTPException, Request, WebSocket
-    from fastapi.concurrency import run_in_threadpool
 
     app = FastAPI(title="thewhisper-amd gateway")
+    n_threads = int(host_threads or min(max(int(max_sessions), 64), 512))
+    pool = ThreadPoolExecutor(max_workers=n_threads, thread_name_prefix="tw-gateway")
+    app.state.host_threads = n_threads
+
+    async def run_in_threadpool(fn, *a):
+        return await asyncio.get_running_loop().run_in_executor(pool, functools.partial(fn, *a))
+
     if hasattr(backend, "create") and hasattr(backend, "add_chunk"):
         host = backend                       # SessionHost or NodeRouter
     else:
@@ -296,6 +322,8 @@ def create_app(backend, auth_token: str = "", model_name: str = "", lang_id: Opt
         except HostBusy as e:
             raise HTTPException(status_code=503, detail=str(e), headers={"Retry-After": "1"}) from e
         except RuntimeError as e:
+            if type(e).__name__ == "WorkerGone":   # node.py: the chosen GPU's serving process died under the call
+                raise HTTPException(status_code=503, detail=str(e), headers={"Retry-After": "1"}) from e
             raise HTTPException(status_code=500, detail=f"Failed to initialize model: {e}") from e
 
     @app.post("/session/{session_id}/end")
@@ -400,10 +428,11 @@ def create_app(backend, auth_token: str = "", model_name: str = "", lang_id: Opt
     return app
 
 
-def main(argv: Optional[List[str]] = None):  # pragma: no cover - needs weights and a GPU
+def build_host(argv: Optional[List[str]] = None):
+    """Parses the command line of ``python -m thewhisper_amd.gateway`` and builds what it serves: ``(host, args)`` with ``host``
+    a ``SessionHost`` over a ``BatchingHub`` over ``AMDWhisperBackend(args.model, ...)`` - the reference's constructor form, a
+    checkpoint NAME OR PATH (R:thestage_speechkit/nvidia/asr_pipeline.py:47-70) - or a ``NodeRouter`` for ``--gpus N``."""
     import argparse
-
-    import uvicorn
 
     ap = argparse.ArgumentParser(description="MI355X Whisper gateway speaking the TheWhisper remote-backend wire format")
     ap.add_argument("--model", required=True, help="HF checkpoint name or path (e.g. TheStageAI/thewhisper-large-v3)")
@@ -415,22 +444,36 @@ def main(argv: Optional[List[str]] = None):  # pragma: no cover - needs weights 
     ap.add_argument("--port", type=int, default=8000)
     ap.add_argument("--auth-token", default="")
     ap.add_argument("--language", default="en")
+    ap.add_argument("--dtype", default=None, choices=[None, "bf16", "fp16", "fp32"], help="compute dtype (default: the checkpoint's)")
     args = ap.parse_args(argv)
+    import torch
+
+    dtype = {None: None, "bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
     if args.gpus > 1:
         from .node import NodeRouter
 
         host = NodeRouter(args.gpus, "thewhisper_amd.node:default_host_factory",
                           dict(model=args.model, chunk_length_s=args.chunk_length_s, max_batch=args.max_batch, language=args.language,
-                               use_vad=args.vad))
+                               use_vad=args.vad, torch_dtype=args.dtype))
     else:
-        backend = AMDWhisperBackend(args.model, chunk_length_s=args.chunk_length_s, language=args.language, batch_size=args.max_batch)
+        backend = AMDWhisperBackend(args.model, chunk_length_s=args.chunk_length_s, language=args.language, batch_size=args.max_batch,
+                                    torch_dtype=dtype)
         vad = None
         if args.vad:
             from .vad import VadService
 
             vad = VadService(max_streams=1024)
         host = SessionHost(BatchingHub(backend, max_batch=args.max_batch), vad=vad)
-    uvicorn.run(create_app(host, auth_token=args.auth_token, model_name=args.model, lang_id=args.language), host=args.host, port=args.port)
+    return host, args
+
+
+def main(argv: Optional[List[str]] = None):  # pragma: no cover - serves until interrupted
+    import uvicorn
+
+    host, args = build_host(argv)
+    app = create_app(host, auth_token=args.auth_token, model_name=args.model, lang_id=args.language,
+                     host_threads=max(64, 2 * args.gpus * args.max_batch))
+    uvicorn.run(app, host=args.host, port=args.port)
 
 
 if __name__ == "__main__":  # pragma: no cover

@@ -54,8 +54,8 @@ class BatchingHub:
         self._closed = False
         self._lock = threading.Lock()
         self._next_id = 0
-        self.batches: "collections.deque[int]" = collections.deque(maxlen=4096)   # sizes of the passes / batches that were run
-        self.passes = 0
+        self.batches: "collections.deque[int]" = collections.deque(maxlen=4096)   # sizes of the LAST passes / batches that were run
+        self.passes = 0   # monotonic count of engine passes (continuous) / pipeline batches (classic): what /health reports
         self.latencies: "collections.deque[float]" = collections.deque(maxlen=4096)  # submit -> answer, seconds
         self._codec = None
         self._carry = None
@@ -267,6 +267,7 @@ class BatchingHub:
 
     def _execute(self, batch):
         self.batches.append(len(batch))
+        self.passes += 1
         try:
             results = self.backend.transcribe_many([(a, t0, sr) for a, t0, sr, _ in batch], batch_size=self.max_batch)
             for (_, _, _, fut), res in zip(batch, results):
