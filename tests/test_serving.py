@@ -205,7 +205,7 @@ def test_hub_falls_back_to_whole_call_batches_when_the_call_is_not_eligible():
     want = backend.transcribe(a.copy(), 2.0, 16000)
     f1, f2 = hub.submit(a.copy(), 2.0, 16000), hub.submit(a.copy(), 2.0, 16000)
     assert normalise(f1.result(300)) == normalise(want) == normalise(f2.result(300))
-    assert hub._codec is None and hub.passes == 0
+    assert hub._codec is None and hub.passes == 1 and hub.rows == 2      # one whole-call batch carried both requests
     hub.close()
 
 

@@ -237,7 +237,10 @@ class SessionHost:
             return self.base_backend.transcribe(audio, 0.0, sr)
 
     def health(self) -> Dict[str, Any]:
-        return {"passes": (self.hub.passes if self.hub is not None else None), "sessions": len(self.sessions),
+        return {"passes": (self.hub.passes if self.hub is not None else None), "rows": (self.hub.rows if self.hub is not None else None),
+                "last_rows": (list(self.hub.batches)[-24:] if self.hub is not None else None),
+                "turnaround_ms": (round(1e3 * self.hub._turn_ema, 1) if self.hub is not None else None),
+                "sessions": len(self.sessions),
                 "vad_launches": (self.vad.launches if self.vad is not None else None)}
 
 
@@ -300,8 +303,13 @@ def create_app(backend, auth_token: str = "", model_name: str = "", lang_id: Opt
             raise HTTPException(status_code=401, detail="invalid or missing bearer token")
 
     async def guarded(fn, *a):
-        """Run a host method in the thread pool and map its failures as the reference's server does (:86-89, :128-133)."""
+        """Run a host method - natively if the host has an async form of it (``NodeRouter.aprocess`` ...: nothing to block on in
+        this process, the work happens in a worker process), in the thread pool otherwise - and map its failures as the
+        reference's server does (:86-89, :128-133)."""
         try:
+            afn = getattr(host, "a" + fn.__name__, None)
+            if afn is not None:
+                return await afn(*a)
             return await run_in_threadpool(fn, *a)
         except KeyError as e:
             raise HTTPException(status_code=404, detail=f"Session {e.args[0]} not found") from e
@@ -400,8 +408,8 @@ def create_app(backend, auth_token: str = "", model_name: str = "", lang_id: Opt
                     break
                 if msg.get("bytes") is not None:
                     audio_np = np.frombuffer(msg["bytes"], dtype=np.float32)
-                    await run_in_threadpool(host.add_chunk, sid, audio_np)
-                    words, uncommited_words = await run_in_threadpool(host.process, sid)
+                    await guarded(host.add_chunk, sid, audio_np)
+                    words, uncommited_words = await guarded(host.process, sid)
                     await ws.send_json({"words": words, "uncommited_words": uncommited_words})
                 elif msg.get("text") == "clear":
                     await run_in_threadpool(host.clear, sid)
@@ -473,7 +481,9 @@ def main(argv: Optional[List[str]] = None):  # pragma: no cover - serves until i
     host, args = build_host(argv)
     app = create_app(host, auth_token=args.auth_token, model_name=args.model, lang_id=args.language,
                      host_threads=max(64, 2 * args.gpus * args.max_batch))
-    uvicorn.run(app, host=args.host, port=args.port)
+    # add_chunk carries base64 PCM in the QUERY STRING, as the reference's route does (R:examples/server.py:135-144): 0.5 s of audio is
+    # 43 KB of URL, above h11's default 16 KB request-line limit
+    uvicorn.run(app, host=args.host, port=args.port, h11_max_incomplete_event_size=1 << 20)
 
 
 if __name__ == "__main__":  # pragma: no cover

@@ -38,24 +38,38 @@ class _StreamBackend:
         self.stream_id = stream_id
 
     def transcribe(self, audio: np.ndarray, buffer_start_time: float, sample_rate: int) -> List[Dict[str, Any]]:
-        return self.hub.submit(audio, buffer_start_time, sample_rate).result()
+        return self.hub.submit(audio, buffer_start_time, sample_rate, stream_id=self.stream_id).result()
 
 
 class BatchingHub:
     def __init__(self, backend: AMDWhisperBackend, max_batch: Optional[int] = None, max_wait_s: float = 0.004,
-                 max_pending: int = 1024, continuous: bool = True):
+                 max_pending: int = 1024, continuous: bool = True, gather_s: float = 0.15):
         self.backend = backend
         eng = backend.asr_pipeline.model.engine
         self.max_batch = int(max_batch or eng.max_batch)
         if self.max_batch > eng.max_batch:
             raise ValueError("max_batch exceeds the engine capacity")
         self.max_wait_s = max_wait_s
+        # Sessions in a closed loop (answer -> next chunk -> next request) split into two cohorts that take turns in half-empty
+        # passes: the requests answered by pass k come back while pass k + 1 - started the moment pass k ended, with whoever
+        # was already waiting - is running (128 sessions on 8 stub ranks, tests/test_node_scale.py: exactly 8.0 of 16 rows per
+        # pass).  So a pass with free rows also waits for the sessions that were JUST ANSWERED, as long as they are on their way:
+        # the hub keeps a running estimate of the sessions' turnaround (answer -> next request of the same stream; only
+        # samples below 0.25 s count, i.e. closed-loop callers - a real-time session comes back after 0.5 s of audio and is not
+        # waited for) and holds the pass until the answered streams have asked again or 1.25 x that estimate (the 90th
+        # percentile of the recent samples; at most `gather_s`) has passed since the last answer.  Costs the requests already waiting at most that, only while rows are free.
+        self.gather_s = float(gather_s)
+        self._last_answer_t = 0.0
+        self._turn_ema = 0.0                       # seconds; 0 = no closed-loop caller seen (reported by /health)
+        self._turns: "collections.deque[float]" = collections.deque(maxlen=64)   # recent turnaround samples
+        self._answered: Dict[int, float] = {}      # stream id -> when its last request was answered (cleared when it asks again)
         self._q: "queue.Queue[Optional[Tuple[np.ndarray, float, int, Future]]]" = queue.Queue(maxsize=max_pending)
         self._closed = False
         self._lock = threading.Lock()
         self._next_id = 0
         self.batches: "collections.deque[int]" = collections.deque(maxlen=4096)   # sizes of the LAST passes / batches that were run
         self.passes = 0   # monotonic count of engine passes (continuous) / pipeline batches (classic): what /health reports
+        self.rows = 0     # ... and of the rows (chunks / requests) they carried: rows / passes = how full the passes are
         self.latencies: "collections.deque[float]" = collections.deque(maxlen=4096)  # submit -> answer, seconds
         self._codec = None
         self._carry = None
@@ -74,13 +88,23 @@ class BatchingHub:
         self._next_id += 1
         return _StreamBackend(self, self._next_id - 1)
 
-    def submit(self, audio: np.ndarray, buffer_start_time: float, sample_rate: int) -> Future:
+    def submit(self, audio: np.ndarray, buffer_start_time: float, sample_rate: int, stream_id: Optional[int] = None) -> Future:
         """Parks one request; raises ``RuntimeError`` after ``close()`` and ``queue.Full`` when ``max_pending`` requests wait."""
         fut: Future = Future()
         fut.t_submit = time.monotonic()  # type: ignore[attr-defined]
+        fut.stream_id = stream_id        # type: ignore[attr-defined]
         with self._lock:
             if self._closed:
                 raise RuntimeError("BatchingHub is closed")
+            if stream_id is not None:
+                t_ans = self._answered.pop(stream_id, None)
+                if t_ans is not None and fut.t_submit - t_ans < 0.25:      # type: ignore[attr-defined]
+                    d = fut.t_submit - t_ans                               # type: ignore[attr-defined]
+                    self._turns.append(d)
+                    # the window has to cover the SLOW returners (a pass started without them leaves them a pass of their own):
+                    # 90th percentile of the recent samples
+                    srt = sorted(self._turns)
+                    self._turn_ema = srt[min(len(srt) - 1, int(0.9 * len(srt)))]
             self._q.put_nowait((np.asarray(audio), float(buffer_start_time), int(sample_rate), fut))
         return fut
 
@@ -109,7 +133,13 @@ class BatchingHub:
     def _answer(self, fut: Future, result=None, exc: Optional[BaseException] = None):
         if fut.done():
             return
-        self.latencies.append(time.monotonic() - getattr(fut, "t_submit", time.monotonic()))
+        now = time.monotonic()
+        self.latencies.append(now - getattr(fut, "t_submit", now))
+        sid = getattr(fut, "stream_id", None)
+        with self._lock:
+            self._last_answer_t = now
+            if sid is not None:
+                self._answered[sid] = now
         if exc is not None:
             fut.set_exception(exc)
         else:
@@ -141,6 +171,21 @@ class BatchingHub:
                 return
             self._codec = None
         self._run_classic()
+
+    def _gather_until(self, deadline: float) -> float:
+        """Until when a pass with free rows keeps its intake open: `deadline`, or - while streams answered a moment ago have
+        not asked again - 1.5 x the measured turnaround after the last answer (see __init__)."""
+        if self._turn_ema <= 0.0:
+            return deadline
+        now = time.monotonic()
+        with self._lock:
+            if len(self._answered) > 256:    # streams that went away: forget answers older than any turnaround that counts
+                self._answered = {k: t for k, t in self._answered.items() if now - t < 0.25}
+            pending = any(now - t < 0.25 for t in self._answered.values())
+            last = self._last_answer_t
+        if not pending:
+            return deadline
+        return max(deadline, last + min(self.gather_s, 1.25 * self._turn_ema))
 
     def _take(self, block: bool = True, timeout: Optional[float] = None):
         """Next parked request: the one taken off the queue before the plan was learned first, then the queue."""
@@ -189,7 +234,8 @@ class BatchingHub:
                         item = self._take()
                         deadline = time.monotonic() + self.max_wait_s
                     else:
-                        item = self._take(timeout=max(0.0, deadline - time.monotonic()))
+                        # (re-read every time: the poster thread answers the previous pass's requests while this loop waits)
+                        item = self._take(timeout=max(0.0, self._gather_until(deadline) - time.monotonic()))
                 except queue.Empty:
                     break
                 if item is None:
@@ -219,6 +265,7 @@ class BatchingHub:
                     continue
                 self.batches.append(len(works))
                 self.passes += 1
+                self.rows += len(works)
                 pas.run()
                 for w in works:
                     if w.passes > shortform.MAX_SEEK_PASSES:
@@ -256,7 +303,7 @@ class BatchingHub:
             deadline = time.monotonic() + self.max_wait_s
             while len(batch) < self.max_batch:
                 try:
-                    nxt = self._q.get(timeout=max(0.0, deadline - time.monotonic()))
+                    nxt = self._q.get(timeout=max(0.0, self._gather_until(deadline) - time.monotonic()))
                 except queue.Empty:
                     break
                 if nxt is None:
@@ -268,6 +315,7 @@ class BatchingHub:
     def _execute(self, batch):
         self.batches.append(len(batch))
         self.passes += 1
+        self.rows += len(batch)
         try:
             results = self.backend.transcribe_many([(a, t0, sr) for a, t0, sr, _ in batch], batch_size=self.max_batch)
             for (_, _, _, fut), res in zip(batch, results):
