@@ -338,7 +338,7 @@ def secondary_leg(label, model, chunk_s, B, dtype, steps, new_tokens, device_ind
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         esz = 2
-        wsz = 1.0 + 1.0 / 32 if dtype == "fp8" else None
+        wsz = 1.0 + 1.0 / 32 if dtype.startswith("fp8") else None
         spc = dsteps // steps
         alg, _W = algorithmic_decode_bytes(dims, B, T, 3, spc, esz, wsz)
         ach = alg / (greedy_ms / steps * 1e-3) / 1e9
@@ -399,7 +399,7 @@ def main(argv=None):
     ap.add_argument("--chunk-s", type=int, default=10)
     ap.add_argument("--streams", type=int, default=16, help="concurrent streams per GPU (1..64; 16 = the per-GPU share of BASELINE configs[3])")
     ap.add_argument("--new-tokens", type=int, default=128)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"],
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8", "fp8a8", "fp8a16"],
                     help="fp8 = bf16 activations/encoder + MXFP8 decoder projection weights (BASELINE config 5)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -560,7 +560,7 @@ def main(argv=None):
 
     if rank == 0:
         esz = 4 if args.dtype == "f32" else 2
-        wsz = 1.0 + 1.0 / 32 if args.dtype == "fp8" else None
+        wsz = 1.0 + 1.0 / 32 if args.dtype.startswith("fp8") else None
         steps_per_call = dec_steps // max(1, args.steps)
         alg_bytes, W = algorithmic_decode_bytes(dims, B, T, n_prompt, steps_per_call, esz, wsz)
         alg_bytes, W = int(alg_bytes), int(W)
@@ -580,7 +580,7 @@ def main(argv=None):
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16 activations, MXFP8 (e4m3 + block scales) decoder weights" if args.dtype == "fp8" else args.dtype,
+            "dtype": (f"bf16 activations, MXFP8 (e4m3 + block scales) decoder weights [{args.dtype}]" if args.dtype.startswith("fp8") else args.dtype),
             "data": "synthetic 16 kHz gaussian audio (sigma 0.1), random-init weights of the named architecture",
             "config": {
                 "workload": f"whisper-{args.model}, {args.chunk_s} s chunks, {B} concurrent streams per GPU (configs[3] per-GPU share), "

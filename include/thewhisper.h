@@ -35,8 +35,12 @@ extern "C" {
 
 /* element types of caller buffers and of the context's compute mode */
 enum { TW_F32 = 0, TW_BF16 = 1, TW_F16 = 2,
-       TW_BF16_MXFP8 = 3 /* context dtype only: bf16 activations / encoder, decoder projection weights as MXFP8 (OCP e4m3 +
-                            one power-of-two scale per 32 values) on v_mfma_scale_f32_16x16x128_f8f6f4; BASELINE config 5 */ };
+       TW_BF16_MXFP8 = 3, /* context dtype only: bf16 activations / encoder, decoder projection weights as MXFP8 (OCP e4m3 +
+                            one power-of-two scale per 32 values) AND the activations quantised the same way in registers, on
+                            v_mfma_scale_f32_16x16x128_f8f6f4 ("W8A8"); fp8 cross-attention K / V caches; BASELINE config 5 */
+       TW_BF16_W8A16 = 4  /* context dtype only: the same MXFP8 weights and fp8 cross K / V caches, but the weight fragments are
+                            widened to bf16 in registers and contracted with the UNQUANTISED bf16 activations on the bf16 MFMA
+                            ("W8A16": same bytes from HBM, no activation-quantisation error); up to 64 streams */ };
 
 /* error codes */
 enum {
@@ -68,7 +72,7 @@ typedef struct tw_config {
                                     (R:thestage_speechkit/nvidia/asr_pipeline.py:15-27). */
   int32_t target_positions;      /* decoder positions, 448 */
   int32_t max_batch;             /* concurrent streams per call: 1..64 (1..16 with TW_BF16_MXFP8) */
-  int32_t dtype;                 /* TW_BF16 (production), TW_F32 (strict-parity mode) or TW_BF16_MXFP8 (fp8 decoder weights) */
+  int32_t dtype;                 /* TW_BF16 (production), TW_F32 (strict-parity mode), TW_BF16_MXFP8 / TW_BF16_W8A16 (fp8 decoder weights) */
   int32_t n_align_heads;         /* alignment heads for word timestamps (generation_config.alignment_heads) */
   int32_t align_heads[2 * TW_MAX_ALIGN_HEADS]; /* (layer, head) pairs */
   int32_t device;                /* HIP device ordinal */

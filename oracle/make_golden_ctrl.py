@@ -39,6 +39,7 @@ CTRL = {
     "full_large-v3_c10": [0, 1],
     "full_large-v3_c10_b16": [0, 1, 2, 3],
     "full_large-v3_c15": [0],
+    "full_large-v3_c15_b4": [0, 1, 2, 3],
     "full_turbo_c30": [0],
 }
 DTYPES = {"bf16": torch.bfloat16, "fp16": torch.float16}

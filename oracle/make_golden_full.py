@@ -12,6 +12,8 @@ are consumed, so only small outputs are stored under tests/golden/full_*.npz):
   full_large-v3_c15    whisper-large-v3   32+32 layers, 15 s chunks (T = 750), 1 clip      (BASELINE config 5)
   full_large-v3_c10_b16  whisper-large-v3 32+32 layers, 10 s chunks, **16 clips, 160 new tokens** (the batch and the length
                        bench.py times: configs[3]'s per-GPU share; reaches the 128- / 192-key self-attention variants)
+  full_large-v3_c15_b4   whisper-large-v3 32+32 layers, 15 s chunks, 4 clips, 128 new tokens (config 5 at the length its
+                       driver-timed leg decodes: the fp8 context's non-vacuous case)
 
 Per case: log-mel rows (HF feature extractor), encoder-state samples, HF ``generate`` greedy ids with the timestamp
 grammar on (``max_new_tokens`` 32) + token timestamps (DTW), and - teacher-forced along that greedy path - per step the
@@ -42,10 +44,12 @@ CASES = {
     "full_turbo_c30": ("large-v3-turbo", 30, [("speechlike", 23)], 0, 32),
     "full_large-v3_c15": ("large-v3", 15, [("speechlike", 24)], 0, 32),
     "full_large-v3_c10_b16": ("large-v3", 10, [(("speechlike", "noise", "sine", "speechlike")[i % 4], 100 + i) for i in range(16)], 0, 160),
+    # BASELINE config 5 at the shape its driver-timed leg runs (15 s chunks, 128 new tokens): 4 clips, one of each audio kind
+    "full_large-v3_c15_b4": ("large-v3", 15, [(("speechlike", "noise", "sine", "speechlike")[i % 4], 200 + i) for i in range(4)], 0, 128),
 }
 # stride of the stored logits-row sample per case (rel-L2 estimate): the 16 x 163-row case keeps 1/8 of the others' density
-LOGIT_STRIDES = {"full_large-v3_c10_b16": 233}
-RAND_LEN = {"full_large-v3_c10_b16": 170}   # random text tokens of the second teacher-forced pass (default 13)
+LOGIT_STRIDES = {"full_large-v3_c10_b16": 233, "full_large-v3_c15_b4": 97}
+RAND_LEN = {"full_large-v3_c10_b16": 170, "full_large-v3_c15_b4": 60}   # random text tokens of the second teacher-forced pass (default 13)
 WSCALE, QGAIN = 0.5, 8.0   # make_weights(scale, q_gain): see its docstring (unit-gain random models degenerate at 32 layers)
 LOGIT_STRIDE = 29   # strided sample of every logits row kept for the relative-L2 estimate
 ENC_TSTRIDE, ENC_DSTRIDE = 25, 16

@@ -513,10 +513,13 @@ def kv8_quant_dequant(x: np.ndarray) -> np.ndarray:
 
 class OracleWhisperMXFP8(OracleWhisper):
     """bf16 activations, decoder projection weights in MXFP8 with the pre-LayerNorm folded into the weights, as the
-    TW_BF16_MXFP8 engine computes:  y = rstd * (Q(x) . Q(W')^T - mean * gW) + cb,  W' = bf16(g * W)."""
+    TW_BF16_MXFP8 engine computes:  y = rstd * (Q(x) . Q(W')^T - mean * gW) + cb,  W' = bf16(g * W).
+    ``act_quant=False`` restates the TW_BF16_W8A16 engine: the same quantised weights, widened to bf16 (exactly), against the
+    UNQUANTISED bf16 activations:  y = rstd * (x . Q(W')^T - mean * gW) + cb."""
 
-    def __init__(self, dims, weights, T=None, cross_q_ahead=True):
+    def __init__(self, dims, weights, T=None, cross_q_ahead=True, act_quant=True):
         super().__init__(dims, weights, T=T, dtype=np.float32)
+        self._qa = mx8_quant_dequant if act_quant else (lambda v: np.asarray(v, dtype=np.float32))
         self._fold_cache: Dict[Tuple[str, str], Tuple[np.ndarray, np.ndarray, np.ndarray]] = {}
         self._wq_cache: Dict[str, np.ndarray] = {}
         self._ahead_cache: Dict[int, Tuple[np.ndarray, np.ndarray]] = {}
@@ -552,7 +555,7 @@ class OracleWhisperMXFP8(OracleWhisper):
             Wc = bf16_round((Wf.astype(np.float32) @ Wo.astype(np.float32)).astype(np.float32))
             self._ahead_cache[i] = (mx8_quant_dequant(Wc), (Wf.astype(np.float32) @ bo.astype(np.float32)).astype(np.float32))
         Wc_q, c0 = self._ahead_cache[i]
-        u = (mx8_quant_dequant(bf16_round(x0)) @ Wq.T + c0) + mx8_quant_dequant(attn_b) @ Wc_q.T
+        u = (self._qa(bf16_round(x0)) @ Wq.T + c0) + self._qa(attn_b) @ Wc_q.T
         xb = bf16_round(x1)
         mean = xb.mean(axis=-1, keepdims=True)
         var = np.maximum((xb.astype(np.float64) ** 2).mean(axis=-1, keepdims=True) - mean.astype(np.float64) ** 2, 0.0)
@@ -565,7 +568,7 @@ class OracleWhisperMXFP8(OracleWhisper):
         mean = xb.mean(axis=-1, keepdims=True)
         var = np.maximum((xb.astype(np.float64) ** 2).mean(axis=-1, keepdims=True) - mean.astype(np.float64) ** 2, 0.0)
         rstd = (1.0 / np.sqrt(var + 1e-5)).astype(np.float32)
-        acc = mx8_quant_dequant(xb) @ Wq.T
+        acc = self._qa(xb) @ Wq.T
         return rstd * (acc - mean * gw) + cb
 
     def _dec_proj(self, x, ln_name, lin_name, bias=True):
@@ -574,7 +577,7 @@ class OracleWhisperMXFP8(OracleWhisper):
     def _dec_lin(self, x, lin_name):
         if lin_name not in self._wq_cache:
             self._wq_cache[lin_name] = mx8_quant_dequant(bf16_round(self.w[lin_name + ".weight"]))
-        return mx8_quant_dequant(bf16_round(x)) @ self._wq_cache[lin_name].T + bf16_round(self.w[lin_name + ".bias"])
+        return self._qa(bf16_round(x)) @ self._wq_cache[lin_name].T + bf16_round(self.w[lin_name + ".bias"])
 
     def _dec_logits(self, x):
         d = "model.decoder"

@@ -13,7 +13,8 @@ from typing import Optional
 from . import build as _build
 
 TW_F32, TW_BF16, TW_F16 = 0, 1, 2
-TW_BF16_MXFP8 = 3  # context dtype only: bf16 activations, MXFP8 decoder projection weights
+TW_BF16_MXFP8 = 3  # context dtype only: bf16 activations, MXFP8 decoder projection weights, activations quantised in registers (W8A8)
+TW_BF16_W8A16 = 4  # context dtype only: MXFP8 decoder projection weights widened to bf16 in registers, bf16 activations
 TW_MAX_ALIGN_HEADS = 32
 
 

@@ -40,7 +40,8 @@ struct LayerW {
 struct tw_ctx {
   tw_config cfg{};
   int dtype = 1;
-  bool w8 = false;   // decoder projection weights in MXFP8 (TW_BF16_MXFP8 contexts)
+  bool w8 = false;   // decoder projection weights in MXFP8 (TW_BF16_MXFP8 / TW_BF16_W8A16 contexts)
+  int a16 = 0;       // ... contracted as bf16 after widening in registers (TW_BF16_W8A16; TW_FP8_ACT=bf16|fp8 overrides at run time for A/B)
   // "cross query ahead" (decode_core): the decoder's cross-attention query projection is folded into the two launches before
   // it, which saves one dependent launch per layer and step.  du = float32 [Bmax][d] pre-activation of that projection.
   bool fuse_cq = false;
@@ -241,14 +242,16 @@ int tw_create(const tw_config* cfg, tw_ctx** out) {
   *out = nullptr;
   if (cfg->heads <= 0 || cfg->d_model != cfg->heads * 64)
     return fail(nullptr, TW_EINVAL, "head_dim must be 64 (d_model=%d heads=%d)", cfg->d_model, cfg->heads);
-  if (cfg->dtype != TW_BF16 && cfg->dtype != TW_F32 && cfg->dtype != TW_BF16_MXFP8)
-    return fail(nullptr, TW_EINVAL, "dtype must be TW_BF16, TW_F32 or TW_BF16_MXFP8");
-  if (cfg->dtype == TW_BF16_MXFP8 && (cfg->d_model % 128 || cfg->ffn % 128))
-    return fail(nullptr, TW_EINVAL, "TW_BF16_MXFP8 needs d_model and ffn to be multiples of 128");
+  if (cfg->dtype != TW_BF16 && cfg->dtype != TW_F32 && cfg->dtype != TW_BF16_MXFP8 && cfg->dtype != TW_BF16_W8A16)
+    return fail(nullptr, TW_EINVAL, "dtype must be TW_BF16, TW_F32, TW_BF16_MXFP8 or TW_BF16_W8A16");
+  const bool cfg_w8 = cfg->dtype == TW_BF16_MXFP8 || cfg->dtype == TW_BF16_W8A16;
+  if (cfg_w8 && (cfg->d_model % 128 || cfg->ffn % 128))
+    return fail(nullptr, TW_EINVAL, "TW_BF16_MXFP8 / TW_BF16_W8A16 need d_model and ffn to be multiples of 128");
   if (cfg->d_model % 64 || cfg->ffn % 64 || cfg->d_model > 1280)
     return fail(nullptr, TW_EINVAL, "d_model/ffn must be multiples of 64 and d_model <= 1280");
   if (cfg->max_batch < 1 || cfg->max_batch > 64) return fail(nullptr, TW_EINVAL, "max_batch must be in [1,64]");
-  if (cfg->dtype == TW_BF16_MXFP8 && cfg->max_batch > 16) return fail(nullptr, TW_EINVAL, "TW_BF16_MXFP8: max_batch must be in [1,16]");
+  if (cfg->dtype == TW_BF16_MXFP8 && cfg->max_batch > 16)
+    return fail(nullptr, TW_EINVAL, "TW_BF16_MXFP8: max_batch must be in [1,16] (TW_BF16_W8A16 takes up to 64 streams)");
   if (cfg->source_positions < 8 || cfg->source_positions > 1500 || cfg->target_positions < 8 || cfg->target_positions > 511)
     return fail(nullptr, TW_EINVAL, "source_positions must be in [8,1500], target_positions in [8,511]");
   if (cfg->n_align_heads < 0 || cfg->n_align_heads > TW_MAX_ALIGN_HEADS) return fail(nullptr, TW_EINVAL, "bad n_align_heads");
@@ -263,7 +266,12 @@ int tw_create(const tw_config* cfg, tw_ctx** out) {
 
   tw_ctx* c = new tw_ctx();
   c->cfg = *cfg;
-  c->w8 = cfg->dtype == TW_BF16_MXFP8;
+  c->w8 = cfg_w8;
+  c->a16 = cfg->dtype == TW_BF16_W8A16;
+  if (cfg->dtype == TW_BF16_MXFP8) {   // same weights and layouts: the activation flavour can be switched for A/B measurements
+    const char* fa = getenv("TW_FP8_ACT");
+    if (fa && !strcmp(fa, "bf16")) c->a16 = 1;
+  }
   c->dtype = c->w8 ? (int)TW_BF16 : cfg->dtype;
   c->esz = c->dtype == TW_BF16 ? 2 : 4;
   c->d = cfg->d_model; c->H = cfg->heads; c->ffn = cfg->ffn; c->V = cfg->vocab;
@@ -807,7 +815,7 @@ int decode_core(tw_ctx* c, int B, hipStream_t st) {
     const bool fq_on = c->fuse_cq && !getenv_off_fuse() && d / (L.tr_o ? L.tr_o : 16) <= 192;
     {  // LN + fused QKV; k,v rows go straight into the cache at position pos
       GemvArgs a{};
-      a.x = xin; a.ldx = d; a.ln_gw = L.qkv_gw; a.ln_cb = L.qkv_cb; a.W = L.wqkv; a.wscale = L.s_qkv; a.N = (fq_on ? 4 : 3) * d; a.K = d; a.B = B;
+      a.x = xin; a.ldx = d; a.ln_gw = L.qkv_gw; a.ln_cb = L.qkv_cb; a.W = L.wqkv; a.wscale = L.s_qkv; a.a16 = c->a16; a.N = (fq_on ? 4 : 3) * d; a.K = d; a.B = B;
       a.y = c->dq; a.ldy = d; a.kcache = sk; a.vcache = sv; a.cache_bstride = (long long)Pp * d; a.d_model = d; a.stt = c->stt;
       a.u = fq_on ? c->du : nullptr;
       HIPCHK(c, launch_gemv(dt, a, st));
@@ -815,7 +823,7 @@ int decode_core(tw_ctx* c, int B, hipStream_t st) {
     HIPCHK(c, launch_dec_self_attn(dt, c->dq, sk, sv, Pp, c->datt, B, H, c->dec_key_bound > 0 ? c->dec_key_bound : P, c->stt, st));
     {
       GemvArgs a{};
-      a.x = c->datt; a.ldx = d; a.W = L.wo; a.wscale = L.s_o; a.tr = L.tr_o; a.bias = L.bo; a.N = (fq_on ? 2 : 1) * d; a.K = d; a.B = B;
+      a.x = c->datt; a.ldx = d; a.W = L.wo; a.wscale = L.s_o; a.a16 = c->a16; a.tr = L.tr_o; a.bias = L.bo; a.N = (fq_on ? 2 : 1) * d; a.K = d; a.B = B;
       a.res = xin; a.ldres = d; a.y = xmid; a.ldy = d;
       if (fq_on) { a.u = c->du; a.nsplit = d; a.stats = c->dstats; }
       HIPCHK(c, launch_gemv(dt, a, st));
@@ -825,7 +833,7 @@ int decode_core(tw_ctx* c, int B, hipStream_t st) {
       fq.u = c->du; fq.stats = c->dstats; fq.n_part = d / (L.tr_o ? L.tr_o : 16); fq.gw = L.qc_gw; fq.cb = L.qc_cb; fq.d = d;
     } else {
       GemvArgs a{};
-      a.x = xmid; a.ldx = d; a.ln_gw = L.qc_gw; a.ln_cb = L.qc_cb; a.W = L.wq_c; a.wscale = L.s_qc; a.tr = L.tr_qc; a.N = d; a.K = d; a.B = B;
+      a.x = xmid; a.ldx = d; a.ln_gw = L.qc_gw; a.ln_cb = L.qc_cb; a.W = L.wq_c; a.wscale = L.s_qc; a.a16 = c->a16; a.tr = L.tr_qc; a.N = d; a.K = d; a.B = B;
       a.y = c->dq; a.ldy = d;
       HIPCHK(c, launch_gemv(dt, a, st));
     }
@@ -835,19 +843,19 @@ int decode_core(tw_ctx* c, int B, hipStream_t st) {
                                     c->w8 ? c->cross_vsc + (size_t)c->Bmax * H * c->Tp * l : nullptr, st));
     {
       GemvArgs a{};
-      a.x = c->datt; a.ldx = d; a.W = L.wo_c; a.wscale = L.s_oc; a.tr = L.tr_oc; a.bias = L.bo_c; a.N = d; a.K = d; a.B = B; a.res = xmid; a.ldres = d;
+      a.x = c->datt; a.ldx = d; a.W = L.wo_c; a.wscale = L.s_oc; a.a16 = c->a16; a.tr = L.tr_oc; a.bias = L.bo_c; a.N = d; a.K = d; a.B = B; a.res = xmid; a.ldres = d;
       a.y = xin; a.ldy = d;
       HIPCHK(c, launch_gemv(dt, a, st));
     }
     {
       GemvArgs a{};
-      a.x = xin; a.ldx = d; a.ln_gw = L.fc1_gw; a.ln_cb = L.fc1_cb; a.W = L.w1; a.wscale = L.s_1; a.tr = L.tr_1; a.N = F; a.K = d; a.B = B;
+      a.x = xin; a.ldx = d; a.ln_gw = L.fc1_gw; a.ln_cb = L.fc1_cb; a.W = L.w1; a.wscale = L.s_1; a.a16 = c->a16; a.tr = L.tr_1; a.N = F; a.K = d; a.B = B;
       a.gelu = 1; a.y = c->dh; a.ldy = F;
       HIPCHK(c, launch_gemv(dt, a, st));
     }
     {
       GemvArgs a{};
-      a.x = c->dh; a.ldx = F; a.W = L.w2; a.wscale = L.s_2; a.tr = L.tr_2; a.bias = L.b2; a.N = d; a.K = F; a.B = B; a.res = xin; a.ldres = d;
+      a.x = c->dh; a.ldx = F; a.W = L.w2; a.wscale = L.s_2; a.a16 = c->a16; a.tr = L.tr_2; a.bias = L.b2; a.N = d; a.K = F; a.B = B; a.res = xin; a.ldres = d;
       a.y = xmid; a.ldy = d;
       HIPCHK(c, launch_gemv(dt, a, st));
     }
@@ -855,7 +863,7 @@ int decode_core(tw_ctx* c, int B, hipStream_t st) {
   }
   {
     GemvArgs a{};
-    a.x = xin; a.ldx = d; a.ln_gw = c->logit_gw; a.ln_cb = c->logit_cb; a.W = c->logit_w; a.wscale = c->logit_ws; a.N = c->V; a.K = d; a.B = B;
+    a.x = xin; a.ldx = d; a.ln_gw = c->logit_gw; a.ln_cb = c->logit_cb; a.W = c->logit_w; a.wscale = c->logit_ws; a.a16 = c->a16; a.N = c->V; a.K = d; a.B = B;
     a.y_f32 = c->logits;
     HIPCHK(c, launch_gemv(dt, a, st));
   }

@@ -17,6 +17,8 @@
 // register-prefetched one tile ahead and double-buffered in LDS: one barrier per 64-key tile.
 #include "tw_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 template <typename T> struct AttnTraits;
@@ -66,10 +68,13 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, v);
 }
 
+// Workgroup id -> (stream*head, query block).  All query blocks of one head read the same K / V^T (128 KB at T = 500); consecutive
+// workgroup ids go to the 8 XCDs round-robin (MI355X_MICROARCH.md), so with the query block as the fastest grid index every
+// head's K / V^T was fetched into 4 different L2s.  xcd = 1: head bh runs on XCD bh % 8, its query blocks back to back there.
 template <typename T, int QT>
 __global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                         const T* __restrict__ vt, T* __restrict__ out, int H, int Tlen,
-                                                        int Tp) {
+                                                        int Tp, int nbh, int nq, int xcd) {
   using TR = AttnTraits<T>;
   constexpr int E = TR::E, NSLOT = TR::NSLOT, KK = TR::KK;
   constexpr int KV = 64 * NSLOT / 256;          // K-tile vectors per thread
@@ -81,9 +86,19 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ q, 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, kb = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int qblock = blockIdx.x * (64 * QT);
-  const long long bh = (long long)b * H + h;
+  int bhi, qb;
+  if (xcd) {
+    const int local = blockIdx.x >> 3;
+    bhi = (local / nq) * 8 + (blockIdx.x & 7);
+    qb = local % nq;
+  } else {
+    bhi = blockIdx.x / nq;
+    qb = blockIdx.x % nq;
+  }
+  if (bhi >= nbh) return;   // padding ids of the last group of 8 heads (whole workgroup, before any barrier)
+  const int b = bhi / H, h = bhi - b * H;
+  const int qblock = qb * (64 * QT);
+  const long long bh = bhi;
   const T* qh = q + bh * Tlen * 64;
   const T* kh = k + bh * Tlen * 64;
   const T* vh = vt + bh * 64 * Tp;
@@ -189,11 +204,16 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ q, 
       alpha[t] = attn_exp<T>(mrun[t] - mnew);
       mrun[t] = mnew;
       float ps = 0.f;
+      // bf16: exp(s - m) = 2^(s * log2(e) - m * log2(e)): one fused multiply-add and the hardware 2^x per score instead of a
+      // subtraction, a multiplication and the 2^x (the loop is VALU-bound: ~34 of these per 32 MFMAs)
+      const float ml = mnew * 1.4426950408889634f;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = attn_exp<T>(s[t][kt][r] - mnew);
+          float p;
+          if constexpr (sizeof(T) == 4) p = expf(s[t][kt][r] - mnew);
+          else p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][kt][r], 1.4426950408889634f, -ml));
           s[t][kt][r] = p;
           ps += p;
         }
@@ -277,16 +297,19 @@ hipError_t launch_enc_attention(int dtype, const void* q, const void* k, const v
   // 128 queries per workgroup when that still yields >= 2 workgroups per CU, else 64.
   const long long blocks128 = (long long)B * H * ((T + 127) / 128);
   const bool big = blocks128 >= 512;
+  static const int xcd = []() { const char* e = getenv("TW_ATTN_XCD"); return e ? atoi(e) : 1; }();
+  const int nbh = B * H;
+  auto grid_for = [&](int nq) { return dim3((unsigned)((xcd ? 8 * ((nbh + 7) / 8) : nbh) * nq)); };
   if (dtype == 1) {
     if (big)
-      hipLaunchKernelGGL((enc_attn_kernel<bf16_t, 2>), dim3((T + 127) / 128, H, B), dim3(256), 0, st, (const bf16_t*)q,
-                         (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, T, Tp);
+      hipLaunchKernelGGL((enc_attn_kernel<bf16_t, 2>), grid_for((T + 127) / 128), dim3(256), 0, st, (const bf16_t*)q,
+                         (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, T, Tp, nbh, (T + 127) / 128, xcd);
     else
-      hipLaunchKernelGGL((enc_attn_kernel<bf16_t, 1>), dim3((T + 63) / 64, H, B), dim3(256), 0, st, (const bf16_t*)q,
-                         (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, T, Tp);
+      hipLaunchKernelGGL((enc_attn_kernel<bf16_t, 1>), grid_for((T + 63) / 64), dim3(256), 0, st, (const bf16_t*)q,
+                         (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, T, Tp, nbh, (T + 63) / 64, xcd);
   } else {
-    hipLaunchKernelGGL((enc_attn_kernel<float, 1>), dim3((T + 63) / 64, H, B), dim3(256), 0, st, (const float*)q,
-                       (const float*)k, (const float*)vt, (float*)out, H, T, Tp);
+    hipLaunchKernelGGL((enc_attn_kernel<float, 1>), grid_for((T + 63) / 64), dim3(256), 0, st, (const float*)q,
+                       (const float*)k, (const float*)vt, (float*)out, H, T, Tp, nbh, (T + 63) / 64, xcd);
   }
   return hipGetLastError();
 }

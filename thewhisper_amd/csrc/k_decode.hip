@@ -169,6 +169,19 @@ __device__ __forceinline__ v8i_t sk_quant_mx8(const u32x4_t (&xv)[4], int& scale
   return out;
 }
 
+// 16 e4m3 bytes -> two bf16 MFMA operands (bytes 0..7, 8..15), each value multiplied by X = 2^(scale byte - 127): exact in bf16
+// (3 mantissa bits times a power of two).  v_cvt_scalef32_pk_bf16_fp8 converts one byte pair per instruction.
+__device__ __forceinline__ void sk_widen8(const u32x4_t& raw, float X, u32x4_t& lo, u32x4_t& hi) {
+  lo[0] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)raw[0], X, false));
+  lo[1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)raw[0], X, true));
+  lo[2] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)raw[1], X, false));
+  lo[3] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)raw[1], X, true));
+  hi[0] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)raw[2], X, false));
+  hi[1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)raw[2], X, true));
+  hi[2] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)raw[3], X, false));
+  hi[3] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8((int)raw[3], X, true));
+}
+
 // (sum, sum of squares) of the 16 bytes of one activation fragment, accumulated per lane
 template <typename T> __device__ __forceinline__ void sk_stats(const u32x4_t& v, float& s, float& ss);
 template <> __device__ __forceinline__ void sk_stats<bf16_t>(const u32x4_t& v, float& s, float& ss) {
@@ -222,7 +235,13 @@ template <> __device__ __forceinline__ void sk_stats<float>(const u32x4_t& v, fl
 // spreads the same bytes over 160 (320) CUs.  The MFMA still contracts a 16-row A operand whose rows >= TR are zero (lanes
 // fr >= TR issue no request): matrix-core time is not what bounds these launches.  Weight layout for TR < 16:
 // [tile][step][kq * TR + fr][E] (tile_weights_kernel), i.e. a wavefront request is TR * 64 contiguous bytes.
-template <typename T, int NW, int SK_MAXS, bool LN, int EPI, bool MULTI, bool W8, int CG, int TR>
+// A16 (with W8) = "W8A16": the MXFP8 weight fragments are widened to bf16 in registers (sk_widen8: value x block scale, exact)
+// and contracted with the UNQUANTISED bf16 activations on v_mfma_f32_16x16x32_bf16 - the same bytes from HBM as W8, no
+// activation quantisation (neither its error nor its ~0.3 us of lane exchanges on the critical path of a latency-bound launch).
+// A weight lane needs the scales of ITS two 32-value blocks (16-byte half h of lane groups 2u, 2u+1, u = kq / 2); the scale array
+// holds block t = 2h + u in lane group t (where the scaled MFMA reads it), so the lane fetches groups u and 2 + u: two byte loads
+// per step instead of one, no exchange.  Several groups of 16 streams (CG > 1) are available in this mode only.
+template <typename T, int NW, int SK_MAXS, bool LN, int EPI, bool MULTI, bool W8, int CG, int TR, bool A16 = false>
 __global__ __launch_bounds__(NW * 64, (CG > 1 ? (NW >= 16 ? 4 : 2) : (NW >= 16 ? 4 : (W8 ? (SK_MAXS <= 2 ? 4 : 2) : (SK_MAXS <= 5 ? 4 : 2)))))
 void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_arg, int n_arg, int rg_arg,
                         const unsigned char* wscale_arg, const void* bias_arg, const void* res_arg, const float* gw_arg, GemvArgs a) {
@@ -233,6 +252,8 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
   static_assert(!W8 || sizeof(T) == 2, "MXFP8 weights go with bf16 activations");
   static_assert(TR == 16 || (!MULTI && EPI != SK_KV && EPI != SK_F32), "narrow tiles: plain / residual / GELU projections only");
   static_assert(!W8 || TR == 16 || TR == 8, "MXFP8 weights: 16- or 8-row tiles");
+  static_assert(!A16 || W8, "A16 is a flavour of the MXFP8-weight kernel");
+  static_assert(!W8 || CG == 1 || A16, "several stream groups with MXFP8 weights: W8A16 only");
   constexpr int E = ElemTraits<T>::kPer16B;
   constexpr int XPS = W8 ? 4 : 1;  // 32-wide activation fragments per MFMA step
   constexpr int WPS = W8 ? 2 : 1;  // 16-B weight requests per MFMA step
@@ -271,7 +292,8 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
   const int ej = (tid >> 4) & 15, ei = tid & 15;  // epilogue role of threads 0..255: stream ej, tile row ei (rows >= TR idle)
 
   u32x4_t wq[SK_MAXS * WPS], xq[CG][SK_MAXS * XPS];
-  int wsc[SK_MAXS];  // MXFP8: scale byte of this lane's 32-value weight block
+  int wsc[SK_MAXS];  // MXFP8: scale byte of the weight block this lane feeds to the scaled MFMA (A16: of its own first block)
+  int wsc2[A16 ? SK_MAXS : 1];  // A16: scale byte of its own second block
   float e_c = 0.f, e_gw = 0.f, e_res[CG];
 #pragma unroll
   for (int g = 0; g < CG; ++g) e_res[g] = 0.f;
@@ -313,7 +335,12 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
         const long long st = min(s0 + i, S - 1);
         wq[2 * i] = sk_load_w<unsigned char>(wt + st * 2048);
         wq[2 * i + 1] = sk_load_w<unsigned char>(wt + st * 2048 + 1024);
-        wsc[i] = ws[st * 64];
+        if constexpr (A16) {
+          wsc[i] = wscale[(long long)tl * S * 64 + st * 64 + (kq >> 1) * 16 + fr];
+          wsc2[i] = wscale[(long long)tl * S * 64 + st * 64 + (2 + (kq >> 1)) * 16 + fr];
+        } else {
+          wsc[i] = ws[st * 64];
+        }
       }
     } else if (W8) {
       // 8-row MXFP8 tiles (quant_mx8_kernel with tr = 8): per (tile, 128-k step) [half][kq*8 + row][16 B] + 32 scale bytes;
@@ -327,7 +354,14 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
         const unsigned o = lane_off + tile_off + st * (unsigned)(8 * TR * 16);
         wq[2 * i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wr, o, 0, 2 /* nt */));
         wq[2 * i + 1] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(wr, o + (unsigned)(4 * TR * 16), 0, 2));
-        wsc[i] = (int)__builtin_amdgcn_raw_buffer_load_b8(wsr, sc_off + ((unsigned)tl * S + st) * (unsigned)(4 * TR), 0, 0);
+        if constexpr (A16) {
+          const unsigned sc_a = (fr < TR) ? (unsigned)((kq >> 1) * TR + fr) : 0x80000000u;
+          const unsigned sc_b = (fr < TR) ? (unsigned)((2 + (kq >> 1)) * TR + fr) : 0x80000000u;
+          wsc[i] = (int)__builtin_amdgcn_raw_buffer_load_b8(wsr, sc_a + ((unsigned)tl * S + st) * (unsigned)(4 * TR), 0, 0);
+          wsc2[i] = (int)__builtin_amdgcn_raw_buffer_load_b8(wsr, sc_b + ((unsigned)tl * S + st) * (unsigned)(4 * TR), 0, 0);
+        } else {
+          wsc[i] = (int)__builtin_amdgcn_raw_buffer_load_b8(wsr, sc_off + ((unsigned)tl * S + st) * (unsigned)(4 * TR), 0, 0);
+        }
       }
     } else if (TR == 16) {
       const T* wt = W + ((long long)tl * S * 64 + lane) * E;
@@ -397,7 +431,20 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
       for (int i = 0; i < SK_MAXS; ++i) {
         const bool on = s0 + i < s_hi;  // wave-uniform: steps past this wavefront's K slice contribute zero
         const u32x4_t zero = u32x4_t{0u, 0u, 0u, 0u};
-        if (W8) {
+        if constexpr (A16) {
+          // fragments m = 0, 1 live in the first 16 bytes (block h = 0), m = 2, 3 in the second (h = 1)
+          u32x4_t wf[4];
+          sk_widen8(on ? wq[2 * i] : zero, __builtin_bit_cast(float, (unsigned)(wsc[i] & 0xff) << 23), wf[0], wf[1]);
+          sk_widen8(on ? wq[2 * i + 1] : zero, __builtin_bit_cast(float, (unsigned)(wsc2[i] & 0xff) << 23), wf[2], wf[3]);
+#pragma unroll
+          for (int g = 0; g < CG; ++g)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              const u32x4_t xv = on ? xq[g][i * 4 + m] : zero;
+              if (LN && (!MULTI || grp == 0)) sk_stats<T>(xv, ps[g], pss[g]);
+              acc[g] = sk_mfma<T>(wf[m], xv, acc[g]);
+            }
+        } else if (W8) {
           const u32x4_t w0 = on ? wq[2 * i] : zero, w1 = on ? wq[2 * i + 1] : zero;
           const v8i_t wb = {(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
 #pragma unroll
@@ -1257,11 +1304,11 @@ static int env_int(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-template <typename T, int NW, int SK_MAXS, bool MULTI, bool W8, int CG, int TR>
+template <typename T, int NW, int SK_MAXS, bool MULTI, bool W8, int CG, int TR, bool A16 = false>
 static hipError_t skinny_launch_cg(const GemvArgs& a, dim3 grid, size_t lds1, hipStream_t st) {
   const bool ln = a.ln_gw != nullptr;
   const size_t lds = lds1 * CG;
-#define SK_GO(LNV, EPIV) hipLaunchKernelGGL((skinny_mfma_kernel<T, NW, SK_MAXS, LNV, EPIV, MULTI, W8, CG, TR>), grid, dim3(NW * 64), lds, st, \
+#define SK_GO(LNV, EPIV) hipLaunchKernelGGL((skinny_mfma_kernel<T, NW, SK_MAXS, LNV, EPIV, MULTI, W8, CG, TR, A16>), grid, dim3(NW * 64), lds, st, \
                                             a.x, a.W, a.K, a.B, a.N, a.rg, a.wscale, a.bias, a.res, a.ln_gw, a)
   if constexpr (TR != 16) {  // narrow tiles: plain / residual / GELU projections, one tile per workgroup
     if (a.y_f32 || a.kcache) return hipErrorInvalidValue;
@@ -1304,9 +1351,24 @@ static hipError_t skinny_launch_cg(const GemvArgs& a, dim3 grid, size_t lds1, hi
 
 template <typename T, int NW, int SK_MAXS, bool MULTI, bool W8, int TR>
 static hipError_t skinny_launch_v(const GemvArgs& a, dim3 grid, size_t lds1, hipStream_t st) {
+  if constexpr (W8) {
+    // MXFP8 weights.  a.a16: W8A16 (weights widened in registers, bf16 activations) - the only flavour with several groups
+    // of 16 streams (2 steps = 8 activation fragments per group in flight, further rounds for longer K)
+    if (a.a16) {
+      if (a.B <= 16) return skinny_launch_cg<T, NW, SK_MAXS, MULTI, true, 1, TR, true>(a, grid, lds1, st);
+      if constexpr (NW != 8 || SK_MAXS != 2) {
+        return hipErrorInvalidValue;
+      } else {
+        if (a.B <= 32) return skinny_launch_cg<T, NW, SK_MAXS, MULTI, true, 2, TR, true>(a, grid, lds1, st);
+        return skinny_launch_cg<T, NW, SK_MAXS, MULTI, true, 4, TR, true>(a, grid, lds1, st);
+      }
+    }
+    if (a.B > 16) return hipErrorInvalidValue;
+    return skinny_launch_cg<T, NW, SK_MAXS, MULTI, true, 1, TR>(a, grid, lds1, st);
+  }
   if (a.B <= 16) return skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 1, TR>(a, grid, lds1, st);
   // several groups of 16 streams: 8 wavefronts x 5 fragments in flight (more rounds for long K) keeps the per-group
-  // activation fragments inside the register file; MXFP8 contexts are limited to one group
+  // activation fragments inside the register file
   if constexpr (W8 || NW != 8 || SK_MAXS != 5) {
     return hipErrorInvalidValue;
   } else {
@@ -1352,19 +1414,20 @@ static hipError_t skinny_launch_w8(const GemvArgs& a0, hipStream_t st) {
   const int tiles = (a.N + TR - 1) / TR;
   static const int max_blocks = env_int("TW_SK_MAX_BLOCKS", 512);
   const int steps_per_wave = (a.K / 128 + NW - 1) / NW;
+  const bool groups = a.B > 16;   // W8A16 only (skinny_launch_v): 2 steps in flight per group, further rounds for longer K
   a.rg = (tiles + max_blocks - 1) / max_blocks;
-  if (a.rg < 1 || steps_per_wave > 3) a.rg = 1;
+  if (a.rg < 1 || steps_per_wave > (groups ? 2 : 3)) a.rg = 1;   // several tiles per workgroup only with one round per tile
   dim3 grid((tiles + a.rg - 1) / a.rg);
   if constexpr (TR != 16) {
     if (a.rg > 1) return hipErrorInvalidValue;
-    if (steps_per_wave <= 2) return skinny_launch_v<bf16_t, NW, 2, false, true, TR>(a, grid, lds, st);
+    if (steps_per_wave <= 2 || groups) return skinny_launch_v<bf16_t, NW, 2, false, true, TR>(a, grid, lds, st);
     return skinny_launch_v<bf16_t, NW, 3, false, true, TR>(a, grid, lds, st);
   } else {
     if (a.rg > 1) {
-      if (steps_per_wave <= 2) return skinny_launch_v<bf16_t, NW, 2, true, true, 16>(a, grid, lds, st);
+      if (steps_per_wave <= 2 || groups) return skinny_launch_v<bf16_t, NW, 2, true, true, 16>(a, grid, lds, st);
       return skinny_launch_v<bf16_t, NW, 3, true, true, 16>(a, grid, lds, st);
     }
-    if (steps_per_wave <= 2) return skinny_launch_v<bf16_t, NW, 2, false, true, 16>(a, grid, lds, st);
+    if (steps_per_wave <= 2 || groups) return skinny_launch_v<bf16_t, NW, 2, false, true, 16>(a, grid, lds, st);
     return skinny_launch_v<bf16_t, NW, 3, false, true, 16>(a, grid, lds, st);
   }
 }

@@ -124,6 +124,35 @@ __device__ __forceinline__ f32x4_t mfma_step<float>(const u32x4_t& wfrag, const 
   return acc;
 }
 
+// Workgroup id -> output tile.  The hardware hands consecutive workgroup ids to the 8 XCDs round-robin (id % 8, MI355X_MICROARCH.md
+// "Workgroup dispatch"), and every XCD has its own 4 MiB L2: with a plain 2-D grid the ~64 workgroups resident on one XCD are
+// scattered over the whole tile space (QKV projection of 16 x 10 s: 34 different activation tile-rows and all 15 weight
+// tile-columns), so every K slice an XCD streams is used by ~3 of its workgroups before it is evicted - the GEMMs ran at the
+// rate the L2s MISS at.  swz = 1: the tile list, ordered in groups of GM tile-rows (m fastest inside a group, then n), is cut
+// into 8 contiguous chunks and chunk x is walked by XCD x in dispatch order, so the workgroups resident on an XCD at any
+// moment cover about GM x 8 neighbouring tiles: each activation slice is shared by ~8 and each weight slice by ~GM of them.
+// swz = 0: n fastest over the whole grid (the 2-D grid's order), kept for A/B runs (TW_GEMM_XCD=0).
+// Returns false for the padding ids of the last chunk.
+__device__ __forceinline__ bool tw_tile_of_block(int id, int Tm, int Tn, int swz, int& tm, int& tn) {
+  const int NT = Tm * Tn;
+  if (swz == 0) {
+    tm = id / Tn;
+    tn = id - tm * Tn;
+    return id < NT;
+  }
+  constexpr int GM = 8;
+  const int chunk = (NT + 7) >> 3;
+  const int local = id >> 3, xcd = id & 7;
+  const int t = xcd * chunk + local;
+  if (local >= chunk || t >= NT) return false;
+  const int per_group = GM * Tn;
+  const int g = t / per_group, r = t - g * per_group;
+  const int gm = min(GM, Tm - g * GM);
+  tn = r / gm;
+  tm = g * GM + (r - tn * gm);
+  return true;
+}
+
 // ---- epilogue shared by the kernels below: a lane holds, per (a,b) MFMA tile, 4 consecutive columns n of row m ----
 template <typename T, int NT, int MT>
 __device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[NT][MT], int m_base, int n_base, int M, int N,
@@ -280,7 +309,7 @@ __device__ __forceinline__ void gemm_epilogue_kv8(const f32x4_t (&acc)[NT][MT], 
 // Used for small M (single stream) where the grid needs small tiles.
 template <typename T, int BM, int BN, int WM, int WN, int ST>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const T* __restrict__ A, RowMap amap, const T* __restrict__ W,
-                                                              int M, int N, int K, GemmEpilogue ep) {
+                                                              int M, int N, int K, int Tm, int Tn, int swz, GemmEpilogue ep) {
   constexpr int E = ElemTraits<T>::kPer16B;  // elements per 16-B vector
   constexpr int BKE = 8 * E;                 // elements per K tile (two MFMA k-steps)
   constexpr int NWAVE = WM * WN;
@@ -299,8 +328,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const T* __restrict_
   const int wave = tid >> 6;
   const int wn = wave % WN;  // wave position along N
   const int wm = wave / WN;  // along M
-  const int n0 = blockIdx.x * BN;
-  const int m0 = blockIdx.y * BM;
+  int tile_m, tile_n;
+  if (!tw_tile_of_block(blockIdx.x, Tm, Tn, swz, tile_m, tile_n)) return;   // (whole workgroup: before any barrier)
+  const int n0 = tile_n * BN;
+  const int m0 = tile_m * BM;
   const int S = K / (4 * E);
 
   // Activations: the DMA writes the 64 lanes of a wavefront to 64 consecutive 16-B LDS slots, so the swizzle is applied on
@@ -404,7 +435,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const T* __restrict_
 // Per K tile and CU: 16 KB of DMA + 32 fragment reads per wavefront for 64 MFMAs each, and (16 + 32) KB for 4.2 MFLOP.
 template <typename T, int BM, int NW, int ST>
 __global__ __launch_bounds__(NW * 64, 2) void gemm_wreg_kernel(const T* __restrict__ A, RowMap amap, const T* __restrict__ W,
-                                                             int M, int N, int K, GemmEpilogue ep) {
+                                                             int M, int N, int K, int Tm, int Tn, int swz, GemmEpilogue ep) {
   constexpr int E = ElemTraits<T>::kPer16B;
   constexpr int BKE = 8 * E;
   constexpr int BN = NW * 64;
@@ -418,8 +449,10 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_wreg_kernel(const T* __restri
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int n0 = blockIdx.x * BN + wave * 64;
-  const int m0 = blockIdx.y * BM;
+  int tile_m, tile_n;
+  if (!tw_tile_of_block(blockIdx.x, Tm, Tn, swz, tile_m, tile_n)) return;   // (whole workgroup: before any barrier)
+  const int n0 = tile_n * BN + wave * 64;
+  const int m0 = tile_m * BM;
   const int S = K / (4 * E);
   const int fr = lane & 15, fq = lane >> 4;
 
@@ -518,19 +551,31 @@ static int gemm_env(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
+// 1-D grid of 8 * ceil(tiles / 8) workgroups (tw_tile_of_block); TW_GEMM_XCD=0 restores the row-major tile order for A/B runs
+static int gemm_grid(int Tm, int Tn, int* swz) {
+  static const int xcd = gemm_env("TW_GEMM_XCD", 1);
+  *swz = xcd ? 1 : 0;
+  const int NT = Tm * Tn;
+  return xcd ? 8 * ((NT + 7) / 8) : NT;
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int ST>
 static hipError_t gemm_go(const void* A, RowMap amap, const void* W, int M, int N, int K, const GemmEpilogue& ep, hipStream_t st) {
-  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM);
+  const int Tn = (N + BN - 1) / BN, Tm = (M + BM - 1) / BM;
+  int swz;
+  dim3 grid(gemm_grid(Tm, Tn, &swz));
   hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, ST>), grid, dim3(WM * WN * 64), 0, st, reinterpret_cast<const T*>(A), amap,
-                     reinterpret_cast<const T*>(W), M, N, K, ep);
+                     reinterpret_cast<const T*>(W), M, N, K, Tm, Tn, swz, ep);
   return hipGetLastError();
 }
 
 template <typename T, int BM, int NW, int ST>
 static hipError_t gemm_wreg_go(const void* A, RowMap amap, const void* W, int M, int N, int K, const GemmEpilogue& ep, hipStream_t st) {
-  dim3 grid((N + NW * 64 - 1) / (NW * 64), (M + BM - 1) / BM);
+  const int Tn = (N + NW * 64 - 1) / (NW * 64), Tm = (M + BM - 1) / BM;
+  int swz;
+  dim3 grid(gemm_grid(Tm, Tn, &swz));
   hipLaunchKernelGGL((gemm_wreg_kernel<T, BM, NW, ST>), grid, dim3(NW * 64), 0, st, reinterpret_cast<const T*>(A), amap,
-                     reinterpret_cast<const T*>(W), M, N, K, ep);
+                     reinterpret_cast<const T*>(W), M, N, K, Tm, Tn, swz, ep);
   return hipGetLastError();
 }
 

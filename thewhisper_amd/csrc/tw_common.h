@@ -169,6 +169,7 @@ struct GemvArgs {
   const float* ln_gw; const float* ln_cb;
   const void* W; const void* bias;     // [N, K] in the fragment-major layout of launch_tile_weights, [N]
   const unsigned char* wscale;         // non-null: W is MXFP8 (launch_quant_mx8), these are its block scales; bf16 activations
+  int a16;                             // with wscale: 1 = W8A16 (weights widened to bf16 in registers, activations not quantised)
   int N, K, B;
   int gelu;
   const void* res; int ldres;    // residual [16, N] (fragment-major) added after bias/act; output then fragment-major too

@@ -6,6 +6,8 @@ path runs in libthewhisper_gfx950.so.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
@@ -20,6 +22,12 @@ _TORCH2TW = {torch.float32: _cabi.TW_F32, torch.bfloat16: _cabi.TW_BF16, torch.f
 def _stream_ptr(device: torch.device) -> C.c_void_p:
     s = torch.cuda.current_stream(device).cuda_stream
     return C.c_void_p(int(s) if s else None)
+
+
+# Which flavour `dtype="fp8"` means (BASELINE config 5): "fp8a16" = MXFP8 weights widened to bf16 in registers, activations not
+# quantised (TW_BF16_W8A16: no activation-quantisation error, up to 64 streams); "fp8a8" = weights AND activations on the scaled fp8
+# MFMA (TW_BF16_MXFP8, <= 16 streams).  THEWHISPER_FP8=a8|a16 overrides.
+FP8_DEFAULT = {"a8": "fp8a8", "a16": "fp8a16"}.get(os.environ.get("THEWHISPER_FP8", "").lower(), "fp8a16")
 
 
 class WhisperEngine:
@@ -88,10 +96,14 @@ class WhisperEngine:
         self.T = int(T)
         self.max_batch = int(max_batch)
         self.device = torch.device("cuda", device)
-        self.dtype_name = dtype
         # "fp8" = bf16 activations and encoder, decoder projection weights quantised to MXFP8 at load (BASELINE config 5)
-        self.tw_dtype = {"bf16": _cabi.TW_BF16, "f32": _cabi.TW_F32, "fp8": _cabi.TW_BF16_MXFP8}[dtype]
-        self.torch_dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "fp8": torch.bfloat16}[dtype]
+        # "fp8a16" = the same fp8 weights widened to bf16 in registers, activations NOT quantised (up to 64 streams); "fp8a8" =
+        # weights and activations on the scaled fp8 MFMA (<= 16 streams); "fp8" = the flavour config 5 ships with (FP8_DEFAULT)
+        if dtype == "fp8":
+            dtype = FP8_DEFAULT
+        self.dtype_name = dtype
+        self.tw_dtype = {"bf16": _cabi.TW_BF16, "f32": _cabi.TW_F32, "fp8a8": _cabi.TW_BF16_MXFP8, "fp8a16": _cabi.TW_BF16_W8A16}[dtype]
+        self.torch_dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "fp8a8": torch.bfloat16, "fp8a16": torch.bfloat16}[dtype]
         self.alignment_heads = [tuple(map(int, x)) for x in (alignment_heads or [])]
         cfg = _cabi.tw_config()
         cfg.d_model = dims["d_model"]
