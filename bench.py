@@ -252,23 +252,46 @@ def pipeline_leg(eng, dims, args, device_index, heads, latency_calls, hub_rounds
             [t.join() for t in th]
 
         out = {}
-        hub = BatchingHub(backend, max_batch=B, max_wait_s=0.004)
-        free_running(hub, 1)                       # warm-up: plan learning + graph capture for this batch size
-        hub.latencies.clear(); hub.batches.clear(); counted["tok"] = 0
-        t0 = time.perf_counter()
-        free_running(hub, hub_rounds)
-        dt = time.perf_counter() - t0
-        lats = sorted(hub.latencies)
-        sizes = list(hub.batches)
-        out.update({
-            "hub_tok_per_s": round(counted["tok"] / dt, 1), "hub_sessions": B, "hub_requests": B * hub_rounds,
-            "hub_mode": "continuous (seek passes of chunks)" if hub.passes else "whole-call batches",
-            "hub_request_p50_ms": round(lats[len(lats) // 2] * 1e3, 2) if lats else None,
-            "hub_request_p90_ms": round(lats[min(len(lats) - 1, (len(lats) * 9) // 10)] * 1e3, 2) if lats else None,
-            "hub_mean_rows_per_pass": round(sum(sizes) / max(1, len(sizes)), 2), "hub_passes": len(sizes),
-            "hub_tokens": counted["tok"],
-        })
-        hub.close()
+
+        def measure(prefix, **hub_kw):
+            hub = BatchingHub(backend, max_batch=B, max_wait_s=0.004, **hub_kw)
+            free_running(hub, 1)                       # warm-up: plan learning + graph capture for this batch size
+            hub.latencies.clear(); hub.batches.clear(); counted["tok"] = 0
+            p0, r0, f0 = hub.passes, hub.rows, hub.prefetched
+            t0 = time.perf_counter()
+            free_running(hub, hub_rounds)
+            dt = time.perf_counter() - t0
+            lats = sorted(hub.latencies)
+            passes, rows = hub.passes - p0, hub.rows - r0
+            res = {
+                f"{prefix}tok_per_s": round(counted["tok"] / dt, 1), f"{prefix}sessions": B, f"{prefix}requests": B * hub_rounds,
+                f"{prefix}mode": "continuous (seek passes of chunks)" if hub._codec is not None else "whole-call batches",
+                f"{prefix}request_p50_ms": round(lats[len(lats) // 2] * 1e3, 2) if lats else None,
+                f"{prefix}request_p90_ms": round(lats[min(len(lats) - 1, (len(lats) * 9) // 10)] * 1e3, 2) if lats else None,
+                f"{prefix}mean_rows_per_pass": round(rows / max(1, passes), 2), f"{prefix}passes": passes,
+                f"{prefix}passes_per_request": round(rows / max(1, B * hub_rounds), 2),
+                f"{prefix}rows_prefetched": hub.prefetched - f0, f"{prefix}tokens": counted["tok"],
+            }
+            hub.close()
+            return res
+
+        # (b1) the headline API reading: arrivals are encoded on a sibling context / CU-masked stream while a pass decodes
+        out.update(measure("hub_", prefetch_cus=args.hub_prefetch_cus))
+        # (b2) the same without the prefetch (round 3's schedule), same box, for the A/B
+        if args.hub_prefetch_cus > 0:
+            r = measure("hub_noprefetch_")
+            out.update({k: r[k] for k in ("hub_noprefetch_tok_per_s", "hub_noprefetch_request_p50_ms", "hub_noprefetch_request_p90_ms")})
+        # (b3) the trained-model regime: a random-weight decoder closes timestamp pairs at random places and so needs ~3 seek passes
+        #      per 10 s buffer; a trained model needs 1-2.  With `hub_short_tokens` new tokens per pass the same streams need <= 2
+        #      passes per buffer (reported), which is the regime in which the 0.5 s cadence of the reference scheduler is testable
+        if args.hub_short_tokens > 0:
+            full_kwargs = backend._generate_kwargs
+            backend._generate_kwargs = lambda: {**full_kwargs(), "max_new_tokens": args.hub_short_tokens}
+            try:
+                out.update(measure("hub_short_", prefetch_cus=args.hub_prefetch_cus))
+                out["hub_short_max_new_tokens"] = args.hub_short_tokens
+            finally:
+                backend._generate_kwargs = full_kwargs
         hub = BatchingHub(backend, max_batch=B, max_wait_s=0.05, continuous=False)
         lockstep(hub, 1)
         counted["tok"] = 0
@@ -414,6 +437,10 @@ def main(argv=None):
     ap.add_argument("--no-pipeline-leg", action="store_true", help="skip the measurement through ASRPipeline / BatchingHub")
     ap.add_argument("--no-secondary", action="store_true", help="skip the compact legs for BASELINE configs 2 (turbo, 30 s, 1 stream) and 5 (fp8, 15 s)")
     ap.add_argument("--hub-rounds", type=int, default=12, help="requests per session in the hub measurement")
+    ap.add_argument("--hub-prefetch-cus", type=int, default=96,
+                    help="compute units of the side stream that encodes arrivals while a hub pass decodes (0 = off; serving.py)")
+    ap.add_argument("--hub-short-tokens", type=int, default=24,
+                    help="max_new_tokens of the second hub measurement (the <= 2 passes per buffer regime; 0 = skip)")
     args = ap.parse_args(argv)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

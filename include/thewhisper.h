@@ -106,6 +106,12 @@ const char* tw_last_error(const tw_ctx* ctx);
  * (R:thestage_speechkit/nvidia/asr_pipeline.py:47-60). */
 int tw_create(const tw_config* cfg, tw_ctx** out);
 int tw_destroy(tw_ctx* ctx);
+/* A second context of the SAME model on the same device that shares `src`'s finalized weights (no copy: `src` owns them and must be
+ * destroyed after the sibling) and has its own workspace, K/V arenas (for `max_batch` streams), graphs and timing events.  What it
+ * is for: two stages of a serving pipeline on one GPU at the same time - the encoder stage of new chunks on a CU-masked stream
+ * while the decode loop of the current pass runs (a context is not thread-safe, two contexts are independent).  No reference
+ * counterpart (one pipeline object, one request at a time: R:examples/server.py:22-115). */
+int tw_create_sibling(const tw_ctx* src, int32_t max_batch, tw_ctx** out);
 
 /* Replaces: `from_pretrained` weight materialisation (R:thestage_speechkit/nvidia/asr_pipeline.py:58-60).
  * `name` is the HF state_dict key (layout table in SURVEY.md section 8b), `dev_ptr` a contiguous device tensor
@@ -144,6 +150,17 @@ int tw_cross_kv(tw_ctx* ctx, int32_t B, void* stream);
  * independent of the grouping.  tw_encode / tw_cross_kv are the slot0 = 0 forms and reset the number of filled slots. */
 int tw_encode_at(tw_ctx* ctx, const void* mel_dev, int32_t mel_dtype, int32_t B, int32_t slot0, void* stream);
 int tw_cross_kv_at(tw_ctx* ctx, int32_t B, int32_t slot0, void* stream);
+
+/* Cross K/V of slots src_slot0 .. src_slot0+B-1 of `src` become slots dst_slot0 .. dst_slot0+B-1 of `dst` (device-to-device copies
+ * on `stream`; both contexts: same model dimensions, same source_positions, same dtype, same device; dst_slot0 must be the
+ * number of slots `dst` holds, like tw_cross_kv_at).  `src_stream` = the stream `src`'s encoder stage was enqueued on (NULL = its
+ * default): the copies are ordered after everything enqueued there so far, and whatever is enqueued there next after the copies
+ * (so the source may refill the slots at once).  The caller must not run another call on `src` concurrently with this one.  What it is for: a serving loop encodes the chunks that ARRIVE while a pass is
+ * decoding on a second context of the same weights (its own workspace and arenas, a CU-masked stream), and the next pass adopts
+ * them - their encoder stage is then hidden under the previous pass's decode loop (thewhisper_amd/serving.py).  No reference
+ * counterpart (R:examples/server.py:22-115 processes one request at a time).  Results are the ones tw_encode_at + tw_cross_kv_at
+ * on `dst` would have produced: same kernels, same weights. */
+int tw_adopt_cross_kv(tw_ctx* dst, int32_t dst_slot0, tw_ctx* src, int32_t src_slot0, int32_t B, void* stream, void* src_stream);
 
 /* A6-A8.  Replaces: WhisperDecoder.forward + proj_out for ONE new token per stream
  * (HF:models/whisper/modeling_whisper.py:649-795, :1080).  tw_decoder_reset rewinds the self-attention

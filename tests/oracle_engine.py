@@ -56,6 +56,28 @@ class OracleEngine:
     def cross_kv(self, B: int, slot0=0):
         assert self._enc.shape[0] >= slot0 + B
 
+    device = None   # no HIP device: serving._Prefetcher then runs without a CU-masked stream
+
+    def sibling(self, max_batch=None):
+        """Same model, own state (WhisperEngine.sibling / tw_create_sibling)."""
+        new = OracleEngine.__new__(OracleEngine)
+        new.__dict__.update(self.__dict__)
+        new.max_batch = int(max_batch or self.max_batch)
+        new.calls = {"logmel": 0, "encode": 0, "generate": 0, "dtw": 0}
+        new._enc = None
+        return new
+
+    def adopt_cross_kv(self, src, src_slot0: int, B: int, dst_slot0: int):
+        """tw_adopt_cross_kv: slots of another context become this one's next slots."""
+        part = src._enc[src_slot0 : src_slot0 + B]
+        assert part.shape[0] == B and dst_slot0 + B <= self.max_batch
+        prev = self._enc[:dst_slot0] if dst_slot0 else part[:0]
+        assert prev.shape[0] == dst_slot0
+        self._enc = np.concatenate([prev, part], axis=0)
+
+    def close(self):
+        pass
+
     def decoder_reset(self, B: int):
         self._cache = self.model.new_cache(self._enc[:B])
 

@@ -257,6 +257,51 @@ def test_w8a16_groups_of_streams_match_single_group():
         make_engine(dims, w, T=T, max_batch=B, dtype="fp8a8")
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp8a16"])
+def test_sibling_context_and_adopted_cross_kv_are_bit_identical(dtype):
+    """tw_create_sibling + tw_adopt_cross_kv (the serving loop's prefetch path): clips encoded by a sibling context (shared
+    weights, own workspace) on a CU-masked stream and adopted into slots 1.. of the main context decode to EXACTLY the logits the
+    main context computes when it encodes them itself - same kernels, same weights."""
+    from thewhisper_amd.overlap import masked_stream
+
+    dims = dims_variant("micro", enc_layers=2, dec_layers=2)
+    w = wo.make_weights(dims, 9)
+    T, B = 100, 5
+    mel = torch.from_numpy(wo.log_mel(clips(T * 320, B), dims.n_mels)).cuda()
+    ids = np.concatenate([np.tile(np.array(PROMPT), (B, 1)), np.random.default_rng(1).integers(0, 50000, size=(B, 3))], axis=1)
+    eng = make_engine(dims, w, T=T, max_batch=B, dtype=dtype)
+
+    def logits():
+        eng.decoder_reset(B)
+        return np.stack([eng.decode_step(ids[:, s].tolist()).cpu().numpy() for s in range(ids.shape[1])], axis=1)
+
+    eng.encode(mel)
+    eng.cross_kv(B)
+    ref = logits()
+    side = eng.sibling(max_batch=4)
+    n_cus = torch.cuda.get_device_properties(0).multi_processor_count
+    side.raw_stream = masked_stream(n_cus - 64, n_cus, n_cus, 0)
+    side.encode(mel[1:3])                      # clips 1, 2 -> sibling slots 0, 1
+    side.encode(mel[3:5], slot0=2)             # clips 3, 4 -> sibling slots 2, 3
+    side.cross_kv(2)
+    side.cross_kv(2, slot0=2)
+    eng.encode(mel[:1])                        # clip 0 the ordinary way ...
+    eng.cross_kv(1)
+    eng.adopt_cross_kv(side, 0, 3, 1)          # ... sibling slots 0..2 -> main slots 1..3
+    eng.adopt_cross_kv(side, 3, 1, 4)          # ... sibling slot 3 -> main slot 4
+    got = logits()
+    assert np.array_equal(got, ref)
+    with pytest.raises(RuntimeError, match="tw_adopt_cross_kv"):
+        eng.adopt_cross_kv(side, 3, 2, 0)      # the sibling holds 4 clips
+    with pytest.raises(RuntimeError, match="shares another context's weights"):
+        side.load_weight("model.encoder.conv1.bias", torch.zeros(dims.d_model))
+    from thewhisper_amd.overlap import _hiplib
+    st, side.raw_stream = side.raw_stream, None
+    _hiplib().stream_destroy(st)
+    eng.close()                                # closes the sibling first
+    assert side.ctx is None
+
+
 def test_mxfp8_greedy_generation_runs_and_is_deterministic():
     """The fp8 context runs the whole path (graph replay, sampler, alignment, DTW); ids are deterministic across calls and
     batch positions (there is no reference for fp8 token ids: with random weights they legitimately differ from bf16)."""

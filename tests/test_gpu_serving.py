@@ -131,3 +131,29 @@ def test_eval_harness_drives_the_gpu_pipeline():
     ins = evaluate_dataset(gen, [a.copy() for a in audio], refs, language="en", generate_kwargs=gk, batch_size=4)
     assert abs(ins["wer"] - len(refs) / sum(len(r.split()) for r in refs)) < 1e-12
     assert mean_over_tasks({"a": exact, "b": ins})["wer"] == ins["wer"] / 2
+
+
+def test_hub_prefetch_on_gpu_gives_the_direct_results():
+    """BatchingHub(prefetch_cus=96): arrivals during a pass are encoded on the sibling context / CU-masked stream and adopted by the
+    next pass.  Words equal direct backend calls; rows did take the prefetch route."""
+    import time
+
+    from tests.test_pipeline_glue import build_amd_pipeline, normalise
+    from thewhisper_amd import AMDWhisperBackend
+    from thewhisper_amd.serving import BatchingHub
+
+    pipe = build_amd_pipeline("micro", 10, 4, device="cuda", engine_factory=None)
+    backend = AMDWhisperBackend(None, chunk_length_s=10, asr_pipeline=pipe)
+    clips = [wo.synth_audio(16000 * 6 + 1600 * k, 70 + k, ["speechlike", "noise", "sine"][k % 3]) for k in range(12)]
+    direct = [normalise(backend.transcribe(c.copy(), 0.5 * k, 16000)) for k, c in enumerate(clips)]
+    hub = BatchingHub(backend, max_batch=4, max_wait_s=0.002, prefetch_cus=96)
+    futs = []
+    for k, c in enumerate(clips):               # a steady trickle: most requests arrive while some pass is decoding
+        futs.append(hub.submit(c.copy(), 0.5 * k, 16000))
+        time.sleep(0.004)
+    got = [normalise(f.result(timeout=300)) for f in futs]
+    prefetched, rows = hub.prefetched, hub.rows
+    hub.close()
+    assert got == direct
+    assert prefetched >= 1, (prefetched, rows)
+    print(f"\nHUB PREFETCH: {prefetched} of {rows} rows were encoded under another pass's decode loop")

@@ -193,6 +193,47 @@ def test_continuous_hub_fills_passes_across_requests_and_answers_early():
     assert max(done_at[0], done_at[1]) <= min(done_at[i] for i in range(2, 6))  # answered when THEIR chunks were done
 
 
+def test_hub_prefetches_the_encoder_stage_of_arrivals_during_a_pass():
+    """`prefetch_cus > 0`: requests that arrive WHILE a pass decodes are opened and encoded on a sibling context by the prefetch
+    thread, and the next pass adopts those rows (tw_adopt_cross_kv; here the CPU stand-in's sibling / adopt_cross_kv): results
+    are exactly the per-request results, every chunk-pass still runs exactly once, and rows did take the prefetch route."""
+    import time
+
+    from tests.test_shortform import build
+    from thewhisper_amd import AMDWhisperBackend
+    from thewhisper_amd.serving import BatchingHub
+
+    pipe = build(batch_size=4, chunk_s=30)
+    backend = AMDWhisperBackend(None, chunk_length_s=30, asr_pipeline=pipe)
+    backend._generate_kwargs = lambda: {"use_cache": True, "num_beams": 1, "do_sample": False, "max_new_tokens": 24, "language": "en"}
+    lens = [480000, 336000, 160000, 475679, 240000, 480000, 400000]
+    bufs = [(wo.synth_audio(n, 40 + i, ["speechlike", "noise", "sine", "speechlike", "zeros", "noise", "sine"][i]), 1.5 * i, 16000)
+            for i, n in enumerate(lens)]
+    eng = pipe.model.engine
+    single, passes_single = [], []
+    for a, t0, sr in bufs:
+        n0 = eng.calls["generate"]
+        single.append(backend.transcribe(a.copy(), t0, sr))
+        passes_single.append(eng.calls["generate"] - n0)
+    hub = BatchingHub(backend, max_batch=4, max_wait_s=0.05, prefetch_cus=8)
+    futs = [hub.submit(a.copy(), t0, sr) for a, t0, sr in bufs[:2]]
+    t_end = time.monotonic() + 120
+    while hub.passes < 1 and time.monotonic() < t_end:      # the first pass is decoding (seconds on the numpy engine) ...
+        time.sleep(0.005)
+    futs += [hub.submit(a.copy(), t0, sr) for a, t0, sr in bufs[2:5]]   # ... when three more arrive: the prefetch thread takes them
+    while hub.passes < 3 and time.monotonic() < t_end:
+        time.sleep(0.005)
+    futs += [hub.submit(a.copy(), t0, sr) for a, t0, sr in bufs[5:]]
+    got = [f.result(timeout=600) for f in futs]
+    batches, prefetched = list(hub.batches), hub.prefetched
+    pf = hub._prefetcher
+    hub.close()
+    assert pf is not None and not pf.thread.is_alive()
+    assert normalise(got) == normalise(single)
+    assert sum(batches) == sum(passes_single), (batches, passes_single)     # every chunk-pass ran exactly once
+    assert prefetched >= 3, prefetched                                       # the late arrivals were encoded on the sibling
+
+
 def test_hub_falls_back_to_whole_call_batches_when_the_call_is_not_eligible():
     from thewhisper_amd import AMDWhisperBackend
     from thewhisper_amd.serving import BatchingHub

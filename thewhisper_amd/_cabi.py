@@ -45,6 +45,7 @@ SYMBOLS = [
     ("tw_last_error", C.c_char_p, [_P]),
     ("tw_create", C.c_int, [C.POINTER(tw_config), C.POINTER(_P)]),
     ("tw_destroy", C.c_int, [_P]),
+    ("tw_create_sibling", C.c_int, [_P, C.c_int32, C.POINTER(_P)]),
     ("tw_load_weight", C.c_int, [_P, C.c_char_p, _P, C.c_int32, C.c_int32, C.POINTER(C.c_int64), _P]),
     ("tw_finalize_weights", C.c_int, [_P, _P]),
     ("tw_logmel", C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int32), C.c_int32, C.c_int32, _P, C.c_int32, _P]),
@@ -52,6 +53,7 @@ SYMBOLS = [
     ("tw_cross_kv", C.c_int, [_P, C.c_int32, _P]),
     ("tw_encode_at", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     ("tw_cross_kv_at", C.c_int, [_P, C.c_int32, C.c_int32, _P]),
+    ("tw_adopt_cross_kv", C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P]),
     ("tw_decoder_reset", C.c_int, [_P, C.c_int32, _P]),
     ("tw_decode_step", C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), _P, _P]),
     ("tw_generate_greedy", C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(tw_greedy_opts),

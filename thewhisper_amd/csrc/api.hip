@@ -63,6 +63,7 @@ struct tw_ctx {
   std::vector<LayerW> enc, dec;
   std::set<std::string> loaded;
   bool finalized = false;
+  bool shares_weights = false;   // tw_create_sibling: the weight pointers belong to another context (never freed here)
 
   // log-mel
   LogmelTables lm{};
@@ -237,7 +238,22 @@ int tw_destroy(tw_ctx* c) {
   return TW_OK;
 }
 
-int tw_create(const tw_config* cfg, tw_ctx** out) {
+static int create_ctx(const tw_config* cfg, const tw_ctx* share, tw_ctx** out);
+
+int tw_create(const tw_config* cfg, tw_ctx** out) { return create_ctx(cfg, nullptr, out); }
+
+int tw_create_sibling(const tw_ctx* src, int32_t max_batch, tw_ctx** out) {
+  if (!src || !out) return fail(nullptr, TW_EINVAL, "tw_create_sibling: null argument");
+  if (!src->finalized) return fail(nullptr, TW_ESTATE, "tw_create_sibling: the source context's weights are not finalized");
+  if (src->shares_weights) return fail(nullptr, TW_EINVAL, "tw_create_sibling: the source is itself a sibling (create it from the owner)");
+  tw_config cfg = src->cfg;
+  cfg.max_batch = max_batch;
+  return create_ctx(&cfg, src, out);
+}
+
+// share != nullptr: every weight pointer is taken from `share` (finalized; it owns them and must outlive this context) instead
+// of being allocated; workspace, arenas, streams, events and graphs are this context's own
+static int create_ctx(const tw_config* cfg, const tw_ctx* share, tw_ctx** out) {
   if (!cfg || !out) return fail(nullptr, TW_EINVAL, "tw_create: null argument");
   *out = nullptr;
   if (cfg->heads <= 0 || cfg->d_model != cfg->heads * 64)
@@ -295,6 +311,17 @@ int tw_create(const tw_config* cfg, tw_ctx** out) {
 
   const size_t e = c->esz;
   const size_t d = c->d, H = c->H, F = c->ffn, V = c->V, T = c->T, Tp = c->Tp, P = c->P, C = c->C, B = c->Bmax;
+  if (share) {
+    c->shares_weights = true;
+    c->fuse_cq = share->fuse_cq;
+    c->a16 = share->a16;
+    c->conv1_w = share->conv1_w; c->conv1_b = share->conv1_b; c->conv2_w = share->conv2_w; c->conv2_b = share->conv2_b;
+    c->enc_pos_raw = share->enc_pos_raw; c->enc_pos = share->enc_pos; c->enc_ln_g = share->enc_ln_g; c->enc_ln_b = share->enc_ln_b;
+    c->tok_emb = share->tok_emb; c->dec_pos = share->dec_pos; c->dec_ln_g = share->dec_ln_g; c->dec_ln_b = share->dec_ln_b;
+    c->logit_w = share->logit_w; c->logit_gw = share->logit_gw; c->logit_cb = share->logit_cb; c->logit_ws = share->logit_ws;
+    c->enc = share->enc; c->dec = share->dec;
+    c->loaded = share->loaded; c->enc_pos_rows = share->enc_pos_rows; c->finalized = true;
+  } else {
   // ---- weights ----
   CALLOC(c->conv1_w, d * 3 * C * e, true);
   CALLOC(c->conv1_b, d * e, true);
@@ -336,6 +363,7 @@ int tw_create(const tw_config* cfg, tw_ctx** out) {
   };
   for (auto& L : c->enc) { int r = alloc_layer(L, false); if (r != TW_OK) return bail(r); }
   for (auto& L : c->dec) { int r = alloc_layer(L, true); if (r != TW_OK) return bail(r); }
+  }  // !share
 
   // ---- log-mel tables ----
   {
@@ -427,6 +455,7 @@ int tw_create(const tw_config* cfg, tw_ctx** out) {
 int tw_load_weight(tw_ctx* c, const char* name_c, const void* src, int32_t sdt, int32_t ndim, const int64_t* shape,
                    void* stream) {
   if (!c || !name_c || !src || !shape) return fail(c, TW_EINVAL, "tw_load_weight: null argument");
+  if (c->shares_weights) return fail(c, TW_ESTATE, "tw_load_weight: this context shares another context's weights (tw_create_sibling)");
   if (sdt != TW_F32 && sdt != TW_BF16 && sdt != TW_F16) return fail(c, TW_EINVAL, "unsupported source dtype %d", sdt);
   TW_ON_DEVICE(c);
   hipStream_t st = pick_stream(c, stream);
@@ -528,6 +557,7 @@ int tw_load_weight(tw_ctx* c, const char* name_c, const void* src, int32_t sdt, 
 
 int tw_finalize_weights(tw_ctx* c, void* stream) {
   if (!c) return TW_EINVAL;
+  if (c->shares_weights) return fail(c, TW_ESTATE, "tw_finalize_weights: this context shares another context's weights (tw_create_sibling)");
   TW_ON_DEVICE(c);
   hipStream_t st = pick_stream(c, stream);
   const size_t expect = 4 + 1 + 2 + (size_t)c->Le * 15 + 2 + 2 + (size_t)c->Ld * 24;
@@ -781,6 +811,48 @@ int tw_cross_kv(tw_ctx* c, int32_t B, void* stream) {
 }
 
 int tw_cross_kv_at(tw_ctx* c, int32_t B, int32_t slot0, void* stream) { return cross_kv_core(c, B, slot0, stream); }
+
+int tw_adopt_cross_kv(tw_ctx* dst, int32_t dst_slot0, tw_ctx* src, int32_t src_slot0, int32_t B, void* stream, void* src_stream) {
+  if (!dst || !src) return fail(dst, TW_EINVAL, "tw_adopt_cross_kv: null context");
+  TW_ON_DEVICE(dst);
+  if (dst == src) return fail(dst, TW_EINVAL, "tw_adopt_cross_kv: source and destination are the same context");
+  if (dst->cfg.device != src->cfg.device || dst->d != src->d || dst->H != src->H || dst->Ld != src->Ld || dst->T != src->T ||
+      dst->Tp != src->Tp || dst->dtype != src->dtype || dst->w8 != src->w8)
+    return fail(dst, TW_EINVAL, "tw_adopt_cross_kv: the contexts differ (model dimensions, source_positions, dtype or device)");
+  if (B < 1 || src_slot0 < 0 || src_slot0 + B > src->cross_B)
+    return fail(dst, TW_ESTATE, "tw_adopt_cross_kv: source slots [%d, %d) but the source holds cross K/V of %d clips", src_slot0, src_slot0 + B, src->cross_B);
+  if (dst_slot0 < 0 || dst_slot0 + B > dst->Bmax) return fail(dst, TW_EINVAL, "tw_adopt_cross_kv: destination slots [%d, %d) outside [0,%d)", dst_slot0, dst_slot0 + B, dst->Bmax);
+  if (dst_slot0 > dst->cross_B) return fail(dst, TW_ESTATE, "tw_adopt_cross_kv: dst_slot0=%d but the destination holds %d clips", dst_slot0, dst->cross_B);
+  hipStream_t st = pick_stream(dst, stream);
+  hipStream_t sst = pick_stream(src, src_stream);
+  // the copies follow everything `src` has enqueued so far (its encoder + cross-K/V launches) ...
+  if (sst != st) {
+    HIPCHK(dst, hipEventRecord(dst->ring_ev[0], sst));
+    HIPCHK(dst, hipStreamWaitEvent(st, dst->ring_ev[0], 0));
+  }
+  // one 2-D copy per arena: row l = layer l, `width` bytes of B consecutive slots, pitches = one layer of each context
+  const size_t slot_bytes = (size_t)dst->Tp * dst->d * (dst->w8 ? 1 : dst->esz);
+  auto copy = [&](void* d_base, const void* s_base, size_t per_slot) -> hipError_t {
+    return hipMemcpy2DAsync(reinterpret_cast<char*>(d_base) + (size_t)dst_slot0 * per_slot, (size_t)dst->Bmax * per_slot,
+                            reinterpret_cast<const char*>(s_base) + (size_t)src_slot0 * per_slot, (size_t)src->Bmax * per_slot,
+                            (size_t)B * per_slot, (size_t)dst->Ld, hipMemcpyDeviceToDevice, st);
+  };
+  HIPCHK(dst, copy(dst->cross_k, src->cross_k, slot_bytes));
+  HIPCHK(dst, copy(dst->cross_v, src->cross_v, slot_bytes));
+  if (dst->w8) {
+    const size_t sc = (size_t)dst->H * dst->Tp;
+    HIPCHK(dst, copy(dst->cross_ksc, src->cross_ksc, sc));
+    HIPCHK(dst, copy(dst->cross_vsc, src->cross_vsc, sc));
+  }
+  // ... and whatever `src` enqueues next (it may refill these slots) follows the copies
+  if (sst != st) {
+    HIPCHK(dst, hipEventRecord(dst->ring_ev[1], st));
+    HIPCHK(dst, hipStreamWaitEvent(sst, dst->ring_ev[1], 0));
+  }
+  dst->cross_B = dst_slot0 + B;
+  if (dst->encoded_B < dst->cross_B) dst->encoded_B = dst->cross_B;   // (the encoder states themselves stay in `src`: nothing reads them after A5)
+  return TW_OK;
+}
 
 }  // extern "C"
 

@@ -297,8 +297,11 @@ hipError_t launch_enc_attention(int dtype, const void* q, const void* k, const v
   // 128 queries per workgroup when that still yields >= 2 workgroups per CU, else 64.
   const long long blocks128 = (long long)B * H * ((T + 127) / 128);
   const bool big = blocks128 >= 512;
-  static const int xcd = []() { const char* e = getenv("TW_ATTN_XCD"); return e ? atoi(e) : 1; }();
+  // TW_ATTN_XCD: 1 (default) = heads pinned to XCDs when there are at least 64 of them (with the 20 heads of one stream 4 XCDs
+  // would get three heads and 4 two: 5.68 -> 5.88 ms for one 30 s chunk), 0 = never, 2 = always
+  static const int xcd_env = []() { const char* e = getenv("TW_ATTN_XCD"); return e ? atoi(e) : 1; }();
   const int nbh = B * H;
+  const int xcd = (xcd_env == 2 || (xcd_env == 1 && nbh >= 64)) ? 1 : 0;
   auto grid_for = [&](int nq) { return dim3((unsigned)((xcd ? 8 * ((nbh + 7) / 8) : nbh) * nq)); };
   if (dtype == 1) {
     if (big)

@@ -551,19 +551,23 @@ static int gemm_env(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-// 1-D grid of 8 * ceil(tiles / 8) workgroups (tw_tile_of_block); TW_GEMM_XCD=0 restores the row-major tile order for A/B runs
-static int gemm_grid(int Tm, int Tn, int* swz) {
+// 1-D grid of 8 * ceil(tiles / 8) workgroups (tw_tile_of_block).  TW_GEMM_XCD: 1 (default) = XCD-aware order for the large-M kernel
+// only, 0 = row-major everywhere, 2 = XCD-aware for both kernels.  Measured (profiles/r04_encoder_xcd_ab.txt, GPU to itself):
+// encoder of 16 x 10 / 15 / 30 s 16.90 -> 16.51 / 24.03 -> 22.72 / 51.55 -> 49.10 ms; the small-M kernel (one stream: 80-320 small
+// tiles) loses 1.5-5 % with it (3.56 -> 3.75 ms at 10 s), hence off there.
+static int gemm_grid(int Tm, int Tn, bool large, int* swz) {
   static const int xcd = gemm_env("TW_GEMM_XCD", 1);
-  *swz = xcd ? 1 : 0;
+  const bool on = xcd == 2 || (xcd == 1 && large);
+  *swz = on ? 1 : 0;
   const int NT = Tm * Tn;
-  return xcd ? 8 * ((NT + 7) / 8) : NT;
+  return on ? 8 * ((NT + 7) / 8) : NT;
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int ST>
 static hipError_t gemm_go(const void* A, RowMap amap, const void* W, int M, int N, int K, const GemmEpilogue& ep, hipStream_t st) {
   const int Tn = (N + BN - 1) / BN, Tm = (M + BM - 1) / BM;
   int swz;
-  dim3 grid(gemm_grid(Tm, Tn, &swz));
+  dim3 grid(gemm_grid(Tm, Tn, false, &swz));
   hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, ST>), grid, dim3(WM * WN * 64), 0, st, reinterpret_cast<const T*>(A), amap,
                      reinterpret_cast<const T*>(W), M, N, K, Tm, Tn, swz, ep);
   return hipGetLastError();
@@ -573,7 +577,7 @@ template <typename T, int BM, int NW, int ST>
 static hipError_t gemm_wreg_go(const void* A, RowMap amap, const void* W, int M, int N, int K, const GemmEpilogue& ep, hipStream_t st) {
   const int Tn = (N + NW * 64 - 1) / (NW * 64), Tm = (M + BM - 1) / BM;
   int swz;
-  dim3 grid(gemm_grid(Tm, Tn, &swz));
+  dim3 grid(gemm_grid(Tm, Tn, true, &swz));
   hipLaunchKernelGGL((gemm_wreg_kernel<T, BM, NW, ST>), grid, dim3(NW * 64), 0, st, reinterpret_cast<const T*>(A), amap,
                      reinterpret_cast<const T*>(W), M, N, K, Tm, Tn, swz, ep);
   return hipGetLastError();

@@ -134,8 +134,30 @@ class WhisperEngine:
         self.ctx = ctx
         self._finalized = False
 
+    def sibling(self, max_batch: Optional[int] = None) -> "WhisperEngine":
+        """A second context of the same model on the same device that SHARES this engine's (finalized) weights and has its own
+        workspace and K/V arenas (tw_create_sibling): two stages of a serving pipeline can then run at the same time - a context
+        is not thread-safe, two contexts are independent.  This engine must outlive the sibling."""
+        if not self._finalized:
+            raise RuntimeError("sibling() needs loaded weights")
+        new = object.__new__(type(self))
+        new.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("ctx", "_held", "raw_stream", "_owner")})
+        new.max_batch = int(max_batch or self.max_batch)
+        ctx = C.c_void_p()
+        rc = self.lib.tw_create_sibling(self.ctx, new.max_batch, C.byref(ctx))
+        if rc != 0:
+            raise RuntimeError(f"tw_create_sibling failed ({rc}): {self.lib.tw_last_error(None).decode()}")
+        new.ctx = ctx
+        new._owner = self           # keeps the weights' owner alive
+        new._siblings = []
+        self.__dict__.setdefault("_siblings", []).append(new)
+        return new
+
     # ---- lifetime ----------------------------------------------------------------------------
     def close(self):
+        for sib in self.__dict__.get("_siblings", []):   # they read this context's weights: they go first
+            sib.close()
+        self.__dict__["_siblings"] = []
         if getattr(self, "ctx", None):
             self.lib.tw_destroy(self.ctx)
             self.ctx = None
@@ -240,6 +262,12 @@ class WhisperEngine:
             self._chk(self.lib.tw_cross_kv_at(self.ctx, B, int(slot0), self._sp()), "tw_cross_kv_at")
         else:
             self._chk(self.lib.tw_cross_kv(self.ctx, B, self._sp()), "tw_cross_kv")
+
+    def adopt_cross_kv(self, src: "WhisperEngine", src_slot0: int, B: int, dst_slot0: int):
+        """Slots ``src_slot0 .. +B`` of ``src`` (another context of the same weights, e.g. one that encoded new arrivals on a
+        CU-masked side stream while this one was decoding) become slots ``dst_slot0 .. +B`` of this context (tw_adopt_cross_kv)."""
+        self._chk(self.lib.tw_adopt_cross_kv(self.ctx, int(dst_slot0), src.ctx, int(src_slot0), int(B), self._sp(), src._sp()),
+                  "tw_adopt_cross_kv")
 
     # ---- A6-A8 (teacher-forced stepping, used by the parity tests) ---------------------------
     def decoder_reset(self, B: int):

@@ -47,7 +47,10 @@ class AMDWhisperFeatureExtractor(WhisperFeatureExtractor):
             self._tls.keep_on_device = False
 
     def _torch_extract_fbank_features(self, waveform: np.ndarray, device: str = "cpu"):  # noqa: ARG002
-        if self._engine is None:
+        # a thread may direct ITS calls to another context of the same model (serving.py: the prefetch thread computes the
+        # log-mel of new arrivals on the sibling context / side stream while the main context is inside its decode loop)
+        engine = getattr(self._tls, "engine", None) or self._engine
+        if engine is None:
             raise RuntimeError("AMDWhisperFeatureExtractor has no engine attached (no CPU fallback)")
         import torch
 
@@ -56,10 +59,10 @@ class AMDWhisperFeatureExtractor(WhisperFeatureExtractor):
         if squeeze:
             w = w[None]
         outs = []
-        mb = self._engine.max_batch
+        mb = engine.max_batch
         for i in range(0, w.shape[0], mb):
             x = torch.from_numpy(np.ascontiguousarray(w[i : i + mb]))
-            outs.append(self._engine.logmel(x, out_dtype=torch.float32))
+            outs.append(engine.logmel(x, out_dtype=torch.float32))
         mel = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
         if getattr(self._tls, "keep_on_device", False):
             return mel[0] if squeeze else mel

@@ -41,9 +41,155 @@ class _StreamBackend:
         return self.hub.submit(audio, buffer_start_time, sample_rate, stream_id=self.stream_id).result()
 
 
+class _Prefetcher:
+    """Encoder stage of NEW arrivals under the decode loop of the running pass.
+
+    A pass's members are only known when the previous pass has ended (a chunk that needs a further seek iteration continues
+    where the decoded timestamps say), so THEIR encoder stage cannot be hidden; a new request's first iteration always starts
+    at frame 0 and can.  This thread is enabled only while ``Pass.run`` blocks in the greedy loop: it takes requests off the
+    hub's queue, opens them (HF's ``preprocess`` with the log-mel on the sibling context) and enqueues encoder + cross-K/V of
+    their chunks on a CU-masked stream into the sibling's slots; the hub's next pass adopts those rows (``Pass.adopt`` ->
+    tw_adopt_cross_kv, ~30 us per 10 s chunk) behind the rows that continue.  Same kernels, same weights, same results."""
+
+    def __init__(self, hub: "BatchingHub", codec, engine, n_cus: int):
+        import torch
+
+        from .overlap import masked_stream
+
+        self.hub, self.codec, self.main = hub, codec, engine
+        self.cap = int(hub.max_batch)
+        self.side = engine.sibling(self.cap)
+        self.stream = None
+        dev = getattr(engine, "device", None)
+        if dev is not None and dev.type == "cuda":     # (the CPU stand-in engine of the tests has no streams)
+            total = torch.cuda.get_device_properties(dev).multi_processor_count
+            n_cus = max(8, min(int(n_cus), total - 8))
+            self.stream = masked_stream(total - n_cus, total, total, dev.index or 0)
+            self.side.raw_stream = self.stream
+        self.lock = threading.Lock()          # held by this thread while it works on one request
+        self.enabled = threading.Event()
+        self.stop = False
+        self.pre: "collections.deque" = collections.deque()    # (work, side slot, segment tensor), slot order
+        self.new_jobs: List[Any] = []
+        self.count = 0                        # filled slots of the sibling context
+        self.thread = threading.Thread(target=self._run, name="thewhisper-prefetch", daemon=True)
+        self.thread.start()
+
+    # -- hub side (the batcher thread) ----------------------------------------------------------------
+    def resume(self):
+        self.enabled.set()
+
+    def pause(self):
+        """Returns once this thread is neither holding a request nor touching the sibling context."""
+        self.enabled.clear()
+        with self.lock:
+            pass
+
+    def drain_jobs(self) -> List[Any]:
+        jobs, self.new_jobs = self.new_jobs, []
+        return jobs
+
+    def take(self, free: int):
+        """Up to `free` pre-encoded rows from the front (consecutive sibling slots): ([works], first slot, [tensors to keep])."""
+        works, keep, slot0 = [], [], None
+        while self.pre and len(works) < free:
+            w, slot, seg = self.pre.popleft()
+            if slot0 is None:
+                slot0 = slot
+            works.append(w)
+            keep.append(seg)
+        if not self.pre:
+            self.count = 0        # tw_adopt_cross_kv orders the sibling's next launches behind the copies
+        return works, slot0, keep
+
+    def shutdown(self):
+        self.stop = True
+        self.enabled.set()
+        self.thread.join(timeout=30)
+        if self.stream is not None:
+            try:
+                from .overlap import _hiplib
+
+                self.side.raw_stream = None
+                _hiplib().stream_destroy(self.stream)     # synchronises first
+            except Exception:  # noqa: BLE001
+                pass
+        self.side.close()
+
+    # -- the thread -------------------------------------------------------------------------------------
+    def _run(self):
+        import torch
+
+        from . import shortform
+
+        import contextlib
+
+        fe = self.codec.pipe.feature_extractor
+        fe._tls.engine = self.side              # this thread's log-mel calls go to the sibling context (feature_extraction.py)
+        ctx = contextlib.nullcontext()
+        if self.stream is not None:             # ... and its torch ops to the side stream, never to the null stream
+            dev = self.main.device
+            torch.cuda.set_device(dev)
+            ctx = torch.cuda.stream(torch.cuda.ExternalStream(self.stream, device=dev))
+        with ctx:
+            while True:
+                self.enabled.wait()
+                if self.stop:
+                    return
+                item = _NOTHING
+                with self.lock:
+                    if self.enabled.is_set() and self.count < self.cap:
+                        try:
+                            item = self.hub._take(timeout=0.004)
+                        except queue.Empty:
+                            item = _NOTHING
+                    if item is None:              # close(): the batcher thread must see it too
+                        self.hub._stopping = True
+                        try:
+                            self.hub._q.put_nowait(None)
+                        except queue.Full:
+                            pass
+                        return
+                    if item is not _NOTHING:
+                        self._prefetch(item, shortform)
+                if item is _NOTHING:
+                    time.sleep(0.001)
+
+    def _prefetch(self, item, shortform):
+        import torch
+
+        audio, t0, sr, fut = item
+        try:
+            job = self.codec.open(audio, t0, sr)
+        except Exception as e:  # noqa: BLE001  (a malformed buffer fails its own session only)
+            self.hub._answer(fut, exc=e)
+            return
+        job.future = fut
+        n = len(job.works)
+        if self.count + n > self.cap:
+            # does not fit the sibling's free slots: the batcher takes it through the ordinary path (opened already)
+            self.new_jobs.append(job)
+            return
+        try:
+            segs = torch.stack([shortform.first_segment(w, self.side.T) for w in job.works], dim=0)
+            self.side.encode(segs, slot0=self.count) if self.count else self.side.encode(segs)
+            self.side.cross_kv(n, slot0=self.count) if self.count else self.side.cross_kv(n)
+        except Exception as e:  # noqa: BLE001
+            self.hub._answer(fut, exc=e)
+            return
+        for i, w in enumerate(job.works):
+            self.pre.append((w, self.count + i, segs))
+        self.count += n
+        self.new_jobs.append(job)
+        self.hub.prefetched += n
+
+
+_NOTHING = object()
+
+
 class BatchingHub:
     def __init__(self, backend: AMDWhisperBackend, max_batch: Optional[int] = None, max_wait_s: float = 0.004,
-                 max_pending: int = 1024, continuous: bool = True, gather_s: float = 0.15):
+                 max_pending: int = 1024, continuous: bool = True, gather_s: float = 0.15, prefetch_cus: int = 0):
         self.backend = backend
         eng = backend.asr_pipeline.model.engine
         self.max_batch = int(max_batch or eng.max_batch)
@@ -73,6 +219,13 @@ class BatchingHub:
         self.latencies: "collections.deque[float]" = collections.deque(maxlen=4096)  # submit -> answer, seconds
         self._codec = None
         self._carry = None
+        # > 0: while a pass decodes, the requests that ARRIVE are opened (log-mel) and the first seek iteration of their chunks is
+        # encoded on a sibling context of the same weights, on a stream confined to that many compute units; the next pass adopts
+        # them (their encoder stage is then hidden under the decode loop).  Continuous mode on the real engine only.
+        self.prefetch_cus = int(prefetch_cus)
+        self._prefetcher: Optional["_Prefetcher"] = None
+        self._stopping = False
+        self.prefetched = 0     # rows whose encoder stage ran under another pass's decode loop
         if continuous and hasattr(backend, "job_codec"):
             self._codec = backend.job_codec()
         self._post_q: "queue.Queue" = queue.Queue()
@@ -204,6 +357,9 @@ class BatchingHub:
         eng = self.backend.asr_pipeline.model.engine
         jobs: List[Any] = []          # requests in flight, oldest first
         stop = False
+        pf = None
+        if self.prefetch_cus > 0 and hasattr(eng, "sibling"):
+            pf = self._prefetcher = _Prefetcher(self, codec, eng, self.prefetch_cus)
 
         def fail_jobs_of(works, exc):
             nonlocal jobs
@@ -212,22 +368,47 @@ class BatchingHub:
                 self._answer(j.future, exc=exc)
             jobs = [j for j in jobs if j not in hit]
 
+        def shutdown():
+            if pf is not None:
+                pf.shutdown()
+                jobs.extend(pf.drain_jobs())
+            for j in jobs:
+                self._answer(j.future, exc=RuntimeError("BatchingHub closed before the request was served"))
+
         while True:
             pas = shortform.Pass(eng, codec.plan)
+            if pf is not None:
+                pf.pause()            # from here to resume() this thread is the only user of the queue and of the sibling context
+                jobs.extend(j for j in pf.drain_jobs() if j not in jobs)
+            if self._stopping:
+                shutdown()
+                return
             # 1. the chunks that need a further seek iteration go first: their encoder stage is enqueued NOW (asynchronous), so
             #    the GPU is already busy while the sessions answered after the last pass are on their way back
-            left = [w for j in jobs for w in j.works if not w.done][: self.max_batch]
+            pre_works = set(w for w, _, _ in pf.pre) if pf is not None else set()
+            left = [w for j in jobs for w in j.works if not w.done and w not in pre_works][: self.max_batch]
             if left:
                 try:
                     pas.add(left)
                 except Exception as e:  # noqa: BLE001  (engine failure)
                     fail_jobs_of(left, e)
                     continue
+            # 1b. rows whose first iteration was encoded under the previous pass's decode loop (_Prefetcher): a copy each
+            adopted: List[Any] = []
+            if pf is not None and pf.pre and pas.free > 0:
+                ws, slot0, keep = pf.take(pas.free)
+                try:
+                    pas.adopt(ws, pf.side, slot0)
+                    pas._keep.extend(keep)
+                    adopted = ws
+                except Exception as e:  # noqa: BLE001
+                    fail_jobs_of(ws, e)
+                    continue
             # 2. intake: block when there is nothing to decode; otherwise linger while rows are free - for max_wait_s, or for as
             #    long as the encoder stage of step 1 keeps the GPU busy anyway (~1.2 ms per chunk), whichever is longer
             fresh: List[Any] = []
             linger = max(self.max_wait_s, 0.0012 * len(left))
-            deadline = time.monotonic() + linger if left else None
+            deadline = time.monotonic() + linger if (left or adopted) else None
             while pas.free - len(fresh) > 0:
                 try:
                     if deadline is None:
@@ -251,11 +432,10 @@ class BatchingHub:
                 jobs.append(job)
                 fresh.extend(job.works)
             if stop:
-                for j in jobs:
-                    self._answer(j.future, exc=RuntimeError("BatchingHub closed before the request was served"))
+                shutdown()
                 return
-            # 3. the late arrivals join the pass as a second group (slots after the first group's), then ONE greedy loop over all
-            works = list(left)
+            # 3. the late arrivals join the pass as a further group (slots after the others'), then ONE greedy loop over all
+            works = list(left) + list(adopted)
             try:
                 take = fresh[: pas.free]
                 if take:
@@ -266,6 +446,8 @@ class BatchingHub:
                 self.batches.append(len(works))
                 self.passes += 1
                 self.rows += len(works)
+                if pf is not None:
+                    pf.resume()       # arrivals from now on are encoded on the side while this pass decodes
                 pas.run()
                 for w in works:
                     if w.passes > shortform.MAX_SEEK_PASSES:

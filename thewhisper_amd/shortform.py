@@ -180,6 +180,23 @@ class Pass:
         self._keep.append(segment_input)
         self.works.extend(works)
 
+    def adopt(self, works: Sequence[ChunkWork], side_engine, side_slot0: int) -> None:
+        """The next rows of the pass are chunks whose FIRST seek iteration (seek = 0) was encoded elsewhere - by ``side_engine``,
+        a sibling context of the same weights, at its slots ``side_slot0 ..`` (serving.py: arrivals are encoded on a CU-masked
+        stream while the previous pass decodes): their cross K/V are copied into this pass's next slots (tw_adopt_cross_kv)."""
+        n_new = len(works)
+        if n_new == 0:
+            return
+        if n_new > self.free:
+            raise ValueError(f"a pass takes at most {self.engine.max_batch} chunks")
+        nsf = 2 * int(self.engine.T)
+        for w in works:
+            if w.seek != 0 or w.done:
+                raise ValueError("only chunks at their first seek iteration can be adopted")
+            self.snf.append(min(w.max_frames, nsf))
+        self.engine.adopt_cross_kv(side_engine, side_slot0, n_new, len(self.works))
+        self.works.extend(works)
+
     def run(self) -> None:
         engine, plan, works, snf = self.engine, self.plan, self.works, self.snf
         B = len(works)
@@ -223,6 +240,16 @@ class Pass:
             w.seek += offset
             w.segments += segments
             w.passes += 1
+
+
+def first_segment(work: ChunkWork, T: int) -> torch.Tensor:
+    """The [n_mels, 2T] segment a chunk's first seek iteration encodes (what ``Pass.add`` cuts for seek = 0)."""
+    nsf = 2 * int(T)
+    n = min(work.max_frames, nsf)
+    s = work.feats[:, :n]
+    if n < nsf:
+        s = F.pad(s, pad=(0, nsf - n))
+    return s
 
 
 def run_pass(engine, plan: ShortFormPlan, works: Sequence[ChunkWork]) -> None:
