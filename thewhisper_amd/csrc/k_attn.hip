@@ -72,7 +72,7 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 // workgroup ids go to the 8 XCDs round-robin (MI355X_MICROARCH.md), so with the query block as the fastest grid index every
 // head's K / V^T was fetched into 4 different L2s.  xcd = 1: head bh runs on XCD bh % 8, its query blocks back to back there.
 template <typename T, int QT>
-__global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
+__global__ __launch_bounds__(256, 2) void enc_attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                         const T* __restrict__ vt, T* __restrict__ out, int H, int Tlen,
                                                         int Tp, int nbh, int nq, int xcd) {
   using TR = AttnTraits<T>;
@@ -185,43 +185,64 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ q, 
     }
 
     // ---- online softmax (per lane: one query, keys key0 + 16kt + 4kb + r) ----
+    // The loop is VALU-bound (round-4 counters: 384 VALU instructions per 64-key tile and wavefront next to 32 MFMAs, 43 % of the
+    // wave cycles issuing): keys are masked only in the one tile that has padding (wave-uniform branch), and the per-score
+    // arithmetic is written on float pairs so that it compiles to v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 (two scores per
+    // instruction) and v_max3_f32.
+    const bool partial = key0 + 64 > Tlen;
     float alpha[QT];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
+      if (partial) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (key0 + kt * 16 + kb * 4 + r >= Tlen) s[t][kt][r] = -1.0e30f;
+      }
       float mx = -1.0e30f;
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = key0 + kt * 16 + kb * 4 + r;
-          float v = s[t][kt][r];
-          if (key >= Tlen) v = -1.0e30f;
-          s[t][kt][r] = v;
-          mx = fmaxf(mx, v);
-        }
+      for (int kt = 0; kt < 4; ++kt) {
+        mx = fmaxf(fmaxf(mx, s[t][kt][0]), s[t][kt][1]);
+        mx = fmaxf(fmaxf(mx, s[t][kt][2]), s[t][kt][3]);
+      }
       mx = tw_xor32_max(tw_xor16_max(mx));
       const float mnew = fmaxf(mrun[t], mx);
       alpha[t] = attn_exp<T>(mrun[t] - mnew);
       mrun[t] = mnew;
       float ps = 0.f;
-      // bf16: exp(s - m) = 2^(s * log2(e) - m * log2(e)): one fused multiply-add and the hardware 2^x per score instead of a
-      // subtraction, a multiplication and the 2^x (the loop is VALU-bound: ~34 of these per 32 MFMAs)
-      const float ml = mnew * 1.4426950408889634f;
+      if constexpr (sizeof(T) == 4) {
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float p;
-          if constexpr (sizeof(T) == 4) p = expf(s[t][kt][r] - mnew);
-          else p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][kt][r], 1.4426950408889634f, -ml));
-          s[t][kt][r] = p;
-          ps += p;
-        }
+          for (int r = 0; r < 4; ++r) {
+            const float p = expf(s[t][kt][r] - mnew);
+            s[t][kt][r] = p;
+            ps += p;
+          }
+      } else {
+        // exp(s - m) = 2^(s * log2(e) - m * log2(e)): one fused multiply-add per PAIR of scores and the hardware 2^x per score
+        const float L2E = 1.4426950408889634f;
+        const f32x2_t c2 = {L2E, L2E};
+        const f32x2_t nml = {-mnew * L2E, -mnew * L2E};
+        f32x2_t ps2 = {0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            f32x2_t v = {s[t][kt][2 * h2], s[t][kt][2 * h2 + 1]};
+            v = v * c2 + nml;
+            f32x2_t p = {__builtin_amdgcn_exp2f(v[0]), __builtin_amdgcn_exp2f(v[1])};
+            s[t][kt][2 * h2] = p[0];
+            s[t][kt][2 * h2 + 1] = p[1];
+            ps2 += p;
+          }
+        ps = ps2[0] + ps2[1];
+      }
       lrun[t] = lrun[t] * alpha[t] + ps;
+      const f32x4_t a4 = {alpha[t], alpha[t], alpha[t], alpha[t]};
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[t][dt][r] *= alpha[t];
+      for (int dt = 0; dt < 4; ++dt) o[t][dt] *= a4;
     }
 
     // ---- O^T += Vt.P^T ----

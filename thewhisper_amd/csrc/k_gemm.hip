@@ -440,10 +440,13 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_wreg_kernel(const T* __restri
   constexpr int BKE = 8 * E;
   constexpr int BN = NW * 64;
   constexpr int NTHR = NW * 64;
-  constexpr int AV = BM * 8 / NTHR;
+  // DMA pieces (64 x 16 B, one per wavefront request) per thread and stage.  BM need not be a multiple of NTHR / 8 rows (80, 96,
+  // 112: tile heights that divide the grid better, see gemm_pick_bm): the last piece then also fetches rows past the tile
+  // (clamped to the matrix; they land in LDS rows nobody reads)
+  constexpr int AV = (BM * 8 + NTHR - 1) / NTHR;
   constexpr int MT = BM / 16, NT = 4;
-  static_assert(AV >= 1 && (ST == 2 || ST == 3), "tile layout");
-  constexpr int STAGE = 8 * BM;
+  static_assert(BM % 16 == 0 && AV >= 1 && (ST == 2 || ST == 3), "tile layout");
+  constexpr int STAGE = AV * NTHR;
   __shared__ u32x4_t lds[ST * STAGE];
 
   const int tid = threadIdx.x;
@@ -609,6 +612,32 @@ static hipError_t gemm_dispatch(const void* A, RowMap amap, const void* W, int M
   else if (N % 256 == 0 && b128 >= wreg_min) cfg = (N <= 2048) ? narrow : 5;
   else if (M > 64) cfg = 1;
   else cfg = 0;
+  if (cfg == 5) {
+    // Tile HEIGHT of kernel 2 by how the grid divides over the chip.  Two workgroups share a CU's matrix pipe, so a CU's time is
+    // proportional to the rows of the tiles it gets, ceil(tiles / 256) x BM, and the kernel ends with the last CU.  The out-projection
+    // and fc2 of 16 x 10 s (M = 8000, N = 1280) are 63 x 5 = 315 tiles of 128 rows: 59 CUs get two and everybody waits for them (the
+    // launch runs at the pace of 512 tiles); 100 x 5 tiles of 80 rows put two on (almost) every CU: 160 instead of 256 rows per CU.
+    // `ovh` rows stand for the per-tile prologue + epilogue.  TW_GEMM_BM forces a height (80 / 96 / 112 / 128) for A/B runs.
+    static const int bm_forced = gemm_env("TW_GEMM_BM", 0);
+    static const int ovh = gemm_env("TW_GEMM_BM_OVH", 24);
+    int best = 128;
+    if (bm_forced) {
+      best = bm_forced;
+    } else {
+      long long best_cost = -1;
+      for (int bm : {128, 112, 96, 80}) {
+        const long long tiles = (long long)((M + bm - 1) / bm) * (N / 256);
+        const long long cost = ((tiles + 255) / 256) * (bm + ovh);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = bm; }
+      }
+    }
+    switch (best) {
+      case 80: return gemm_wreg_go<T, 80, 4, 3>(A, amap, W, M, N, K, ep, st);
+      case 96: return gemm_wreg_go<T, 96, 4, 3>(A, amap, W, M, N, K, ep, st);
+      case 112: return gemm_wreg_go<T, 112, 4, 3>(A, amap, W, M, N, K, ep, st);
+      default: break;
+    }
+  }
   switch (cfg) {
     case 5: return gemm_wreg_go<T, 128, 4, 3>(A, amap, W, M, N, K, ep, st);
     case 6: return gemm_wreg_go<T, 128, 4, 2>(A, amap, W, M, N, K, ep, st);
