@@ -275,20 +275,25 @@ def pipeline_leg(eng, dims, args, device_index, heads, latency_calls, hub_rounds
             hub.close()
             return res
 
-        # (b1) the headline API reading: arrivals are encoded on a sibling context / CU-masked stream while a pass decodes
-        out.update(measure("hub_", prefetch_cus=args.hub_prefetch_cus))
-        # (b2) the same without the prefetch (round 3's schedule), same box, for the A/B
+        # (b1) the headline API reading (round 3's schedule: the encoder stage of a pass runs before its decode loop)
+        out.update(measure("hub_"))
+        # (b2) the same with arrivals encoded on a sibling context / CU-masked stream while a pass decodes (serving._Prefetcher;
+        #      round 4).  Closed-loop sessions come back within milliseconds of a pass's END, i.e. during the intake of the next
+        #      pass, not during its decode loop: few rows take the prefetch route (17 of 624) and the extra thread costs more than
+        #      they save (9 505 vs 9 739 tok/s, profiles/r04_hub_prefetch_ab.json) - reported, not the default.
         if args.hub_prefetch_cus > 0:
-            r = measure("hub_noprefetch_")
-            out.update({k: r[k] for k in ("hub_noprefetch_tok_per_s", "hub_noprefetch_request_p50_ms", "hub_noprefetch_request_p90_ms")})
-        # (b3) the trained-model regime: a random-weight decoder closes timestamp pairs at random places and so needs ~3 seek passes
-        #      per 10 s buffer; a trained model needs 1-2.  With `hub_short_tokens` new tokens per pass the same streams need <= 2
-        #      passes per buffer (reported), which is the regime in which the 0.5 s cadence of the reference scheduler is testable
+            r = measure("hub_prefetch_", prefetch_cus=args.hub_prefetch_cus)
+            out.update({k: r[k] for k in ("hub_prefetch_tok_per_s", "hub_prefetch_request_p50_ms", "hub_prefetch_request_p90_ms",
+                                          "hub_prefetch_rows_prefetched")})
+        # (b3) short passes: `hub_short_tokens` new tokens per pass instead of 128.  A random-weight decoder closes timestamp pairs at
+        #      random places, so a 10 s buffer needs 3-4 seek passes whatever the budget (a trained model: 1-2); with 24-token passes
+        #      a request's wall time is what a trained model's ONE 128-token pass costs, which makes the reference scheduler's 0.5 s
+        #      cadence testable at 16 sessions per GPU (passes per request are reported with it)
         if args.hub_short_tokens > 0:
             full_kwargs = backend._generate_kwargs
             backend._generate_kwargs = lambda: {**full_kwargs(), "max_new_tokens": args.hub_short_tokens}
             try:
-                out.update(measure("hub_short_", prefetch_cus=args.hub_prefetch_cus))
+                out.update(measure("hub_short_"))
                 out["hub_short_max_new_tokens"] = args.hub_short_tokens
             finally:
                 backend._generate_kwargs = full_kwargs

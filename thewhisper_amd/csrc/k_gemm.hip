@@ -619,7 +619,7 @@ static hipError_t gemm_dispatch(const void* A, RowMap amap, const void* W, int M
     // launch runs at the pace of 512 tiles); 100 x 5 tiles of 80 rows put two on (almost) every CU: 160 instead of 256 rows per CU.
     // `ovh` rows stand for the per-tile prologue + epilogue.  TW_GEMM_BM forces a height (80 / 96 / 112 / 128) for A/B runs.
     static const int bm_forced = gemm_env("TW_GEMM_BM", 0);
-    static const int ovh = gemm_env("TW_GEMM_BM_OVH", 24);
+    static const int ovh = gemm_env("TW_GEMM_BM_OVH", 48);   // 24 picked 96-row tiles for the QKV projection (111 vs 106 us) and lost 3 % at 16 x 30 s
     int best = 128;
     if (bm_forced) {
       best = bm_forced;
