@@ -96,6 +96,13 @@ typedef struct tw_greedy_opts {
   int32_t n_suppress;
   const int32_t* suppress;       /* host */
   int32_t want_alignment;        /* 1: record alignment-head cross-attention rows for tw_token_timestamps */
+  int32_t n_forced;              /* the last n_forced tokens of every prompt row are FORCED OUTPUT, not prompt: they count as generated
+                                    (begin index = n_prompt - n_forced: max_new_tokens, min_new_tokens and the timestamp grammar see
+                                    them as tokens the loop produced), and positions 0 .. n_prompt-2 are processed by a batched
+                                    prefill (rows = streams x positions per launch) instead of one step each.  What it is for:
+                                    SURVEY.md section 8f-3 - a streaming backend re-decodes every 0.5 s a buffer most of whose text
+                                    it emitted a moment ago (R:thestage_speechkit/streaming/streaming_pipeline.py:770-796) and may
+                                    force that text and decode only the tail (thewhisper_amd/streaming.py, opt-in).  0 = off. */
 } tw_greedy_opts;
 
 const char* tw_version(void);

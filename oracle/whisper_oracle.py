@@ -739,8 +739,12 @@ def greedy_generate(
     prompt: np.ndarray,
     opt: GreedyOptions,
     teacher: Optional[np.ndarray] = None,
+    begin_index: Optional[int] = None,
 ):
     """A9 inner loop: HF:generation/utils.py:2783-2946 for num_beams=1, do_sample=False.
+    ``begin_index`` < n0: the prompt's tail from there on is OUTPUT that is already known (a generation that is being continued:
+    the logits processors' begin index and the new-token budget count from ``begin_index``, as they did when those tokens were
+    produced; the engine's tw_greedy_opts::n_forced).
 
     ``prompt`` int [B, n0].  Returns dict(sequences [B, n0+G] padded with ``pad``, logits list
     (raw fp32 last-position logits per step, [B, V]), cross [B, Ha, n0+G-1, T] or None).
@@ -751,7 +755,8 @@ def greedy_generate(
     cache = model.new_cache(enc)
     seqs = [list(map(int, prompt[i])) for i in range(b)]
     unfinished = np.ones(b, dtype=bool)
-    max_len = min(opt.max_length, n0 + opt.max_new_tokens)
+    nb = n0 if begin_index is None else int(begin_index)
+    max_len = min(opt.max_length, nb + opt.max_new_tokens)
     raw_logits: List[np.ndarray] = []
     cross_rows: List[np.ndarray] = []
     feed = prompt
@@ -764,7 +769,7 @@ def greedy_generate(
         raw_logits.append(last)
         nxt = np.zeros(b, dtype=np.int64)
         for i in range(b):
-            sc = apply_logits_processors(last[i], seqs[i], n0, opt)
+            sc = apply_logits_processors(last[i], seqs[i], nb, opt)
             tok = int(np.argmax(sc))  # first maximal index, as torch.argmax
             if teacher is not None:
                 tok = int(teacher[i, step])

@@ -87,7 +87,7 @@ class OracleEngine:
 
     def generate_greedy(self, prompt, max_new_tokens=128, min_new_tokens=0, max_length=448, eos_id=50257, pad_id=50257,
                         timestamps=False, no_timestamps_id=50364, max_initial_timestamp_index=50, begin_suppress=(220, 50257),
-                        suppress=(), want_alignment=False):
+                        suppress=(), want_alignment=False, n_forced=0):
         self.calls["generate"] += 1
         opt = wo.GreedyOptions(eos=eos_id, pad=pad_id, max_new_tokens=max_new_tokens, min_new_tokens=min_new_tokens,
                                max_length=max_length, begin_suppress=tuple(begin_suppress), suppress=tuple(suppress),
@@ -95,7 +95,8 @@ class OracleEngine:
                                max_initial_timestamp_index=max_initial_timestamp_index,
                                alignment_heads=self.alignment_heads if want_alignment else None)
         B = prompt.shape[0]
-        res = wo.greedy_generate(self.model, self._enc[:B], np.asarray(prompt), opt)
+        res = wo.greedy_generate(self.model, self._enc[:B], np.asarray(prompt), opt,
+                                 begin_index=(prompt.shape[1] - int(n_forced)) if n_forced else None)
         self._cross = res["cross"]
         return {"sequences": res["sequences"], "length": int(res["sequences"].shape[1])}
 

@@ -380,6 +380,65 @@ def test_greedy_ids_alignment_and_timestamps(preset, T, B, max_new, graph, min_n
     eng.close()
 
 
+FORCED_CASES = [("micro", 100, 1, 60, 37, "f32", True), ("micro", 100, 1, 150, 120, "f32", False), ("micro", 500, 3, 40, 25, "f32", True),
+                ("micro", 100, 16, 30, 9, "f32", True), ("micro", 100, 1, 60, 37, "bf16", True), ("micro", 750, 2, 40, 30, "fp8a16", True),
+                ("micro", 100, 2, 24, 1, "f32", True), ("micro", 100, 5, 90, 70, "bf16", False)]
+
+
+@pytest.mark.parametrize("preset,T,B,max_new,n_forced,dtype,graph", FORCED_CASES)
+def test_forced_prefix_prefill_continues_the_same_generation(preset, T, B, max_new, n_forced, dtype, graph):
+    """tw_greedy_opts::n_forced (SURVEY.md section 8f-3): the first `n_forced` tokens of a finished generation handed back as
+    forced output - processed by the batched prefill (rows = streams x positions per launch, up to 64 rows: several launches for
+    the long cases) - continue into EXACTLY the same sequence, alignment rows and token timestamps as the step-by-step run:
+    strict f32 against the oracle (whose `begin_index` restates the semantics: processors and the token budget count from the
+    real prompt) and against the engine's own unforced run in every dtype."""
+    dims = wo.PRESETS[preset]
+    w = wo.make_weights(dims, 0)
+    heads = [(dims.dec_layers - 1, 0), (dims.dec_layers - 1, 1)]
+    eng = make_engine(dims, w, T=T, max_batch=B, dtype=dtype, heads=heads, use_graph=graph)
+    pcm = clips(T * 320, B)
+    eng.encode(eng.logmel(torch.from_numpy(pcm).cuda(), out_dtype=torch.float32))
+    eng.cross_kv(B)
+    prompt = np.tile(np.array(PROMPT, dtype=np.int32), (B, 1))
+    kw = dict(max_new_tokens=max_new, min_new_tokens=max_new, timestamps=True, want_alignment=True)
+    full = eng.generate_greedy(prompt, **kw)
+    L = full["length"]
+    al_full = eng.get_alignment(B, L - 1)
+    nf = [2 * T] * B
+    ts_full = eng.token_timestamps(B, 3, L, nf)
+    forced = full["sequences"][:, : 3 + n_forced].astype(np.int32)
+    out = eng.generate_greedy(forced, n_forced=n_forced, **kw)
+    al = eng.get_alignment(B, L - 1)
+    ts = eng.token_timestamps(B, 3, L, nf)
+    if dtype == "f32":
+        om = wo.OracleWhisper(dims, w, T=T)
+        opt = wo.GreedyOptions(max_new_tokens=max_new, min_new_tokens=max_new, timestamps=True, alignment_heads=heads)
+        ref = wo.greedy_generate(om, om.encode(wo.log_mel(pcm, dims.n_mels)), forced, opt, begin_index=3)
+        assert np.array_equal(out["sequences"], ref["sequences"])
+        assert np.abs(al - ref["cross"]).max() < 1e-4
+        assert np.array_equal(out["sequences"], full["sequences"]) and out["length"] == L
+        assert np.abs(al - al_full).max() < 1e-5 and np.array_equal(ts, ts_full)
+    else:
+        # reduced precision: the prefill launches hold 16-64 rows where a step holds B, i.e. other instantiations of the projection
+        # kernel (fc2's K split) - a bf16 rounding may flip; the forced part is identical by construction, the continuation on
+        # this model too, and the alignment rows agree to bf16 noise
+        assert np.array_equal(out["sequences"][:, : 3 + n_forced], full["sequences"][:, : 3 + n_forced])
+        assert np.abs(al[:, :, : 2 + n_forced] - al_full[:, :, : 2 + n_forced]).max() < 2e-2
+        same = (out["sequences"] == full["sequences"]).all(axis=1)
+        assert same.mean() >= 0.5, (out["sequences"], full["sequences"])
+        for b in np.nonzero(same)[0]:
+            assert np.abs(ts[b] - ts_full[b]).max() <= 0.0601
+    # errors: more forced tokens than prompt, forced <eos>, nothing left to generate
+    with pytest.raises(RuntimeError, match="n_forced"):
+        eng.generate_greedy(forced, n_forced=forced.shape[1], **kw)
+    bad = forced.copy(); bad[0, -1] = 50257
+    with pytest.raises(RuntimeError, match="forced token"):
+        eng.generate_greedy(bad, n_forced=max(1, n_forced), **kw)
+    with pytest.raises(RuntimeError, match="nothing to generate"):
+        eng.generate_greedy(full["sequences"][:, :L].astype(np.int32), n_forced=L - 3, **kw)
+    eng.close()
+
+
 @pytest.mark.parametrize("timestamps", [False, True])
 def test_suppress_lists_match_oracle(timestamps):
     """SuppressTokens / SuppressTokensAtBegin (HF:generation/logits_process.py:1816-1906): a suppress list that contains the

@@ -34,7 +34,7 @@ class tw_greedy_opts(C.Structure):
         ("max_length", C.c_int32), ("timestamps", C.c_int32), ("no_timestamps_id", C.c_int32),
         ("max_initial_timestamp_index", C.c_int32), ("n_begin_suppress", C.c_int32),
         ("begin_suppress", C.POINTER(C.c_int32)), ("n_suppress", C.c_int32), ("suppress", C.POINTER(C.c_int32)),
-        ("want_alignment", C.c_int32),
+        ("want_alignment", C.c_int32), ("n_forced", C.c_int32),
     ]
 
 

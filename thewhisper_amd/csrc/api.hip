@@ -89,6 +89,10 @@ struct tw_ctx {
   SamplerPartial* sampler_partials = nullptr;
   unsigned* suppress_bits = nullptr;  // [(V+31)/32] static suppress list as a bitmap, rebuilt per generate call
   int* h_pinned = nullptr;  // pinned host scratch: finished ring [8][64] | n_valid [64] | DecState upload [16]
+  int* row_ids = nullptr;   // device token table of a prefill (position-major), row_ids_cap ints
+  int* h_rows = nullptr;    // its pinned host staging
+  size_t row_ids_cap = 0;
+  int row_cap = 0;          // rows the per-token activation buffers hold (>= max_batch; 64 for the prefill launches)
   int* h_stage = nullptr;   // pinned staging of tw_generate_greedy: token table [Bmax][P] (up and down) | 3 x [Bmax] | suppress lists | DecState
   size_t h_stage_ints = 0;
   hipEvent_t ring_ev[8]{};
@@ -227,6 +231,7 @@ int tw_destroy(tw_ctx* c) {
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
+  if (c->h_rows) (void)hipHostFree(c->h_rows);
   for (int i = 0; i < 5; ++i) {
     if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
     if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
@@ -414,11 +419,17 @@ static int create_ctx(const tw_config* cfg, const tw_ctx* share, tw_ctx** out) {
     CALLOC(c->cross_vsc, Ld * B * H * Tp, true);
   }
   // per-token decoder activations that feed a projection are fragment-major in groups of 16 streams (tw_xt_index)
-  const size_t Bg = (B + 15) / 16 * 16;  // whole groups of 16 streams
-  CALLOC(c->dx0, Bg * d * e, true); CALLOC(c->dx1, Bg * d * e, true); CALLOC(c->dq, B * d * e, true);
+  // (sized for the 64 rows of a prefill launch - rows mode, tw_common.h - whatever max_batch is: < 1 MB)
+  c->row_cap = (int)std::max<size_t>(B, 64);
+  const size_t R = c->row_cap;
+  const size_t Bg = (R + 15) / 16 * 16;  // whole groups of 16 streams
+  CALLOC(c->dx0, Bg * d * e, true); CALLOC(c->dx1, Bg * d * e, true); CALLOC(c->dq, R * d * e, true);
   CALLOC(c->datt, Bg * d * e, true); CALLOC(c->dh, Bg * F * e, true);
-  CALLOC(c->du, B * d * 4, true);
-  CALLOC(c->dstats, B * (d / 4) * 2 * 4, true);
+  CALLOC(c->du, R * d * 4, true);
+  CALLOC(c->dstats, R * (d / 4) * 2 * 4, true);
+  c->row_ids_cap = (size_t)B * P;
+  CALLOC(c->row_ids, c->row_ids_cap * 4, true);
+  CHIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_rows), sizeof(int) * c->row_ids_cap, hipHostMallocDefault));
   CALLOC(c->logits, B * V * 4, true);
   const size_t Ha = c->Ha > 0 ? c->Ha : 1;
   CALLOC(c->align, B * Ha * P * T * 4, true);
@@ -868,10 +879,12 @@ bool getenv_off_fuse() {
 }
 
 // one token for every stream: embed -> Ld layers -> final LN + tied logits (fp32)
-int decode_core(tw_ctx* c, int B, hipStream_t st) {
+// rs > 0: rows mode (tw_common.h: tw_row_of) - the B rows are rs streams x B / rs consecutive positions whose tokens are `ids`
+// (device, row order); no logits are produced (the tokens of those positions are known: prefill_core)
+int decode_core(tw_ctx* c, int B, hipStream_t st, int rs = 0, const int* ids = nullptr) {
   const int d = c->d, H = c->H, F = c->ffn, T = c->T, P = c->P, dt = c->dtype;
   const size_t e = c->esz;
-  HIPCHK(c, launch_embed(dt, c->cur_ids, c->stt, c->tok_emb, c->dec_pos, c->dx0, B, d, st));
+  HIPCHK(c, launch_embed(dt, rs > 0 ? ids : c->cur_ids, c->stt, c->tok_emb, c->dec_pos, c->dx0, B, d, rs, st));
   void* xin = c->dx0;
   void* xmid = c->dx1;
   const int Pp = (P + 63) / 64 * 64;
@@ -890,9 +903,10 @@ int decode_core(tw_ctx* c, int B, hipStream_t st) {
       a.x = xin; a.ldx = d; a.ln_gw = L.qkv_gw; a.ln_cb = L.qkv_cb; a.W = L.wqkv; a.wscale = L.s_qkv; a.a16 = c->a16; a.N = (fq_on ? 4 : 3) * d; a.K = d; a.B = B;
       a.y = c->dq; a.ldy = d; a.kcache = sk; a.vcache = sv; a.cache_bstride = (long long)Pp * d; a.d_model = d; a.stt = c->stt;
       a.u = fq_on ? c->du : nullptr;
+      a.rows_streams = rs;
       HIPCHK(c, launch_gemv(dt, a, st));
     }
-    HIPCHK(c, launch_dec_self_attn(dt, c->dq, sk, sv, Pp, c->datt, B, H, c->dec_key_bound > 0 ? c->dec_key_bound : P, c->stt, st));
+    HIPCHK(c, launch_dec_self_attn(dt, c->dq, sk, sv, Pp, c->datt, B, H, c->dec_key_bound > 0 ? c->dec_key_bound : P, c->stt, rs, st));
     {
       GemvArgs a{};
       a.x = c->datt; a.ldx = d; a.W = L.wo; a.wscale = L.s_o; a.a16 = c->a16; a.tr = L.tr_o; a.bias = L.bo; a.N = (fq_on ? 2 : 1) * d; a.K = d; a.B = B;
@@ -912,7 +926,7 @@ int decode_core(tw_ctx* c, int B, hipStream_t st) {
     HIPCHK(c, launch_dec_cross_attn(dt, c->dq, fq, at(c->cross_k, cross_layer * l, c->w8 ? 1 : e), at(c->cross_v, cross_layer * l, c->w8 ? 1 : e),
                                     c->datt, B, H, T, c->Tp, c->Ha > 0 ? c->align_slot + (size_t)l * H : nullptr, c->align, c->Ha,
                                     P, c->stt, c->w8 ? c->cross_ksc + (size_t)c->Bmax * H * c->Tp * l : nullptr,
-                                    c->w8 ? c->cross_vsc + (size_t)c->Bmax * H * c->Tp * l : nullptr, st));
+                                    c->w8 ? c->cross_vsc + (size_t)c->Bmax * H * c->Tp * l : nullptr, rs, st));
     {
       GemvArgs a{};
       a.x = c->datt; a.ldx = d; a.W = L.wo_c; a.wscale = L.s_oc; a.a16 = c->a16; a.tr = L.tr_oc; a.bias = L.bo_c; a.N = d; a.K = d; a.B = B; a.res = xmid; a.ldres = d;
@@ -933,11 +947,36 @@ int decode_core(tw_ctx* c, int B, hipStream_t st) {
     }
     void* t = xin; xin = xmid; xmid = t;
   }
-  {
+  if (rs == 0) {
     GemvArgs a{};
     a.x = xin; a.ldx = d; a.ln_gw = c->logit_gw; a.ln_cb = c->logit_cb; a.W = c->logit_w; a.wscale = c->logit_ws; a.a16 = c->a16; a.N = c->V; a.K = d; a.B = B;
     a.y_f32 = c->logits;
     HIPCHK(c, launch_gemv(dt, a, st));
+  }
+  return TW_OK;
+}
+
+// Batched prefill of the positions [0, n_pos) of B streams whose tokens are known (host table tok[b * ld + p]): launches of up to
+// `cap` rows = B streams x L consecutive positions (rows mode), each a full pass through the decoder layers that fills the
+// self-attention caches and the alignment rows of its positions; the weights are streamed once per L positions instead of once per
+// position.  On return the device position is n_pos.  Not captured in a graph (a handful of launches per call).
+int prefill_core(tw_ctx* c, int B, const int* tok, int ld, int n_pos, hipStream_t st) {
+  if (n_pos <= 0) return TW_OK;
+  const int cap = (c->w8 && !c->a16) ? 16 : 64;     // W8A8 quantises activations per group of 16 rows: one group per launch
+  if (B > cap) return fail(c, TW_EINVAL, "prefill: %d streams exceed the %d rows of a launch", B, cap);
+  const int L = std::max(1, std::min(cap, c->row_cap) / B);
+  // position-major token table: row r of the launch at p0 is stream r % B at position p0 + r / B
+  if ((size_t)n_pos * B > c->row_ids_cap) return fail(c, TW_EINVAL, "prefill: %d positions x %d streams exceed the row table", n_pos, B);
+  int* h = c->h_rows;
+  for (int p = 0; p < n_pos; ++p)
+    for (int b = 0; b < B; ++b) h[(size_t)p * B + b] = tok[(size_t)b * ld + p];
+  HIPCHK(c, hipMemcpyAsync(c->row_ids, h, sizeof(int) * (size_t)n_pos * B, hipMemcpyHostToDevice, st));
+  for (int p0 = 0; p0 < n_pos; p0 += L) {
+    const int l = std::min(L, n_pos - p0);
+    c->dec_key_bound = std::min(((p0 + l + 63) / 64) * 64, ((c->P + 63) / 64) * 64);
+    int r = decode_core(c, l * B, st, B, c->row_ids + (size_t)p0 * B);
+    if (r != TW_OK) return r;
+    HIPCHK(c, launch_advance(c->stt, l, st));
   }
   return TW_OK;
 }
@@ -975,7 +1014,7 @@ int tw_decode_step(tw_ctx* c, int32_t B, const int32_t* ids_host, float* logits_
   if (r != TW_OK) return r;
   if (logits_dev)
     HIPCHK(c, hipMemcpyAsync(logits_dev, c->logits, sizeof(float) * (size_t)B * c->V, hipMemcpyDeviceToDevice, st));
-  HIPCHK(c, launch_advance(c->stt, st));  // pos += 1 on the device (keeps the step graph-compatible)
+  HIPCHK(c, launch_advance(c->stt, 1, st));  // pos += 1 on the device (keeps the step graph-compatible)
   return TW_OK;
 }
 
@@ -987,7 +1026,11 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
   if (n_prompt < 1 || n_prompt >= c->P) return fail(c, TW_EINVAL, "bad n_prompt %d", n_prompt);
   if (o->n_begin_suppress > 64 || o->n_suppress > 1024) return fail(c, TW_EINVAL, "suppress lists too long");
   if (o->want_alignment && c->Ha == 0) return fail(c, TW_EINVAL, "want_alignment but the context has no alignment heads");
-  int max_len = n_prompt + o->max_new_tokens;
+  // forced output tokens (tw_greedy_opts::n_forced): the begin index of the generation is n_begin, the tokens behind it are given
+  const int n_forced = o->n_forced;
+  if (n_forced < 0 || n_forced >= n_prompt) return fail(c, TW_EINVAL, "bad n_forced %d (n_prompt %d)", n_forced, n_prompt);
+  const int n_begin = n_prompt - n_forced;
+  int max_len = n_begin + o->max_new_tokens;
   if (o->max_length > 0 && o->max_length < max_len) max_len = o->max_length;
   if (max_len > c->P) max_len = c->P;
   if (max_len <= n_prompt) return fail(c, TW_EINVAL, "nothing to generate (max_len %d <= n_prompt %d)", max_len, n_prompt);
@@ -1012,9 +1055,15 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
       if (t < 0 || t >= c->V) return fail(c, TW_EINVAL, "prompt token %d out of range", t);
       hseq[(size_t)b * P + i] = t;
     }
-    first[b] = prompt[(size_t)b * n_prompt];
+    // with forced tokens the loop starts at the LAST given position (everything before it is prefilled below)
+    first[b] = prompt[(size_t)b * n_prompt + (n_forced > 0 ? n_prompt - 1 : 0)];
     zeros[b] = 0;
     neg[b] = -1;
+    for (int i = n_begin; i < n_prompt; ++i) {   // state the sampler would have after producing the forced tokens itself
+      const int t = prompt[(size_t)b * n_prompt + i];
+      if (t == o->eos_id) return fail(c, TW_EINVAL, "a forced token is <eos>");
+      if (o->timestamps && t > o->no_timestamps_id) neg[b] = t;
+    }
   }
   HIPCHK(c, hipMemcpyAsync(c->seq, hseq, sizeof(int) * (size_t)B * P, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(c->cur_ids, first, sizeof(int) * B, hipMemcpyHostToDevice, st));
@@ -1029,8 +1078,13 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
     HIPCHK(c, hipMemcpyAsync(c->suppress_dev, sup, sizeof(int) * o->n_suppress, hipMemcpyHostToDevice, st));
   }
   HIPCHK(c, launch_suppress_bitmap(c->suppress_dev, o->n_suppress, c->suppress_bits, c->V, st));
-  *s0p = DecState{0, n_prompt, max_len - 1, B};
+  *s0p = DecState{0, n_begin, max_len - 1, B};
   HIPCHK(c, hipMemcpyAsync(c->stt, s0p, sizeof(DecState), hipMemcpyHostToDevice, st));
+  const int s_start = n_forced > 0 ? n_prompt - 1 : 0;
+  if (n_forced > 0) {   // positions 0 .. n_prompt-2 in batched launches (self-attention caches + alignment rows); device pos -> s_start
+    int r = prefill_core(c, B, prompt, n_prompt, s_start, st);
+    if (r != TW_OK) return r;
+  }
 
   SamplerArgs sa{};
   sa.logits = c->logits; sa.V = c->V; sa.B = B; sa.seq = c->seq; sa.seq_ld = P; sa.cur_ids = c->cur_ids;
@@ -1092,12 +1146,12 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
   const int LAG = std::max(1, 4 / group);
   int steps = 0, launches = 0;
   bool all_done = false;
-  for (int s = 0; s < max_len - 1 && !all_done;) {
+  for (int s = s_start; s < max_len - 1 && !all_done;) {
     // step s produces the token at position s + 1, which can be <eos> only once s + 1 - n_prompt >= min_new_tokens
     // (not for the first launch of a call: submitting a graph costs host time in proportion to its nodes, and the GPU is idle until
     // the first one is in; a small first launch covers the submission of the big second one)
     const bool eos_free = use_graph && launches >= 1 && group_forced > group && s + group_forced <= max_len - 1 &&
-                          s + group_forced - 1 < n_prompt + o->min_new_tokens - 1;
+                          s + group_forced - 1 < n_begin + o->min_new_tokens - 1;
     const int n = eos_free ? group_forced : ((use_graph && s + group <= max_len - 1) ? group : 1);   // steps in this launch
     const int last = s + n - 1;
     const int kb = std::min(((last + 64) / 64) * 64, ((max_len + 63) / 64) * 64);   // keys [0, kb) cover positions s .. last
@@ -1132,7 +1186,7 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
   HIPCHK(c, hipStreamSynchronize(st));
 
   // common sequence length exactly as HF's loop would have stopped: when the last row hit eos, or at max_len
-  const int produced = steps + 1;  // positions 0..steps are filled
+  const int produced = s_start + steps + 1;  // positions 0 .. s_start + steps are filled
   int L = n_prompt + 1;
   for (int b = 0; b < B; ++b) {
     int lb = produced;

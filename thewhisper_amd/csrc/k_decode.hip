@@ -276,6 +276,7 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
   float* u_p = a.u;              // "cross query ahead" (tw_common.h): float32 [B][d_model] pre-activation, null = off
   float* stats_p = a.stats;
   const int nsplit = a.nsplit;   // SK_RES: rows >= nsplit accumulate into u (the launcher sets N when there is no such half)
+  const int rows_streams = a.rows_streams;   // SK_KV: rows mode of the cache scatter (tw_row_of)
   // (1) what the activation / weight requests need: delivered with the wave (leading arguments), nothing to wait for
   asm volatile("" ::"s"(x), "s"(W), "s"(K), "s"(N), "s"(B), "s"(RG), "s"(wscale));
   int cur_pos = 0;
@@ -406,7 +407,7 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
   // (2) everything else (epilogue operands, outputs, cache geometry): ONE batch of scalar loads from the argument block, waited for
   // here, behind the operand requests that are already on their way
   asm volatile("" ::"s"(bias), "s"(res), "s"(gw_p), "s"(cb_p), "s"(a.gelu), "s"(ldy), "s"(d_model), "s"(cache_bstride), "s"(y),
-               "s"(y_f32), "s"(kcache), "s"(vcache), "s"(stt), "s"(u_p), "s"(nsplit), "s"(stats_p));
+               "s"(y_f32), "s"(kcache), "s"(vcache), "s"(stt), "s"(u_p), "s"(nsplit), "s"(stats_p), "s"(rows_streams));
 #ifdef TW_PROBE_TS
   cur_pos = stt->pos;
 #else
@@ -545,9 +546,11 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
             if (seg == 3) {   // cross query ahead: x . W'^T + c0 WITHOUT this LayerNorm (its own is applied by the consumer)
               u_p[(long long)jg * d_model + nn] = vraw + e_c;
             } else {
-              const long long hb = (long long)jg * cache_bstride + (long long)hh * (cache_bstride / (d_model >> 6));  // (stream, head)
+              int srow, prow;   // rows mode (prefill): row jg is stream jg % rs at position cur_pos + jg / rs
+              tw_row_of(jg, rows_streams, cur_pos, srow, prow);
+              const long long hb = (long long)srow * cache_bstride + (long long)hh * (cache_bstride / (d_model >> 6));  // (stream, head)
               T* dst = seg == 0 ? y + (long long)jg * ldy + n
-                                : (seg == 1 ? kcache + hb + tw_kf_index<T>(cur_pos, cc) : vcache + hb + tw_vtf_index<T>(cur_pos, cc));
+                                : (seg == 1 ? kcache + hb + tw_kf_index<T>(prow, cc) : vcache + hb + tw_vtf_index<T>(prow, cc));
               *dst = (T)v;
             }
           } else if (EPI == SK_STORE) {
@@ -1017,14 +1020,17 @@ __device__ __forceinline__ float attn_mfma_block_kv8(const bf16_t* __restrict__ 
 template <typename T, bool SINGLE, int NW>
 __global__ __launch_bounds__(NW * 64) void dec_self_attn_kernel(const T* __restrict__ q, const T* __restrict__ kc,
                                                                  const T* __restrict__ vc, int rows, int H, int key_bound,
-                                                                 T* __restrict__ out, const DecState* __restrict__ stt) {
+                                                                 T* __restrict__ out, const DecState* __restrict__ stt, int rows_streams) {
   // argument order: what the K / V^T / q request addresses need comes first (kernarg preload, see skinny_mfma_kernel)
   __shared__ float sc[512];
   __shared__ float red[2 * 4 + 4 * 64];
   asm volatile("" ::"s"(q), "s"(kc), "s"(vc), "s"(rows), "s"(H), "s"(key_bound));
   const int h = blockIdx.x, b = blockIdx.y;
-  const int n_keys = stt->pos + 1;
-  const long long base = ((long long)b * H + h) * rows * 64;
+  // rows mode (prefill): row b is a position of stream b % rs - its K / V^T live in that stream's cache (the addresses depend on
+  // kernel arguments only, as before) and it sees the keys up to ITS position (causal inside the launch)
+  const int srow = rows_streams > 0 ? b % rows_streams : b;
+  const int n_keys = stt->pos + (rows_streams > 0 ? b / rows_streams : 0) + 1;
+  const long long base = ((long long)srow * H + h) * rows * 64;
   // the host guarantees pos < key_bound (a multiple of 64, <= rows): the requests do not wait for `pos`
   attn_mfma_block<T, NW, SINGLE>(q + ((long long)b * H + h) * 64, kc + base, vc + base, n_keys, key_bound, sc, red,
                                 out + (long long)(b >> 4) * 16 * H * 64, b & 15, h * 64);  // fragment-major, groups of 16 streams
@@ -1034,20 +1040,22 @@ template <typename T, bool SINGLE, bool FQ>
 __global__ __launch_bounds__(512) void dec_cross_attn_kernel(const T* __restrict__ ck, const T* __restrict__ cv, int H, int Tp,
                                                               int Tlen, const T* __restrict__ q, T* __restrict__ out,
                                                               const int* __restrict__ align_slot, float* __restrict__ align,
-                                                              int Ha, int P, const DecState* __restrict__ stt, FusedQ fq) {
+                                                              int Ha, int P, const DecState* __restrict__ stt, FusedQ fq, int rows_streams) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* sc = reinterpret_cast<float*>(smem);  // [Tp] scores -> unnormalised probabilities
   __shared__ float red[2 * 8 + 8 * 64];
   __shared__ __attribute__((aligned(16))) T qst[FQ ? 8 * 64 : 8];
   asm volatile("" ::"s"(ck), "s"(cv), "s"(H), "s"(Tp), "s"(Tlen));
   const int h = blockIdx.x, b = blockIdx.y;
-  const long long base = ((long long)b * H + h) * Tp * 64;
+  const int srow = rows_streams > 0 ? b % rows_streams : b;   // rows mode (prefill): the stream whose encoder K / V this row attends to
+  const long long base = ((long long)srow * H + h) * Tp * 64;
   const float inv = attn_mfma_block<T, 8, SINGLE, FQ>(q + ((long long)b * H + h) * 64, ck + base, cv + base, Tlen, Tp, sc, red,
                                                       out + (long long)(b >> 4) * 16 * H * 64, b & 15, h * 64, fq, b, h, qst);
   const int slot = align_slot ? align_slot[h] : -1;
   if (slot >= 0) {  // A11 side output: softmax row of an alignment head
     __syncthreads();
-    float* row = align + (((long long)b * Ha + slot) * P + stt->pos) * Tlen;
+    const int prow = stt->pos + (rows_streams > 0 ? b / rows_streams : 0);
+    float* row = align + (((long long)srow * Ha + slot) * P + prow) * Tlen;
     for (int t = threadIdx.x; t < Tlen; t += 512) row[t] = sc[t] * inv;
   }
 }
@@ -1058,7 +1066,7 @@ __global__ __launch_bounds__(512) void dec_cross_attn_kv8_kernel(const unsigned 
                                                                   const unsigned char* __restrict__ vsc, int H, int Tp, int Tlen,
                                                                   const bf16_t* __restrict__ q, bf16_t* __restrict__ out,
                                                                   const int* __restrict__ align_slot, float* __restrict__ align,
-                                                                  int Ha, int P, const DecState* __restrict__ stt, FusedQ fq) {
+                                                                  int Ha, int P, const DecState* __restrict__ stt, FusedQ fq, int rows_streams) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* sc = reinterpret_cast<float*>(smem);  // [Tp] scores -> unnormalised probabilities
   float* scv = sc + Tp;                        // [Tp] probabilities x V scale
@@ -1066,14 +1074,16 @@ __global__ __launch_bounds__(512) void dec_cross_attn_kv8_kernel(const unsigned 
   __shared__ __attribute__((aligned(16))) bf16_t qst[FQ ? 8 * 64 : 8];
   asm volatile("" ::"s"(ck), "s"(cv), "s"(ksc), "s"(vsc), "s"(H), "s"(Tp), "s"(Tlen));
   const int h = blockIdx.x, b = blockIdx.y;
-  const long long hb = ((long long)b * H + h) * Tp;
+  const int srow = rows_streams > 0 ? b % rows_streams : b;   // rows mode (prefill), as in dec_cross_attn_kernel
+  const long long hb = ((long long)srow * H + h) * Tp;
   const float inv = attn_mfma_block_kv8<8, G, FQ>(q + ((long long)b * H + h) * 64, ck + hb * 64, cv + hb * 64, ksc + hb, vsc + hb,
                                                   Tlen, Tp, sc, scv, red, out + (long long)(b >> 4) * 16 * H * 64, b & 15, h * 64,
                                                   fq, b, h, qst);
   const int slot = align_slot ? align_slot[h] : -1;
   if (slot >= 0) {  // A11 side output: softmax row of an alignment head
     __syncthreads();
-    float* row = align + (((long long)b * Ha + slot) * P + stt->pos) * Tlen;
+    const int prow = stt->pos + (rows_streams > 0 ? b / rows_streams : 0);
+    float* row = align + (((long long)srow * Ha + slot) * P + prow) * Tlen;
     for (int t = threadIdx.x; t < Tlen; t += 512) row[t] = sc[t] * inv;
   }
 }
@@ -1293,7 +1303,7 @@ __global__ __launch_bounds__(1024) void sampler_finish_kernel(SamplerArgs a) {
   if (tid == 0) a.stt->pos += 1;
 }
 
-__global__ void advance_kernel(DecState* stt) { stt->pos += 1; }
+__global__ void advance_kernel(DecState* stt, int n) { stt->pos += n; }
 
 }  // namespace
 
@@ -1415,7 +1425,11 @@ static hipError_t skinny_launch_w8(const GemvArgs& a0, hipStream_t st) {
   static const int max_blocks = env_int("TW_SK_MAX_BLOCKS", 512);
   const int steps_per_wave = (a.K / 128 + NW - 1) / NW;
   const bool groups = a.B > 16;   // W8A16 only (skinny_launch_v): 2 steps in flight per group, further rounds for longer K
-  a.rg = (tiles + max_blocks - 1) / max_blocks;
+  // several groups of streams: every workgroup re-reads the whole activation block (164 KB per 64 streams at K = 1280, more bytes than
+  // its weight tile), so the 320-tile launches walk TWO tiles per workgroup and keep the activation fragments in registers
+  // (64 streams x 15 s: 3.50 -> 3.32 ms per step, profiles/r04_b64_15s_two_tiles_per_workgroup.txt; neutral for the bf16 kernels)
+  static const int max_blocks_groups = env_int("TW_SK_MAX_BLOCKS_W8_GROUPS", 160);
+  a.rg = (tiles + (groups ? max_blocks_groups : max_blocks) - 1) / (groups ? max_blocks_groups : max_blocks);
   if (a.rg < 1 || steps_per_wave > (groups ? 2 : 3)) a.rg = 1;   // several tiles per workgroup only with one round per tile
   dim3 grid((tiles + a.rg - 1) / a.rg);
   if constexpr (TR != 16) {
@@ -1470,14 +1484,14 @@ hipError_t launch_gemv(int dtype, const GemvArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_dec_self_attn(int dtype, const void* q, const void* kc, const void* vc, int rows, void* out, int B, int H,
-                                int key_bound, const DecState* stt, hipStream_t st) {
+                                int key_bound, const DecState* stt, int rows_streams, hipStream_t st) {
   // key_bound: an upper bound of pos+1 for this call known on the host (prompt + max new tokens)
   int kb = (key_bound + 63) / 64 * 64;
   if (rows % 64 != 0 || rows > 512 || kb > rows) return hipErrorInvalidValue;
   const bool single = kb <= 256;
   const int nw = kb <= 64 ? 1 : (kb <= 128 ? 2 : 4);
 #define SA_GO(TT, SV, NWV) hipLaunchKernelGGL((dec_self_attn_kernel<TT, SV, NWV>), dim3(H, B), dim3(NWV * 64), 0, st, (const TT*)q, \
-                                              (const TT*)kc, (const TT*)vc, rows, H, kb, (TT*)out, stt)
+                                              (const TT*)kc, (const TT*)vc, rows, H, kb, (TT*)out, stt, rows_streams)
 #define SA_PICK(TT) do { if (nw == 1) SA_GO(TT, true, 1); else if (nw == 2) SA_GO(TT, true, 2); else if (single) SA_GO(TT, true, 4); \
                          else SA_GO(TT, false, 4); } while (0)
   if (dtype == 1) SA_PICK(bf16_t); else SA_PICK(float);
@@ -1488,7 +1502,8 @@ hipError_t launch_dec_self_attn(int dtype, const void* q, const void* kc, const 
 
 hipError_t launch_dec_cross_attn(int dtype, const void* q, const FusedQ& fq, const void* ck, const void* cv, void* out, int B, int H,
                                  int T, int Tp, const int* align_slot_for_head, float* align, int Ha, int P,
-                                 const DecState* stt, const unsigned char* ksc, const unsigned char* vsc, hipStream_t st) {
+                                 const DecState* stt, const unsigned char* ksc, const unsigned char* vsc, int rows_streams,
+                                 hipStream_t st) {
   if (Tp % 64 != 0 || Tp < T) return hipErrorInvalidValue;
   const bool single = Tp <= 512;
   const bool f = fq.u != nullptr;
@@ -1502,7 +1517,7 @@ hipError_t launch_dec_cross_attn(int dtype, const void* q, const FusedQ& fq, con
     const size_t lds8 = (size_t)Tp * sizeof(float) * 2;
 #define CA8_GO(GV, FV) hipLaunchKernelGGL((dec_cross_attn_kv8_kernel<GV, FV>), dim3(H, B), dim3(512), lds8, st,                        \
                                           (const unsigned char*)ck, (const unsigned char*)cv, ksc, vsc, H, Tp, T, (const bf16_t*)q,  \
-                                          (bf16_t*)out, align_slot_for_head, align, Ha, P, stt, fq)
+                                          (bf16_t*)out, align_slot_for_head, align, Ha, P, stt, fq, rows_streams)
 #define CA8_PICK(FV) do { if (Tp <= 512) CA8_GO(1, FV); else if (Tp <= 1024) CA8_GO(2, FV); else if (Tp <= 1536) CA8_GO(3, FV);      \
                           else return hipErrorInvalidValue; } while (0)
     if (f) CA8_PICK(true); else CA8_PICK(false);
@@ -1512,7 +1527,7 @@ hipError_t launch_dec_cross_attn(int dtype, const void* q, const FusedQ& fq, con
   }
   const size_t lds = (size_t)Tp * sizeof(float);
 #define CA_GO(TT, SV, FV) hipLaunchKernelGGL((dec_cross_attn_kernel<TT, SV, FV>), dim3(H, B), dim3(512), lds, st, (const TT*)ck,      \
-                                             (const TT*)cv, H, Tp, T, (const TT*)q, (TT*)out, align_slot_for_head, align, Ha, P, stt, fq)
+                                             (const TT*)cv, H, Tp, T, (const TT*)q, (TT*)out, align_slot_for_head, align, Ha, P, stt, fq, rows_streams)
 #define CA_PICK(TT) do { if (single) { if (f) CA_GO(TT, true, true); else CA_GO(TT, true, false); }                                  \
                          else { if (f) CA_GO(TT, false, true); else CA_GO(TT, false, false); } } while (0)
   if (dtype == 1) CA_PICK(bf16_t); else CA_PICK(float);
@@ -1543,8 +1558,8 @@ hipError_t launch_suppress_bitmap(const int* list, int n, unsigned* bits, int V,
   return hipGetLastError();
 }
 
-hipError_t launch_advance(DecState* stt, hipStream_t st) {
-  hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, stt);
+hipError_t launch_advance(DecState* stt, int n, hipStream_t st) {
+  hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, stt, n);
   return hipGetLastError();
 }
 

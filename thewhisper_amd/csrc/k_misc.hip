@@ -151,10 +151,11 @@ __global__ void interp_positions_kernel(const TS* __restrict__ src, TD* __restri
 
 template <typename T>
 __global__ void embed_kernel(const int* __restrict__ ids, const DecState* __restrict__ stt, const T* __restrict__ tok,
-                             const T* __restrict__ pos, T* __restrict__ x, int B, int d) {
+                             const T* __restrict__ pos, T* __restrict__ x, int B, int d, int rows_streams) {
   const int b = blockIdx.x;
   const int id = ids[b];
-  const int p = stt->pos;
+  int stream, p;
+  tw_row_of(b, rows_streams, stt->pos, stream, p);
   for (int i = threadIdx.x; i < d; i += blockDim.x)  // decoder activations are fragment-major (tw_common.h: tw_xt_index)
     x[(long long)(b >> 4) * 16 * d + tw_xt_index<T>(b & 15, i)] = (T)((float)tok[(long long)id * d + i] + (float)pos[(long long)p * d + i]);
 }
@@ -236,8 +237,8 @@ hipError_t launch_interp_positions(int dd, int sd, const void* src, void* dst, i
 }
 
 hipError_t launch_embed(int dtype, const int* ids, const DecState* stt, const void* tok, const void* pos, void* x,
-                        int B, int d, hipStream_t st) {
-  if (dtype == 1) hipLaunchKernelGGL(embed_kernel<bf16_t>, dim3(B), dim3(256), 0, st, ids, stt, (const bf16_t*)tok, (const bf16_t*)pos, (bf16_t*)x, B, d);
-  else hipLaunchKernelGGL(embed_kernel<float>, dim3(B), dim3(256), 0, st, ids, stt, (const float*)tok, (const float*)pos, (float*)x, B, d);
+                        int B, int d, int rows_streams, hipStream_t st) {
+  if (dtype == 1) hipLaunchKernelGGL(embed_kernel<bf16_t>, dim3(B), dim3(256), 0, st, ids, stt, (const bf16_t*)tok, (const bf16_t*)pos, (bf16_t*)x, B, d, rows_streams);
+  else hipLaunchKernelGGL(embed_kernel<float>, dim3(B), dim3(256), 0, st, ids, stt, (const float*)tok, (const float*)pos, (float*)x, B, d, rows_streams);
   return hipGetLastError();
 }

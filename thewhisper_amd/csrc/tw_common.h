@@ -158,9 +158,24 @@ struct DecState {   // lives in device memory so that a captured graph is positi
   int step_limit;   // last position that may be produced (max_len - 1)
   int unfinished;   // count of unfinished streams (written by the sampler)
 };
-// x[b] = tok_emb[ids[b]] + pos_emb[pos]
+// "Rows mode" of the decoder kernels (batched prefill of FORCED tokens, api.hip: prefill_core): the B rows of a launch are not B
+// streams at one position but rs streams x B / rs consecutive positions - row r is stream r % rs at position pos + r / rs (stream
+// fastest: a group of 16 rows is one position of 16 streams).  Row-wise work (projections, LayerNorm statistics, the fused cross
+// query) does not care; what does is everything that touches a stream's caches or its position: the embedding's positional row,
+// the K / V^T cache scatter of the QKV projection, the self-attention's key range (causal inside the launch: keys [0, p]), the
+// cross-attention's arena and its alignment row.  rs = 0: the ordinary step (row = stream, one position).
+__device__ __forceinline__ void tw_row_of(int r, int rs, int pos, int& stream, int& p) {
+  if (rs > 0) {
+    stream = r % rs;
+    p = pos + r / rs;
+  } else {
+    stream = r;
+    p = pos;
+  }
+}
+// x[b] = tok_emb[ids[b]] + pos_emb[pos]   (rows mode: pos_emb[pos + b / rows_streams])
 hipError_t launch_embed(int dtype, const int* ids, const DecState* stt, const void* tok, const void* pos, void* x,
-                        int B, int d, hipStream_t st);
+                        int B, int d, int rows_streams, hipStream_t st);
 // y[b, n] = epi( LN?(x[b,:]) . W[n,:] + bias[n] )  for b < B <= 16.
 struct GemvArgs {
   const void* x; int ldx;        // [16, K] input (T), fragment-major (tw_xt_index); ldx unused
@@ -187,6 +202,7 @@ struct GemvArgs {
   //    They also leave (sum, sum of squares) of the residual rows they produced in stats[stream][tile][2] (tile = n / tr):
   //    the consumer of u applies the folded LayerNorm with them.
   float* u; int nsplit; float* stats;
+  int rows_streams;  // rows mode (tw_row_of): > 0 = number of streams the B rows cycle through; only the K / V^T scatter uses it
 };
 hipError_t launch_gemv(int dtype, const GemvArgs& a, hipStream_t st);
 hipError_t init_decode_kernels();
@@ -201,7 +217,7 @@ hipError_t launch_fold_ln(int dtype, void* W, const void* Wsrc, const void* g, c
 // (tw_kf_index / tw_vtf_index); out [16,d] fragment-major (tw_xt_index).
 // key_bound: host-known upper bound of pos+1 for this call; <= 256 selects the single-round-trip kernel
 hipError_t launch_dec_self_attn(int dtype, const void* q, const void* kc, const void* vc, int rows, void* out, int B, int H,
-                                int key_bound, const DecState* stt, hipStream_t st);
+                                int key_bound, const DecState* stt, int rows_streams, hipStream_t st);
 // cross attention over cached encoder K/V: ck/cv per (stream, head) Tp keys fragment-major; out fragment-major; align rows:
 // for head h with align_slot[h] >= 0 write the softmax row to align[((b*Ha + slot)*P + pos)*T + t]
 // ksc / vsc non-null: ck / cv are the fp8 caches above (bf16 contexts only), these their per-key scale bytes [B][H][Tp]
@@ -215,7 +231,8 @@ struct FusedQ {
 };
 hipError_t launch_dec_cross_attn(int dtype, const void* q, const FusedQ& fq, const void* ck, const void* cv, void* out, int B, int H,
                                  int T, int Tp, const int* align_slot_for_head, float* align, int Ha, int P,
-                                 const DecState* stt, const unsigned char* ksc, const unsigned char* vsc, hipStream_t st);
+                                 const DecState* stt, const unsigned char* ksc, const unsigned char* vsc, int rows_streams,
+                                 hipStream_t st);
 // load-time composition for "cross query ahead": out[n][k] = sum_j A[n][j] Bm[j][k] (row-major, T), c0[n] = sum_j A[n][j] bvec[j]
 hipError_t launch_compose(int dtype, const void* A, const void* Bm, const void* bvec, void* out, float* c0, int N, int J, int K,
                           hipStream_t st);
@@ -236,7 +253,7 @@ struct SamplerArgs {   // A10 + argmax + bookkeeping
 };
 hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st);   // sampler + pos advance
 hipError_t launch_suppress_bitmap(const int* list, int n, unsigned* bits, int V, hipStream_t st);  // zero + set bits
-hipError_t launch_advance(DecState* stt, hipStream_t st);            // pos += 1 only (teacher-forced stepping)
+hipError_t launch_advance(DecState* stt, int n, hipStream_t st);     // pos += n only (teacher-forced stepping, prefill)
 
 // A11: alignment rows -> token timestamps
 struct DtwArgs {

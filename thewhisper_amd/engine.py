@@ -300,7 +300,10 @@ class WhisperEngine:
         begin_suppress: Iterable[int] = (220, 50257),
         suppress: Iterable[int] = (),
         want_alignment: bool = False,
+        n_forced: int = 0,
     ) -> Dict[str, np.ndarray]:
+        """``n_forced``: the last ``n_forced`` tokens of every prompt row are forced OUTPUT tokens (they count as generated; a
+        batched prefill processes them - tw_greedy_opts::n_forced); the returned sequences contain them like generated ones."""
         prompt = np.ascontiguousarray(prompt, dtype=np.int32)
         B, n0 = prompt.shape
         o = _cabi.tw_greedy_opts()
@@ -316,6 +319,7 @@ class WhisperEngine:
         o.n_begin_suppress, o.begin_suppress = len(bs), bs_arr
         o.n_suppress, o.suppress = len(sp), sp_arr
         o.want_alignment = 1 if want_alignment else 0
+        o.n_forced = int(n_forced)
         out = np.full((B, int(max_length)), pad_id, dtype=np.int32)
         out_len = C.c_int32(0)
         rc = self.lib.tw_generate_greedy(self.ctx, B, prompt.ctypes.data_as(C.POINTER(C.c_int32)), n0, C.byref(o),
