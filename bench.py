@@ -217,13 +217,45 @@ def pipeline_leg(eng, dims, args, device_index, heads, latency_calls, hub_rounds
         # 2.0, 2.5, ... 10.5 s, then oscillates between ~6.8 and ~8.9 s as committed audio is trimmed): ragged buffers, one call
         # per 0.5 s of new audio - the p50 of THIS sequence is what a streaming session sees (R:...streaming_pipeline.py:740-822)
         ragged = [2.0 + 0.5 * i for i in range(18)] + [6.8 + 0.5 * (i % 5) for i in range(40)]
-        rag = []
-        for i, secs in enumerate(ragged if latency_calls > 0 else []):
-            buf = clips[i % B][: min(len(clips[0]), int(secs * 16000))]
-            t0 = time.perf_counter()
-            backend.transcribe(buf, 0.0, 16000)
-            rag.append((time.perf_counter() - t0) * 1e3)
+        # ... as ONE stream (round 4): the buffer's end advances 0.5 s per call and its start jumps when the scheduler trims, so that
+        # four of five calls extend their predecessor - the premise of the opt-in decoder-side reuse
+        stream = (np.random.default_rng(11).standard_normal(int((2.0 + 0.5 * len(ragged) + 1) * 16000)) * 0.1).clip(-1, 1).astype(np.float32)
+
+        def run_pattern(be):
+            lat_ms, words = [], []
+            for i, secs in enumerate(ragged if latency_calls > 0 else []):
+                end = 2.0 + 0.5 * i
+                secs = min(secs, end, float(args.chunk_s))
+                start = round(end - secs, 3)
+                buf = stream[int(start * 16000) : int(end * 16000)]
+                t0 = time.perf_counter()
+                words.append(be.transcribe(buf, start, 16000))
+                lat_ms.append((time.perf_counter() - t0) * 1e3)
+            return lat_ms, words
+
+        rag, plain_words = run_pattern(backend)
         rag.sort()
+        reuse_out = {}
+        if latency_calls > 0 and args.chunk_s <= 10:
+            rb = AMDWhisperBackend(None, chunk_length_s=args.chunk_s, asr_pipeline=pipe, reuse_committed_prefix=True)
+            rl, reuse_words = run_pattern(rb)
+            rl.sort()
+            ident = []
+            for a, b in zip(plain_words, reuse_words):
+                n = max(len(a), len(b))
+                if n:
+                    ident.append(sum(1 for x, y in zip(a, b) if x["text"] == y["text"]) / n)
+            st = rb.reuse_stats
+            reuse_out = {
+                "reuse_scheduler_pattern_p50_ms": round(rl[len(rl) // 2], 2), "reuse_scheduler_pattern_p90_ms": round(rl[(len(rl) * 9) // 10], 2),
+                "reuse_calls": st["calls"], "reuse_calls_with_forced_prefix": st["reused"],
+                "reuse_forced_token_share": round(st["forced_tokens"] / max(1, st["forced_tokens"] + st["decoded_tokens"]), 3),
+                "reuse_word_identity_mean": round(float(np.mean(ident)), 3) if ident else None,
+                "reuse_note": "AMDWhisperBackend(reuse_committed_prefix=True), opt-in: the previous tick's tokens whose word timestamps end >= 1 s "
+                              "before the old buffer's end are forced through a batched prefill (tw_greedy_opts::n_forced), only the tail "
+                              "is decoded; word identity = share of words equal (same index, same text) to the plain backend's on the same "
+                              "calls - random weights, so a chaotic lower bound",
+            }
         # (a) lock-step rounds (continuity with rounds 1-2: all sessions ask at once and wait for the slowest), classic whole-call
         #     batches: what the hub did until round 3
         def lockstep(hub, rounds):
@@ -312,6 +344,7 @@ def pipeline_leg(eng, dims, args, device_index, heads, latency_calls, hub_rounds
             "scheduler_pattern_p50_ms": round(rag[len(rag) // 2], 2) if rag else None,
             "scheduler_pattern_p90_ms": round(rag[min(len(rag) - 1, (len(rag) * 9) // 10)], 2) if rag else None,
             "scheduler_pattern_calls": len(rag),
+            **reuse_out,
             "note": f"host float32 {args.chunk_s} s buffers through thewhisper_amd.AMDWhisperBackend.transcribe (reference contract "
                     f"R:thestage_speechkit/streaming/streaming_pipeline.py:388-435: word timestamps on, max_new_tokens=128, natural eos); "
                     f"hub_*: {B} free-running session threads share one engine through BatchingHub, {hub_rounds} requests each, tokens "

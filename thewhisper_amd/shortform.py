@@ -60,9 +60,13 @@ class ShortFormPlan:
 class ChunkWork:
     """Decoding state of one <= chunk_length_s piece of audio (one row of a ``generate`` batch)."""
 
-    __slots__ = ("feats", "num_frames", "max_frames", "seek", "segments", "passes", "tag")
+    __slots__ = ("feats", "num_frames", "max_frames", "seek", "segments", "passes", "tag", "forced", "first_pass")
 
     def __init__(self, feats: torch.Tensor, num_frames: Optional[int], tag: Any = None):
+        # SURVEY.md section 8f-3 (opt-in, streaming.py): output tokens of the FIRST seek iteration that are already known - they
+        # are handed to the greedy loop as forced output (batched prefill) and the loop decodes only what follows
+        self.forced: Optional[np.ndarray] = None
+        self.first_pass: Optional[Tuple[np.ndarray, np.ndarray]] = None   # (ids after the prompt, their timestamps) of iteration 1
         self.feats = feats                      # [n_mels, frames] log-mel (device tensor); frames = 2 * T for short-form
         self.num_frames = num_frames            # frames of real audio (attention_mask.sum), None if no mask was given
         self.max_frames = int(feats.shape[-1])  # HF:...:1769 - short-form: the padded feature length, not the audio length
@@ -204,7 +208,15 @@ class Pass:
             raise ValueError("empty pass")
         n_prompt = plan.n_prompt
         prompt = np.tile(np.asarray(plan.init_tokens, dtype=np.int32), (B, 1))
-        out = engine.generate_greedy(prompt, **plan.greedy)
+        n_forced = 0
+        if any(w.forced is not None and w.seek == 0 for w in works):
+            # forced output prefixes (first iteration only): one length for the whole pass (the engine's loop is in lock-step)
+            lens = {len(w.forced) if (w.forced is not None and w.seek == 0) else 0 for w in works}
+            if len(lens) != 1:
+                raise ValueError("a pass takes forced prefixes of ONE length")
+            n_forced = lens.pop()
+            prompt = np.concatenate([prompt, np.stack([np.asarray(w.forced, dtype=np.int32) for w in works])], axis=1)
+        out = engine.generate_greedy(prompt, n_forced=n_forced, **plan.greedy) if n_forced else engine.generate_greedy(prompt, **plan.greedy)
         self._keep.clear()
         seq = torch.from_numpy(np.ascontiguousarray(out["sequences"])).to(torch.long)
         L = int(seq.shape[1])
@@ -234,6 +246,10 @@ class Pass:
                     seek_sequence = seek_sequence[:-num_paddings]
             if seek_sequence.numel() > 0 and seek_sequence[-1] == plan.eos:
                 seek_sequence = seek_sequence[:-1]
+            if w.seek == 0 and w.first_pass is None:
+                n_tok = int(seek_sequence.numel())
+                w.first_pass = (seek_sequence.numpy().copy(),
+                                ts[i, n_prompt : n_prompt + n_tok].numpy().copy() if ts is not None else None)
             time_offset = torch.tensor(w.seek, dtype=torch.long).to(torch.float64) * plan.time_precision / plan.input_stride
             segments, offset = retrieve_segment(seek_sequence, result, ts[i] if ts is not None else [], time_offset,
                                                 plan.timestamp_begin, snf[i], plan, n_prompt)

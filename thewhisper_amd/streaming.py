@@ -36,8 +36,18 @@ class AMDWhisperBackend:
         tokenizer=None,
         revision: str = "main",
         asr_pipeline=None,
+        reuse_committed_prefix: bool = False,
+        reuse_margin_s: float = 1.0,
         **pipeline_kwargs,
     ):
+        """``reuse_committed_prefix`` (never the default): the reference scheduler hands over, every 0.5 s,
+        a rolling buffer most of which the previous call already transcribed (R:...streaming_pipeline.py:770-796 re-decodes all
+        of it).  With the option on, a call whose buffer EXTENDS the previous call's (same ``buffer_start_time``, at least as
+        long, one chunk) hands the previous call's tokens whose word timestamps end at least ``reuse_margin_s`` before the old
+        buffer's end to the greedy loop as forced output - one batched prefill (tw_greedy_opts::n_forced) instead of one decode
+        step each - and decodes only the tail.  The audio those tokens belong to is unchanged, but the encoder is not causal and
+        the log-mel clamp is global, so the forced tokens need not be what a fresh decode would pick: an approximation, whose
+        delta bench.py / tests measure.  ``reuse_stats`` counts calls, reused calls and forced tokens."""
         from .asr_pipeline import ASRPipeline
 
         if torch_dtype is None:
@@ -58,11 +68,20 @@ class AMDWhisperBackend:
             revision=revision,
             **pipeline_kwargs,
         )
+        self.reuse_committed_prefix = bool(reuse_committed_prefix)
+        self.reuse_margin_s = float(reuse_margin_s)
+        self.reuse_stats = {"calls": 0, "reused": 0, "forced_tokens": 0, "decoded_tokens": 0}
+        self._reuse_codec = None      # JobCodec (learned plan), built on the first reuse-enabled call
+        self._last = None             # what the previous call left: start time, samples, first-iteration tokens + timestamps
 
     def _generate_kwargs(self) -> Dict[str, Any]:
         return {"use_cache": True, "num_beams": 1, "do_sample": False, "max_new_tokens": 128, "language": self.language}
 
     def transcribe(self, audio: np.ndarray, buffer_start_time: float, sample_rate: int) -> List[Dict[str, Any]]:
+        if self.reuse_committed_prefix:
+            words = self._transcribe_with_reuse(np.asarray(audio), float(buffer_start_time), int(sample_rate))
+            if words is not None:
+                return words
         result: Dict[str, Any] = self.asr_pipeline(
             audio,
             return_timestamps="word",
@@ -70,6 +89,67 @@ class AMDWhisperBackend:
             chunk_length_s=self.chunk_length_s,
         )
         return self._to_tokens(result, len(audio) / sample_rate, buffer_start_time)
+
+    # -- decoder-side reuse between the ticks of one stream (opt-in) -------------------------------
+    def _forced_prefix(self, n_samples: int, buffer_start_time: float, sample_rate: int) -> Optional[np.ndarray]:
+        """Tokens of the previous call that may be forced in this one, or None.  Eligible: same buffer start, buffer not shorter
+        (the scheduler appended audio; a trimmed buffer starts elsewhere and is decoded afresh).  Kept: the longest prefix whose
+        token timestamps (DTW, seconds from the buffer start) end ``reuse_margin_s`` before the OLD buffer's end - the audio
+        behind them has had its right context for at least that long."""
+        last = self._last
+        if last is None or abs(last["start"] - buffer_start_time) > 1e-6 or n_samples < last["n_samples"] or last["sr"] != sample_rate:
+            return None
+        ids, ts = last["ids"], last["ts"]
+        if ids is None or ts is None or len(ids) == 0:
+            return None
+        limit = last["n_samples"] / sample_rate - self.reuse_margin_s
+        keep = 0
+        for i in range(len(ids)):
+            if ts[i] > limit:
+                break
+            keep = i + 1
+        if keep < 2:
+            return None
+        return np.asarray(ids[:keep], dtype=np.int32)
+
+    def _transcribe_with_reuse(self, audio: np.ndarray, buffer_start_time: float, sample_rate: int):
+        """The call through the restated short-form loop (shortform.py) with a forced prefix on the first seek iteration; None
+        when this backend cannot (no learned plan, a buffer longer than one chunk): the ordinary call then runs."""
+        from . import shortform
+
+        if self._reuse_codec is None:
+            self.reuse_committed_prefix = False           # (the plan is learned from one ORDINARY call of this backend)
+            codec = self.job_codec()
+            if codec is None or not codec.learn():
+                return None                               # not eligible on this pipeline: stays the plain backend
+            self.reuse_committed_prefix = True
+            self._reuse_codec = codec
+        codec = self._reuse_codec
+        self.reuse_stats["calls"] += 1
+        job = codec.open(audio, buffer_start_time, sample_rate)
+        eng = self.asr_pipeline.model.engine
+        if len(job.works) != 1:
+            self._last = None
+            forced = None
+        else:
+            forced = self._forced_prefix(len(audio), buffer_start_time, sample_rate)
+            budget = int(codec.plan.greedy.get("max_new_tokens", 128))
+            if forced is not None and len(forced) >= budget - 1:
+                forced = forced[: max(0, budget - 2)]
+            if forced is not None and len(forced) >= 2:
+                job.works[0].forced = forced
+                self.reuse_stats["reused"] += 1
+                self.reuse_stats["forced_tokens"] += int(len(forced))
+        while not job.done:
+            for w in [w for w in job.works if not w.done]:
+                shortform.run_pass(eng, codec.plan, [w])
+                if w.passes > shortform.MAX_SEEK_PASSES:
+                    raise RuntimeError(f"a chunk needed more than {shortform.MAX_SEEK_PASSES} seek passes")
+        if len(job.works) == 1 and job.works[0].first_pass is not None:
+            ids, ts = job.works[0].first_pass
+            self.reuse_stats["decoded_tokens"] += int(len(ids)) - (int(len(forced)) if forced is not None else 0)
+            self._last = {"start": buffer_start_time, "n_samples": len(audio), "sr": sample_rate, "ids": ids, "ts": ts}
+        return codec.close(job)
 
     def transcribe_many(self, requests, batch_size: Optional[int] = None) -> List[List[Dict[str, Any]]]:
         """Several streams' rolling buffers in ONE pipeline call: [(audio, buffer_start_time, sample_rate), ...].
