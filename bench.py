@@ -460,7 +460,7 @@ def main(argv=None):
     ap.add_argument("--chunk-s", type=int, default=10)
     ap.add_argument("--streams", type=int, default=16, help="concurrent streams per GPU (1..64; 16 = the per-GPU share of BASELINE configs[3])")
     ap.add_argument("--new-tokens", type=int, default=128)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8", "fp8a8", "fp8a16"],
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32", "fp8", "fp8a8", "fp8a16"],
                     help="fp8 = bf16 activations/encoder + MXFP8 decoder projection weights (BASELINE config 5)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -708,7 +708,9 @@ def main(argv=None):
             legs = []
             for label, model, chunk_s, nb, dt_, k in (("configs[1]: large-v3-turbo, 30 s chunk, batch 1, bf16", "large-v3-turbo", 30, 1, "bf16", 5),
                                                         ("configs[4]: large-v3, MXFP8 decoder weights + fp8 cross-K/V, 15 s chunks, word timestamps", "large-v3", 15, B, "fp8", 3),
-                                                        ("configs[4] shape in bf16 (for the fp8 / bf16 ratio)", "large-v3", 15, B, "bf16", 3)):
+                                                        ("configs[4] shape in bf16 (for the fp8 / bf16 ratio)", "large-v3", 15, B, "bf16", 3),
+                                                        ("the headline configuration in float16 (the reference's streaming default dtype; same kernels "
+                                                         "instantiated for _Float16)", "large-v3", args.chunk_s, B, "f16", 3)):
                 try:
                     legs.append(secondary_leg(label, model, chunk_s, nb, dt_, k, args.new_tokens, local, use_graph=not args.no_graph))
                 except Exception as e:  # noqa: BLE001

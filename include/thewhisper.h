@@ -72,7 +72,10 @@ typedef struct tw_config {
                                     (R:thestage_speechkit/nvidia/asr_pipeline.py:15-27). */
   int32_t target_positions;      /* decoder positions, 448 */
   int32_t max_batch;             /* concurrent streams per call: 1..64 (1..16 with TW_BF16_MXFP8) */
-  int32_t dtype;                 /* TW_BF16 (production), TW_F32 (strict-parity mode), TW_BF16_MXFP8 / TW_BF16_W8A16 (fp8 decoder weights) */
+  int32_t dtype;                 /* TW_BF16 (production), TW_F16 (the reference's streaming default dtype,
+                                    R:thestage_speechkit/streaming/streaming_pipeline.py:369-370: same MFMA rate, 10 mantissa bits,
+                                    activations saturate at 65504 as HF clamps its float16 hidden states), TW_F32 (strict-parity
+                                    mode), TW_BF16_MXFP8 / TW_BF16_W8A16 (fp8 decoder weights) */
   int32_t n_align_heads;         /* alignment heads for word timestamps (generation_config.alignment_heads) */
   int32_t align_heads[2 * TW_MAX_ALIGN_HEADS]; /* (layer, head) pairs */
   int32_t device;                /* HIP device ordinal */

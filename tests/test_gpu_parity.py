@@ -65,6 +65,9 @@ ENC_CASES = [
     ("tiny.en", 1500, 1, "f32", 4, 5e-5, {}), ("micro", 100, 1, "f32", 0, 2e-5, {}),
     # chunk lengths whose frame count is no multiple of the 64-key tiles: 1 s (less than one tile), 25 s, 29 s
     ("micro", 50, 2, "f32", 2, 2e-5, {}), ("micro", 1250, 1, "f32", 2, 2e-5, {}), ("micro", 1450, 2, "bf16", 2, 3e-2, {}),
+    # float16 contexts (round 4; the reference's streaming default dtype): 10 mantissa bits, bounds 1/8 of bf16's
+    ("micro", 100, 2, "f16", 2, 4e-3, {}), ("micro", 500, 4, "f16", 2, 4e-3, {}), ("large-v3", 500, 4, "f16", 1, 4e-3, {}),
+    ("micro", 1450, 2, "f16", 2, 4e-3, {}), ("large-v3", 500, 1, "f16", 1, 4e-3, {}),
 ]
 
 
@@ -102,6 +105,9 @@ DEC_CASES = [
     ("micro", 100, 17, "f32", 2, 2e-5), ("micro", 100, 40, "bf16", 2, 3e-2), ("micro", 100, 64, "f32", 1, 2e-5),  # > 16 streams: groups of 16
     ("large-v3", 500, 32, "bf16", 1, 3e-2),
     ("micro", 50, 2, "f32", 2, 2e-5), ("micro", 1250, 2, "f32", 2, 2e-5), ("micro", 1450, 3, "bf16", 2, 3e-2),   # ragged last key tile
+    # float16 contexts
+    ("micro", 100, 16, "f16", 2, 4e-3), ("large-v3", 500, 2, "f16", 1, 4e-3), ("large-v3", 500, 16, "f16", 1, 4e-3),
+    ("micro", 750, 3, "f16", 2, 4e-3), ("micro", 100, 40, "f16", 2, 4e-3), ("micro", 1450, 3, "f16", 2, 4e-3),
 ]
 
 
@@ -123,9 +129,9 @@ def test_decoder_teacher_forced(preset, T, B, dtype, layers, tol):
         ref = ref[:, 0]
         got = eng.decode_step(ids[:, s].tolist()).cpu().numpy()
         assert rel_l2(got, ref) < tol
-        if dtype == "bf16":  # top-1 agreement wherever the oracle's margin is clear
+        if dtype in ("bf16", "f16"):  # top-1 agreement wherever the oracle's margin is clear
             srt = np.sort(ref, axis=-1)
-            clear = (srt[:, -1] - srt[:, -2]) > 0.25
+            clear = (srt[:, -1] - srt[:, -2]) > (0.25 if dtype == "bf16" else 0.03)
             assert np.array_equal(got.argmax(-1)[clear], ref.argmax(-1)[clear])
     eng.close()
 
@@ -382,7 +388,7 @@ def test_greedy_ids_alignment_and_timestamps(preset, T, B, max_new, graph, min_n
 
 FORCED_CASES = [("micro", 100, 1, 60, 37, "f32", True), ("micro", 100, 1, 150, 120, "f32", False), ("micro", 500, 3, 40, 25, "f32", True),
                 ("micro", 100, 16, 30, 9, "f32", True), ("micro", 100, 1, 60, 37, "bf16", True), ("micro", 750, 2, 40, 30, "fp8a16", True),
-                ("micro", 100, 2, 24, 1, "f32", True), ("micro", 100, 5, 90, 70, "bf16", False)]
+                ("micro", 100, 2, 24, 1, "f32", True), ("micro", 100, 5, 90, 70, "bf16", False), ("micro", 500, 3, 40, 25, "f16", True)]
 
 
 @pytest.mark.parametrize("preset,T,B,max_new,n_forced,dtype,graph", FORCED_CASES)
@@ -772,7 +778,7 @@ def test_c_abi_error_behaviour():
         refused(lib.tw_encode(ctx, None, 0, 2, None, 0, sp))
         refused(lib.tw_encode(ctx, mp, 77, 2, None, 0, sp))
         hid = torch.empty((2, 100, dims.d_model), device="cuda")
-        refused(lib.tw_encode(ctx, mp, 0, 2, C.c_void_p(hid.data_ptr()), 2, sp))                          # hidden states as fp16: not offered
+        refused(lib.tw_encode(ctx, mp, 0, 2, C.c_void_p(hid.data_ptr()), 5, sp))                          # hidden states in an unknown element type
         refused(lib.tw_logmel(ctx, None, 32000, None, 2, 32000, mp, 0, sp))
         refused(lib.tw_logmel(ctx, C.c_void_p(mel.data_ptr()), 32000, None, 2, 32001, mp, 0, sp))     # not a whole number of hops
         eng.encode(mel)

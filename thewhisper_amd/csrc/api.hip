@@ -263,8 +263,8 @@ static int create_ctx(const tw_config* cfg, const tw_ctx* share, tw_ctx** out) {
   *out = nullptr;
   if (cfg->heads <= 0 || cfg->d_model != cfg->heads * 64)
     return fail(nullptr, TW_EINVAL, "head_dim must be 64 (d_model=%d heads=%d)", cfg->d_model, cfg->heads);
-  if (cfg->dtype != TW_BF16 && cfg->dtype != TW_F32 && cfg->dtype != TW_BF16_MXFP8 && cfg->dtype != TW_BF16_W8A16)
-    return fail(nullptr, TW_EINVAL, "dtype must be TW_BF16, TW_F32, TW_BF16_MXFP8 or TW_BF16_W8A16");
+  if (cfg->dtype != TW_BF16 && cfg->dtype != TW_F32 && cfg->dtype != TW_F16 && cfg->dtype != TW_BF16_MXFP8 && cfg->dtype != TW_BF16_W8A16)
+    return fail(nullptr, TW_EINVAL, "dtype must be TW_BF16, TW_F16, TW_F32, TW_BF16_MXFP8 or TW_BF16_W8A16");
   const bool cfg_w8 = cfg->dtype == TW_BF16_MXFP8 || cfg->dtype == TW_BF16_W8A16;
   if (cfg_w8 && (cfg->d_model % 128 || cfg->ffn % 128))
     return fail(nullptr, TW_EINVAL, "TW_BF16_MXFP8 / TW_BF16_W8A16 need d_model and ffn to be multiples of 128");
@@ -294,7 +294,7 @@ static int create_ctx(const tw_config* cfg, const tw_ctx* share, tw_ctx** out) {
     if (fa && !strcmp(fa, "bf16")) c->a16 = 1;
   }
   c->dtype = c->w8 ? (int)TW_BF16 : cfg->dtype;
-  c->esz = c->dtype == TW_BF16 ? 2 : 4;
+  c->esz = c->dtype == TW_F32 ? 4 : 2;
   c->d = cfg->d_model; c->H = cfg->heads; c->ffn = cfg->ffn; c->V = cfg->vocab;
   c->T = cfg->source_positions; c->Tp = (c->T + 63) / 64 * 64; c->P = cfg->target_positions;
   c->n_mels = cfg->n_mels; c->C = (cfg->n_mels + 63) / 64 * 64;
@@ -711,7 +711,8 @@ int encode_core(tw_ctx* c, const void* mel, int32_t mel_dtype, int32_t B, int32_
   if (B < 1 || slot0 < 0 || slot0 + B > c->Bmax) return fail(c, TW_EINVAL, "tw_encode: slots [%d, %d) outside [0,%d)", slot0, slot0 + B, c->Bmax);
   if (slot0 > c->encoded_B) return fail(c, TW_ESTATE, "tw_encode_at: slot0=%d but only %d slots are filled", slot0, c->encoded_B);
   if (mel_dtype != TW_F32 && mel_dtype != TW_BF16 && mel_dtype != TW_F16) return fail(c, TW_EINVAL, "tw_encode: mel_dtype %d is not TW_F32 / TW_BF16 / TW_F16", mel_dtype);
-  if (out_hidden && out_dtype != TW_F32 && out_dtype != TW_BF16) return fail(c, TW_EINVAL, "tw_encode: out_dtype %d is not TW_F32 / TW_BF16", out_dtype);
+  if (out_hidden && out_dtype != TW_F32 && out_dtype != TW_BF16 && out_dtype != TW_F16)
+    return fail(c, TW_EINVAL, "tw_encode: out_dtype %d is not TW_F32 / TW_BF16 / TW_F16", out_dtype);
   hipStream_t st = pick_stream(c, stream);
   const int d = c->d, T = c->T, C = c->C, H = c->H, F = c->ffn, dt = c->dtype;
   const size_t e = c->esz;

@@ -27,6 +27,7 @@ template <> struct AttnTraits<bf16_t> {
   static constexpr int NSLOT = 8;    // 16-B slots per 64-dim row
   static constexpr int KK = 2;       // MFMA k-steps over head_dim
 };
+template <> struct AttnTraits<f16_t> : AttnTraits<bf16_t> {};
 template <> struct AttnTraits<float> {
   static constexpr int E = 4;
   static constexpr int NSLOT = 16;
@@ -34,11 +35,8 @@ template <> struct AttnTraits<float> {
 };
 
 template <typename T>
-__device__ __forceinline__ f32x4_t mfma16(const u32x4_t& a, const u32x4_t& b, f32x4_t acc);
-template <>
-__device__ __forceinline__ f32x4_t mfma16<bf16_t>(const u32x4_t& a, const u32x4_t& b, f32x4_t acc) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc,
-                                                 0, 0, 0);
+__device__ __forceinline__ f32x4_t mfma16(const u32x4_t& a, const u32x4_t& b, f32x4_t acc) {
+  return tw_mfma32<T>(a, b, acc);   // bf16 / f16
 }
 template <>
 __device__ __forceinline__ f32x4_t mfma16<float>(const u32x4_t& a, const u32x4_t& b, f32x4_t acc) {
@@ -61,12 +59,6 @@ __device__ __forceinline__ float attn_exp(float x) {
   else return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
 }
 
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  bf16x2_t v;
-  v[0] = (bf16_t)lo;
-  v[1] = (bf16_t)hi;
-  return __builtin_bit_cast(unsigned, v);
-}
 
 // Workgroup id -> (stream*head, query block).  All query blocks of one head read the same K / V^T (128 KB at T = 500); consecutive
 // workgroup ids go to the 8 XCDs round-robin (MI355X_MICROARCH.md), so with the query block as the fastest grid index every
@@ -252,10 +244,10 @@ __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const T* __restrict__ 
         u32x4_t pf[QT];
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-          pf[t][0] = pack_bf16x2(s[t][2 * pr][0], s[t][2 * pr][1]);
-          pf[t][1] = pack_bf16x2(s[t][2 * pr][2], s[t][2 * pr][3]);
-          pf[t][2] = pack_bf16x2(s[t][2 * pr + 1][0], s[t][2 * pr + 1][1]);
-          pf[t][3] = pack_bf16x2(s[t][2 * pr + 1][2], s[t][2 * pr + 1][3]);
+          pf[t][0] = tw_pack2_inrange<T>(s[t][2 * pr][0], s[t][2 * pr][1]);
+          pf[t][1] = tw_pack2_inrange<T>(s[t][2 * pr][2], s[t][2 * pr][3]);
+          pf[t][2] = tw_pack2_inrange<T>(s[t][2 * pr + 1][0], s[t][2 * pr + 1][1]);
+          pf[t][3] = tw_pack2_inrange<T>(s[t][2 * pr + 1][2], s[t][2 * pr + 1][3]);
         }
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
@@ -300,8 +292,8 @@ __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const T* __restrict__ 
       T* p = orow + dt * 16 + kb * 4;
       if constexpr (sizeof(T) == 2) {
         u32x2_t w;
-        w[0] = pack_bf16x2(o[t][dt][0] * inv, o[t][dt][1] * inv);
-        w[1] = pack_bf16x2(o[t][dt][2] * inv, o[t][dt][3] * inv);
+        w[0] = tw_pack2_inrange<T>(o[t][dt][0] * inv, o[t][dt][1] * inv);
+        w[1] = tw_pack2_inrange<T>(o[t][dt][2] * inv, o[t][dt][3] * inv);
         *reinterpret_cast<u32x2_t*>(p) = w;
       } else {
         *reinterpret_cast<f32x4_t*>(p) = f32x4_t{o[t][dt][0] * inv, o[t][dt][1] * inv, o[t][dt][2] * inv, o[t][dt][3] * inv};
@@ -331,6 +323,13 @@ hipError_t launch_enc_attention(int dtype, const void* q, const void* k, const v
     else
       hipLaunchKernelGGL((enc_attn_kernel<bf16_t, 1>), grid_for((T + 63) / 64), dim3(256), 0, st, (const bf16_t*)q,
                          (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, H, T, Tp, nbh, (T + 63) / 64, xcd);
+  } else if (dtype == 2) {
+    if (big)
+      hipLaunchKernelGGL((enc_attn_kernel<f16_t, 2>), grid_for((T + 127) / 128), dim3(256), 0, st, (const f16_t*)q,
+                         (const f16_t*)k, (const f16_t*)vt, (f16_t*)out, H, T, Tp, nbh, (T + 127) / 128, xcd);
+    else
+      hipLaunchKernelGGL((enc_attn_kernel<f16_t, 1>), grid_for((T + 63) / 64), dim3(256), 0, st, (const f16_t*)q,
+                         (const f16_t*)k, (const f16_t*)vt, (f16_t*)out, H, T, Tp, nbh, (T + 63) / 64, xcd);
   } else {
     hipLaunchKernelGGL((enc_attn_kernel<float, 1>), grid_for((T + 63) / 64), dim3(256), 0, st, (const float*)q,
                        (const float*)k, (const float*)vt, (float*)out, H, T, Tp, nbh, (T + 63) / 64, xcd);

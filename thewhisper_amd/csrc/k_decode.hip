@@ -59,6 +59,12 @@ template <> __device__ __forceinline__ u32x4_t pack16<bf16_t>(const float* in) {
   for (int i = 0; i < 8; ++i) f[i] = (bf16_t)in[i];
   return __builtin_bit_cast(u32x4_t, f);
 }
+template <> __device__ __forceinline__ u32x4_t pack16<f16_t>(const float* in) {   // probabilities: in range, no saturation needed
+  f16x8_t f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] = (f16_t)in[i];
+  return __builtin_bit_cast(u32x4_t, f);
+}
 
 // Folded pre-LayerNorm.  For y = LN(x) . W^T + bias with LN(x) = (x - mean) * rstd * g + beta:
 //     y[n] = rstd * ( x . W'[n]  -  mean * gW[n] )  +  cb[n],
@@ -87,7 +93,11 @@ template <typename T>
 __device__ __forceinline__ f32x4_t sk_mfma(const u32x4_t& w, const u32x4_t& x, f32x4_t acc);
 template <>
 __device__ __forceinline__ f32x4_t sk_mfma<bf16_t>(const u32x4_t& w, const u32x4_t& x, f32x4_t acc) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, x), acc, 0, 0, 0);
+  return tw_mfma32<bf16_t>(w, x, acc);
+}
+template <>
+__device__ __forceinline__ f32x4_t sk_mfma<f16_t>(const u32x4_t& w, const u32x4_t& x, f32x4_t acc) {
+  return tw_mfma32<f16_t>(w, x, acc);
 }
 template <>
 __device__ __forceinline__ f32x4_t sk_mfma<float>(const u32x4_t& w, const u32x4_t& x, f32x4_t acc) {
@@ -199,6 +209,20 @@ template <> __device__ __forceinline__ void sk_stats<bf16_t>(const u32x4_t& v, f
   s = __builtin_amdgcn_fdot2_f32_bf16(p3, one, s, false);
   ss = __builtin_amdgcn_fdot2_f32_bf16(p3, p3, ss, false);
 }
+template <> __device__ __forceinline__ void sk_stats<f16_t>(const u32x4_t& v, float& s, float& ss) {
+  const f16x8_t a = __builtin_bit_cast(f16x8_t, v);
+  const f16x2_t one = {(f16_t)1.0f, (f16_t)1.0f};
+  const f16x2_t p0 = __builtin_shufflevector(a, a, 0, 1), p1 = __builtin_shufflevector(a, a, 2, 3);
+  const f16x2_t p2 = __builtin_shufflevector(a, a, 4, 5), p3 = __builtin_shufflevector(a, a, 6, 7);
+  s = tw_dot2<f16_t>(p0, one, s);
+  ss = tw_dot2<f16_t>(p0, p0, ss);
+  s = tw_dot2<f16_t>(p1, one, s);
+  ss = tw_dot2<f16_t>(p1, p1, ss);
+  s = tw_dot2<f16_t>(p2, one, s);
+  ss = tw_dot2<f16_t>(p2, p2, ss);
+  s = tw_dot2<f16_t>(p3, one, s);
+  ss = tw_dot2<f16_t>(p3, p3, ss);
+}
 template <> __device__ __forceinline__ void sk_stats<float>(const u32x4_t& v, float& s, float& ss) {
   const f32x4_t a = __builtin_bit_cast(f32x4_t, v);
 #pragma unroll
@@ -249,7 +273,7 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
   // delivers the leading kernel-argument dwords in SGPRs with the wave (kernarg preload, build.py: -amdgpu-kernarg-preload-count),
   // so the activation and weight requests leave without waiting for a scalar load; everything else (epilogue operands, outputs)
   // stays in the GemvArgs block behind them - a struct is never preloaded - and arrives while those requests are in flight.
-  static_assert(!W8 || sizeof(T) == 2, "MXFP8 weights go with bf16 activations");
+  static_assert(!W8 || ElemTraits<T>::kCode == 1, "MXFP8 weights go with bf16 activations");
   static_assert(TR == 16 || (!MULTI && EPI != SK_KV && EPI != SK_F32), "narrow tiles: plain / residual / GELU projections only");
   static_assert(!W8 || TR == 16 || TR == 8, "MXFP8 weights: 16- or 8-row tiles");
   static_assert(!A16 || W8, "A16 is a flavour of the MXFP8-weight kernel");
@@ -529,7 +553,7 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
         if (EPI == SK_GELU) v = gelu_exact<T>(v);
         if (EPI == SK_RES) v += e_res[g];
         if (EPI == SK_RES && u_p) {   // (kernel-uniform) LayerNorm statistics of the residual rows of this tile, as stored
-          const float xs = (tile < n_tiles && n < nsplit && jg < B && i < TR) ? (float)(T)v : 0.f;
+          const float xs = (tile < n_tiles && n < nsplit && jg < B && i < TR) ? (float)tw_cast<T>(v) : 0.f;
           const float s1 = tw_row16_sum(xs), s2 = tw_row16_sum(xs * xs);   // the 16 threads of one stream are one DPP row
           if (i == 0 && jg < B && tile < n_tiles && tile * TR < nsplit) {
             float* sp = stats_p + ((long long)jg * (nsplit / TR) + tile) * 2;
@@ -551,15 +575,15 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
               const long long hb = (long long)srow * cache_bstride + (long long)hh * (cache_bstride / (d_model >> 6));  // (stream, head)
               T* dst = seg == 0 ? y + (long long)jg * ldy + n
                                 : (seg == 1 ? kcache + hb + tw_kf_index<T>(prow, cc) : vcache + hb + tw_vtf_index<T>(prow, cc));
-              *dst = (T)v;
+              *dst = tw_cast<T>(v);
             }
           } else if (EPI == SK_STORE) {
-            y[(long long)jg * ldy + n] = (T)v;  // row-major [B][ldy] (the attention kernels' query operand)
+            y[(long long)jg * ldy + n] = tw_cast<T>(v);  // row-major [B][ldy] (the attention kernels' query operand)
           } else if (EPI == SK_RES) {
             if (n >= nsplit) u_p[(long long)jg * (N - nsplit) + (n - nsplit)] = v;   // composed half: u += attn . Wc^T
-            else y[(long long)g * 16 * nsplit + tw_xt_index<T>(j, n)] = (T)v;       // residual stream, fragment-major
+            else y[(long long)g * 16 * nsplit + tw_xt_index<T>(j, n)] = tw_cast<T>(v);       // residual stream, fragment-major
           } else {
-            y[(long long)g * 16 * N + tw_xt_index<T>(j, n)] = (T)v;    // feeds the next projection: fragment-major
+            y[(long long)g * 16 * N + tw_xt_index<T>(j, n)] = tw_cast<T>(v);    // feeds the next projection: fragment-major
           }
         }
       }
@@ -731,7 +755,7 @@ __device__ __forceinline__ void fq_finish(const QRaw<T>& r, const FusedQ& fq, in
   const float inv_k = __builtin_amdgcn_rcpf((float)fq.d);
   const float mean = s * inv_k;
   const float rstd = __frsqrt_rn(fmaxf(ss * inv_k - mean * mean, 0.f) + 1e-5f);
-  qrow[lane] = (T)(rstd * (r.u - mean * r.gw) + r.cb);
+  qrow[lane] = tw_cast<T>(rstd * (r.u - mean * r.gw) + r.cb);
 }
 
 // SINGLE: n_bound <= NW*64, so every K and V^T fragment of the head is requested before anything is waited for
@@ -1451,7 +1475,7 @@ static hipError_t skinny_launch(const GemvArgs& a, hipStream_t st) {
   static const int nw_big = env_int("TW_SK_NW_BIGK", 16);  // wavefronts per tile when K is long (fc2: K = 5120)
   const bool big = a.K >= 4096 && nw_big == 16 && !a.ln_gw && !a.y_f32 && !a.kcache && !a.gelu && a.B <= 16;
   if (a.wscale) {
-    if (sizeof(T) != 2) return hipErrorInvalidValue;
+    if (ElemTraits<T>::kCode != 1) return hipErrorInvalidValue;
     if (a.tr == 8) return big ? skinny_launch_w8<16, 8>(a, st) : skinny_launch_w8<8, 8>(a, st);
     if (a.tr != 0 && a.tr != 16) return hipErrorInvalidValue;
     return big ? skinny_launch_w8<16, 16>(a, st) : skinny_launch_w8<8, 16>(a, st);
@@ -1480,7 +1504,7 @@ static hipError_t gemv_b(const GemvArgs& a0, hipStream_t st) {
 }
 
 hipError_t launch_gemv(int dtype, const GemvArgs& a, hipStream_t st) {
-  return dtype == 1 ? gemv_b<bf16_t>(a, st) : gemv_b<float>(a, st);
+  return dtype == 1 ? gemv_b<bf16_t>(a, st) : (dtype == 2 ? gemv_b<f16_t>(a, st) : gemv_b<float>(a, st));
 }
 
 hipError_t launch_dec_self_attn(int dtype, const void* q, const void* kc, const void* vc, int rows, void* out, int B, int H,
@@ -1494,7 +1518,7 @@ hipError_t launch_dec_self_attn(int dtype, const void* q, const void* kc, const 
                                               (const TT*)kc, (const TT*)vc, rows, H, kb, (TT*)out, stt, rows_streams)
 #define SA_PICK(TT) do { if (nw == 1) SA_GO(TT, true, 1); else if (nw == 2) SA_GO(TT, true, 2); else if (single) SA_GO(TT, true, 4); \
                          else SA_GO(TT, false, 4); } while (0)
-  if (dtype == 1) SA_PICK(bf16_t); else SA_PICK(float);
+  if (dtype == 1) SA_PICK(bf16_t); else if (dtype == 2) SA_PICK(f16_t); else SA_PICK(float);
 #undef SA_PICK
 #undef SA_GO
   return hipGetLastError();
@@ -1530,7 +1554,7 @@ hipError_t launch_dec_cross_attn(int dtype, const void* q, const FusedQ& fq, con
                                              (const TT*)cv, H, Tp, T, (const TT*)q, (TT*)out, align_slot_for_head, align, Ha, P, stt, fq, rows_streams)
 #define CA_PICK(TT) do { if (single) { if (f) CA_GO(TT, true, true); else CA_GO(TT, true, false); }                                  \
                          else { if (f) CA_GO(TT, false, true); else CA_GO(TT, false, false); } } while (0)
-  if (dtype == 1) CA_PICK(bf16_t); else CA_PICK(float);
+  if (dtype == 1) CA_PICK(bf16_t); else if (dtype == 2) CA_PICK(f16_t); else CA_PICK(float);
 #undef CA_PICK
 #undef CA_GO
   return hipGetLastError();
@@ -1564,11 +1588,11 @@ hipError_t launch_advance(DecState* stt, int n, hipStream_t st) {
 }
 
 hipError_t launch_tile_weights(int dtype, const void* src, void* dst, int N, int K, int tr, hipStream_t st) {
-  const int E = dtype == 1 ? 8 : 4;
+  const int E = dtype == 0 ? 4 : 8;
   if (K % (4 * E) != 0 || (tr != 16 && tr != 8 && tr != 4) || N % tr != 0 && tr != 16) return hipErrorInvalidValue;
   const long long total = (long long)((N + tr - 1) / tr) * (K / E / 4) * 4 * tr;
   dim3 grid((unsigned)((total + 255) / 256));
-  if (dtype == 1) hipLaunchKernelGGL(tile_weights_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, N, K, tr);
+  if (dtype != 0) hipLaunchKernelGGL(tile_weights_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, N, K, tr);   // a pure copy: bf16 and f16 alike
   else hipLaunchKernelGGL(tile_weights_kernel<float>, grid, dim3(256), 0, st, (const float*)src, (float*)dst, N, K, tr);
   return hipGetLastError();
 }
@@ -1584,23 +1608,14 @@ hipError_t launch_quant_mx8(const void* src_bf16, void* dst_fp8, void* dst_scale
 hipError_t launch_compose(int dtype, const void* A, const void* Bm, const void* bvec, void* out, float* c0, int N, int J, int K,
                           hipStream_t st) {
   const dim3 grid((K + 15) / 16, (N + 15) / 16);
-  if (dtype == 1)
-    hipLaunchKernelGGL(compose_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)A, (const bf16_t*)Bm, (const bf16_t*)bvec,
-                       (bf16_t*)out, c0, N, J, K);
-  else
-    hipLaunchKernelGGL(compose_kernel<float>, grid, dim3(256), 0, st, (const float*)A, (const float*)Bm, (const float*)bvec,
-                       (float*)out, c0, N, J, K);
+  TW_DISPATCH3(dtype, T, hipLaunchKernelGGL(compose_kernel<T>, grid, dim3(256), 0, st, (const T*)A, (const T*)Bm, (const T*)bvec, (T*)out, c0, N, J, K));
   return hipGetLastError();
 }
 
 hipError_t launch_fold_ln(int dtype, void* W, const void* Wsrc, const void* g, const void* beta, const void* bias, float* gw,
                           float* cb, int N, int K, hipStream_t st) {
   dim3 grid((N + 3) / 4);
-  if (dtype == 1)
-    hipLaunchKernelGGL(fold_ln_kernel<bf16_t>, grid, dim3(256), 0, st, (bf16_t*)W, (const bf16_t*)Wsrc, (const bf16_t*)g,
-                       (const bf16_t*)beta, (const bf16_t*)bias, gw, cb, N, K);
-  else
-    hipLaunchKernelGGL(fold_ln_kernel<float>, grid, dim3(256), 0, st, (float*)W, (const float*)Wsrc, (const float*)g,
-                       (const float*)beta, (const float*)bias, gw, cb, N, K);
+  TW_DISPATCH3(dtype, T, hipLaunchKernelGGL(fold_ln_kernel<T>, grid, dim3(256), 0, st, (T*)W, (const T*)Wsrc, (const T*)g, (const T*)beta,
+                                             (const T*)bias, gw, cb, N, K));
   return hipGetLastError();
 }

@@ -105,13 +105,19 @@ template <> struct Vec4<bf16_t> {
   __device__ bf16_t elem(int i) const { return e[i]; }
 };
 
-template <typename T>
-__device__ __forceinline__ f32x4_t mfma_step(const u32x4_t& wfrag, const u32x4_t& afrag, f32x4_t acc);
+template <> struct Vec4<f16_t> {
+  f16_t e[4];
+  __device__ void load(const f16_t* p) { *reinterpret_cast<uint2*>(e) = *reinterpret_cast<const uint2*>(p); }
+  __device__ void store(f16_t* p) const { *reinterpret_cast<uint2*>(p) = *reinterpret_cast<const uint2*>(e); }
+  __device__ float get(int i) const { return (float)e[i]; }
+  // saturating: HF clamps its float16 hidden states to the largest finite value (HF:models/whisper/modeling_whisper.py:409-411)
+  __device__ void set(int i, float f) { e[i] = (f16_t)fminf(fmaxf(f, -65504.f), 65504.f); }
+  __device__ f16_t elem(int i) const { return e[i]; }
+};
 
-template <>
-__device__ __forceinline__ f32x4_t mfma_step<bf16_t>(const u32x4_t& wfrag, const u32x4_t& afrag, f32x4_t acc) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wfrag),
-                                                 __builtin_bit_cast(bf16x8_t, afrag), acc, 0, 0, 0);
+template <typename T>
+__device__ __forceinline__ f32x4_t mfma_step(const u32x4_t& wfrag, const u32x4_t& afrag, f32x4_t acc) {
+  return tw_mfma32<T>(wfrag, afrag, acc);   // bf16 / f16
 }
 template <>
 __device__ __forceinline__ f32x4_t mfma_step<float>(const u32x4_t& wfrag, const u32x4_t& afrag, f32x4_t acc) {
@@ -232,7 +238,7 @@ template <typename T, int NT, int MT>
 __device__ __forceinline__ void gemm_epilogue_kv8(const f32x4_t (&acc)[NT][MT], int m_base, int n_base, int M, int N,
                                                   const GemmEpilogue& ep, int fr, int fq) {
   static_assert(NT == 4, "one 64-column head per wavefront");
-  if constexpr (sizeof(T) == 2) {
+  if constexpr (ElemTraits<T>::kCode == 1) {   // fp8 cross K / V caches exist in bf16 contexts only
     const T* bias = reinterpret_cast<const T*>(ep.bias);
     const int dmodel = ep.H * 64;
     if (n_base >= N) return;
@@ -605,7 +611,7 @@ static hipError_t gemm_dispatch(const void* A, RowMap amap, const void* W, int M
   const long long b128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
   int cfg;
   if (ep.mode == EPI_KV_CROSS8) {   // fp8 cross-K/V epilogue: one head per wavefront, i.e. kernel 2 whatever the shape
-    if (sizeof(T) != 2 || N % 64 != 0) return hipErrorInvalidValue;
+    if (ElemTraits<T>::kCode != 1 || N % 64 != 0) return hipErrorInvalidValue;
     return gemm_wreg_go<T, 128, 4, 3>(A, amap, W, M, N, K, ep, st);
   }
   if (forced >= 0) cfg = forced;
@@ -651,5 +657,6 @@ static hipError_t gemm_dispatch(const void* A, RowMap amap, const void* W, int M
 hipError_t launch_gemm(int dtype, const void* A, RowMap amap, const void* W, int M, int N, int K,
                        const GemmEpilogue& ep, hipStream_t st) {
   if (dtype == 1) return gemm_dispatch<bf16_t>(A, amap, W, M, N, K, ep, st);
+  if (dtype == 2) return gemm_dispatch<f16_t>(A, amap, W, M, N, K, ep, st);
   return gemm_dispatch<float>(A, amap, W, M, N, K, ep, st);
 }

@@ -152,6 +152,8 @@ hipError_t launch_logmel(const float* pcm, long long pcm_stride, const int* n_va
   dim3 g2((unsigned)min((per_clip + 255) / 256, (long long)1024), B);
   if (out_dtype == 1)
     hipLaunchKernelGGL(logmel_finalize_kernel<bf16_t>, g2, dim3(256), 0, st, logspec_ws, max_ws, (bf16_t*)out, per_clip);
+  else if (out_dtype == 2)
+    hipLaunchKernelGGL(logmel_finalize_kernel<f16_t>, g2, dim3(256), 0, st, logspec_ws, max_ws, (f16_t*)out, per_clip);
   else if (out_dtype == 0)
     hipLaunchKernelGGL(logmel_finalize_kernel<float>, g2, dim3(256), 0, st, logspec_ws, max_ws, (float*)out, per_clip);
   else

@@ -18,6 +18,11 @@ template <> __device__ __forceinline__ void load16<bf16_t>(const bf16_t* p, floa
 #pragma unroll
   for (int i = 0; i < 8; ++i) out[i] = (float)v[i];
 }
+template <> __device__ __forceinline__ void load16<f16_t>(const f16_t* p, float* out) {
+  const f16x8_t v = *reinterpret_cast<const f16x8_t*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = (float)v[i];
+}
 template <typename T> __device__ __forceinline__ void store16(T* p, const float* in);
 template <> __device__ __forceinline__ void store16<float>(float* p, const float* in) {
   *reinterpret_cast<f32x4_t*>(p) = f32x4_t{in[0], in[1], in[2], in[3]};
@@ -27,6 +32,12 @@ template <> __device__ __forceinline__ void store16<bf16_t>(bf16_t* p, const flo
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = (bf16_t)in[i];
   *reinterpret_cast<bf16x8_t*>(p) = v;
+}
+template <> __device__ __forceinline__ void store16<f16_t>(f16_t* p, const float* in) {
+  u32x4_t v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = tw_pack2<f16_t>(in[2 * i], in[2 * i + 1]);   // saturating
+  *reinterpret_cast<u32x4_t*>(p) = v;
 }
 
 // One wave per row; the row lives in registers between the mean and variance passes (two-pass
@@ -167,43 +178,30 @@ hipError_t launch_layernorm(int dtype, const void* x, const void* g, const void*
                             hipStream_t st) {
   if (rows <= 0) return hipSuccess;
   dim3 grid((rows + 3) / 4);
-  if (dtype == 1) {
-    if (d % 8 != 0 || d > 64 * 5 * 8) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)g,
-                       (const bf16_t*)b, (bf16_t*)y, rows, d);
-  } else {
-    if (d % 4 != 0 || d > 64 * 5 * 4) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(layernorm_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)g,
-                       (const float*)b, (float*)y, rows, d);
-  }
+  const int E = dtype == 0 ? 4 : 8;
+  if (d % E != 0 || d > 64 * 5 * E) return hipErrorInvalidValue;
+  TW_DISPATCH3(dtype, T, hipLaunchKernelGGL(layernorm_kernel<T>, grid, dim3(256), 0, st, (const T*)x, (const T*)g, (const T*)b, (T*)y, rows, d));
   return hipGetLastError();
 }
 
+// two-type kernels: destination = a context element type, source = a caller element type (0 f32, 1 bf16, 2 f16)
+#define TW_DISPATCH_DS(dd, sd, TD, TS, ...) TW_DISPATCH3(dd, TD, TW_DISPATCH3(sd, TS, __VA_ARGS__))
+
 hipError_t launch_mel_transpose(int dd, int sd, const void* mel, void* melT, int B, int n_mels, int F, int C,
                                 hipStream_t st) {
+  if (dd < 0 || dd > 2 || sd < 0 || sd > 2) return hipErrorInvalidValue;
   dim3 grid((F + 31) / 32, (C + 31) / 32, B);
-  if (dd == 1 && sd == 1) hipLaunchKernelGGL((mel_transpose_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)mel, (bf16_t*)melT, B, n_mels, F, C);
-  else if (dd == 1 && sd == 0) hipLaunchKernelGGL((mel_transpose_kernel<bf16_t, float>), grid, dim3(256), 0, st, (const float*)mel, (bf16_t*)melT, B, n_mels, F, C);
-  else if (dd == 0 && sd == 1) hipLaunchKernelGGL((mel_transpose_kernel<float, bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)mel, (float*)melT, B, n_mels, F, C);
-  else if (dd == 0 && sd == 0) hipLaunchKernelGGL((mel_transpose_kernel<float, float>), grid, dim3(256), 0, st, (const float*)mel, (float*)melT, B, n_mels, F, C);
-  else if (dd == 1 && sd == 2) hipLaunchKernelGGL((mel_transpose_kernel<bf16_t, _Float16>), grid, dim3(256), 0, st, (const _Float16*)mel, (bf16_t*)melT, B, n_mels, F, C);
-  else if (dd == 0 && sd == 2) hipLaunchKernelGGL((mel_transpose_kernel<float, _Float16>), grid, dim3(256), 0, st, (const _Float16*)mel, (float*)melT, B, n_mels, F, C);
-  else return hipErrorInvalidValue;
+  TW_DISPATCH_DS(dd, sd, TD, TS, hipLaunchKernelGGL((mel_transpose_kernel<TD, TS>), grid, dim3(256), 0, st, (const TS*)mel, (TD*)melT, B, n_mels, F, C));
   return hipGetLastError();
 }
 
 hipError_t launch_convert(int dd, int sd, const void* src, void* dst, long long n, float scale, hipStream_t st) {
   if (n <= 0) return hipSuccess;
+  if (dd < 0 || dd > 2 || sd < 0 || sd > 2) return hipErrorInvalidValue;
   long long blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   dim3 grid((unsigned)blocks);
-  if (dd == 1 && sd == 1) hipLaunchKernelGGL((convert_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, n, scale);
-  else if (dd == 1 && sd == 0) hipLaunchKernelGGL((convert_kernel<bf16_t, float>), grid, dim3(256), 0, st, (const float*)src, (bf16_t*)dst, n, scale);
-  else if (dd == 1 && sd == 2) hipLaunchKernelGGL((convert_kernel<bf16_t, _Float16>), grid, dim3(256), 0, st, (const _Float16*)src, (bf16_t*)dst, n, scale);
-  else if (dd == 0 && sd == 1) hipLaunchKernelGGL((convert_kernel<float, bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)src, (float*)dst, n, scale);
-  else if (dd == 0 && sd == 0) hipLaunchKernelGGL((convert_kernel<float, float>), grid, dim3(256), 0, st, (const float*)src, (float*)dst, n, scale);
-  else if (dd == 0 && sd == 2) hipLaunchKernelGGL((convert_kernel<float, _Float16>), grid, dim3(256), 0, st, (const _Float16*)src, (float*)dst, n, scale);
-  else return hipErrorInvalidValue;
+  TW_DISPATCH_DS(dd, sd, TD, TS, hipLaunchKernelGGL((convert_kernel<TD, TS>), grid, dim3(256), 0, st, (const TS*)src, (TD*)dst, n, scale));
   return hipGetLastError();
 }
 
@@ -214,31 +212,24 @@ hipError_t launch_fill_zero(void* dst, long long bytes, hipStream_t st) {
 
 hipError_t launch_conv_weight_reorder(int dd, int sd, const void* src, void* dst, int co, int ci, int C,
                                       hipStream_t st) {
+  if (dd < 0 || dd > 2 || sd < 0 || sd > 2) return hipErrorInvalidValue;
   const long long n = (long long)co * 3 * C;
   dim3 grid((unsigned)((n + 255) / 256));
-  if (dd == 1 && sd == 1) hipLaunchKernelGGL((conv_weight_reorder_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, co, ci, C);
-  else if (dd == 1 && sd == 0) hipLaunchKernelGGL((conv_weight_reorder_kernel<bf16_t, float>), grid, dim3(256), 0, st, (const float*)src, (bf16_t*)dst, co, ci, C);
-  else if (dd == 1 && sd == 2) hipLaunchKernelGGL((conv_weight_reorder_kernel<bf16_t, _Float16>), grid, dim3(256), 0, st, (const _Float16*)src, (bf16_t*)dst, co, ci, C);
-  else if (dd == 0 && sd == 1) hipLaunchKernelGGL((conv_weight_reorder_kernel<float, bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)src, (float*)dst, co, ci, C);
-  else if (dd == 0 && sd == 0) hipLaunchKernelGGL((conv_weight_reorder_kernel<float, float>), grid, dim3(256), 0, st, (const float*)src, (float*)dst, co, ci, C);
-  else if (dd == 0 && sd == 2) hipLaunchKernelGGL((conv_weight_reorder_kernel<float, _Float16>), grid, dim3(256), 0, st, (const _Float16*)src, (float*)dst, co, ci, C);
-  else return hipErrorInvalidValue;
+  TW_DISPATCH_DS(dd, sd, TD, TS, hipLaunchKernelGGL((conv_weight_reorder_kernel<TD, TS>), grid, dim3(256), 0, st, (const TS*)src, (TD*)dst, co, ci, C));
   return hipGetLastError();
 }
 
 hipError_t launch_interp_positions(int dd, int sd, const void* src, void* dst, int n_old, int n_new, int d,
                                    hipStream_t st) {
+  if (sd != 0 || dd < 0 || dd > 2) return hipErrorInvalidValue;
   const long long n = (long long)n_new * d;
   dim3 grid((unsigned)((n + 255) / 256));
-  if (dd == 1 && sd == 0) hipLaunchKernelGGL((interp_positions_kernel<bf16_t, float>), grid, dim3(256), 0, st, (const float*)src, (bf16_t*)dst, n_old, n_new, d);
-  else if (dd == 0 && sd == 0) hipLaunchKernelGGL((interp_positions_kernel<float, float>), grid, dim3(256), 0, st, (const float*)src, (float*)dst, n_old, n_new, d);
-  else return hipErrorInvalidValue;
+  TW_DISPATCH3(dd, TD, hipLaunchKernelGGL((interp_positions_kernel<TD, float>), grid, dim3(256), 0, st, (const float*)src, (TD*)dst, n_old, n_new, d));
   return hipGetLastError();
 }
 
 hipError_t launch_embed(int dtype, const int* ids, const DecState* stt, const void* tok, const void* pos, void* x,
                         int B, int d, int rows_streams, hipStream_t st) {
-  if (dtype == 1) hipLaunchKernelGGL(embed_kernel<bf16_t>, dim3(B), dim3(256), 0, st, ids, stt, (const bf16_t*)tok, (const bf16_t*)pos, (bf16_t*)x, B, d, rows_streams);
-  else hipLaunchKernelGGL(embed_kernel<float>, dim3(B), dim3(256), 0, st, ids, stt, (const float*)tok, (const float*)pos, (float*)x, B, d, rows_streams);
+  TW_DISPATCH3(dtype, T, hipLaunchKernelGGL(embed_kernel<T>, dim3(B), dim3(256), 0, st, ids, stt, (const T*)tok, (const T*)pos, (T*)x, B, d, rows_streams));
   return hipGetLastError();
 }

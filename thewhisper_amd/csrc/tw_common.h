@@ -7,6 +7,11 @@
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// float16 contexts (TW_F16, round 4): the reference's streaming default dtype (R:thestage_speechkit/streaming/streaming_pipeline.py:369-370).
+// Same 16-bit containers, same MFMA rate (v_mfma_f32_16x16x32_f16), 10 mantissa bits instead of 7.
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;  // a 16-B register quad (native vector: stays in VGPRs)
@@ -47,6 +52,56 @@ __device__ __forceinline__ float tw_wave_max(float v) { return tw_xor32_max(tw_x
 template <typename T> struct ElemTraits;
 template <> struct ElemTraits<float> { static constexpr int kPer16B = 4; static constexpr int kCode = 0; };
 template <> struct ElemTraits<bf16_t> { static constexpr int kPer16B = 8; static constexpr int kCode = 1; };
+template <> struct ElemTraits<f16_t> { static constexpr int kPer16B = 8; static constexpr int kCode = 2; };
+
+// ---- the 16-bit element types share everything but three instructions: the MFMA, the float -> T pair conversion, the 2-way dot ----
+template <typename T> struct Pair16;
+template <> struct Pair16<bf16_t> { typedef bf16x2_t x2; typedef bf16x8_t x8; };
+template <> struct Pair16<f16_t> { typedef f16x2_t x2; typedef f16x8_t x8; };
+// acc += A(16 x 32) . B(32 x 16) on 16-B operand fragments of T
+template <typename T> __device__ __forceinline__ f32x4_t tw_mfma32(const u32x4_t& a, const u32x4_t& b, f32x4_t acc);
+template <> __device__ __forceinline__ f32x4_t tw_mfma32<bf16_t>(const u32x4_t& a, const u32x4_t& b, f32x4_t acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4_t tw_mfma32<f16_t>(const u32x4_t& a, const u32x4_t& b, f32x4_t acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
+}
+// two floats -> one dword holding (T)lo | (T)hi << 16 (round to nearest even; float16: saturating at the largest finite value,
+// as HF clamps its float16 hidden states, HF:models/whisper/modeling_whisper.py:409-411)
+template <typename T> __device__ __forceinline__ unsigned tw_pack2(float lo, float hi) {
+  typename Pair16<T>::x2 v;
+  if constexpr (sizeof(T) == 2 && ElemTraits<T>::kCode == 2) {
+    lo = fminf(fmaxf(lo, -65504.f), 65504.f);
+    hi = fminf(fmaxf(hi, -65504.f), 65504.f);
+  }
+  v[0] = (T)lo;
+  v[1] = (T)hi;
+  return __builtin_bit_cast(unsigned, v);
+}
+// float -> T for activations (float16: saturating, see tw_pack2)
+template <typename T> __device__ __forceinline__ T tw_cast(float v) {
+  if constexpr (ElemTraits<T>::kCode == 2) v = fminf(fmaxf(v, -65504.f), 65504.f);
+  return (T)v;
+}
+// the same without the saturation, for values known to be in range (probabilities, convex combinations of stored values)
+template <typename T> __device__ __forceinline__ unsigned tw_pack2_inrange(float lo, float hi) {
+  typename Pair16<T>::x2 v;
+  v[0] = (T)lo;
+  v[1] = (T)hi;
+  return __builtin_bit_cast(unsigned, v);
+}
+// s += a0 * b0 + a1 * b1 on pairs of T, float accumulate
+template <typename T> __device__ __forceinline__ float tw_dot2(typename Pair16<T>::x2 a, typename Pair16<T>::x2 b, float s);
+template <> __device__ __forceinline__ float tw_dot2<bf16_t>(bf16x2_t a, bf16x2_t b, float s) { return __builtin_amdgcn_fdot2_f32_bf16(a, b, s, false); }
+template <> __device__ __forceinline__ float tw_dot2<f16_t>(f16x2_t a, f16x2_t b, float s) { return __builtin_amdgcn_fdot2(a, b, s, false); }
+
+// launcher-side dispatch on a context element type code (0 f32, 1 bf16, 2 f16)
+#define TW_DISPATCH3(code, T, ...)                       \
+  do {                                                   \
+    if ((code) == 1) { typedef bf16_t T; __VA_ARGS__; }  \
+    else if ((code) == 2) { typedef f16_t T; __VA_ARGS__; } \
+    else { typedef float T; __VA_ARGS__; }               \
+  } while (0)
 
 // Fragment-major ("xt") layout of the decoder's per-token activations, a [16 streams][K] block stored as the MFMA B
 // operand of the decode projections reads it: 64-B step s = k / (4E), then lane = ((k / E) & 3) * 16 + stream, then the

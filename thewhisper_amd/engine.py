@@ -102,8 +102,11 @@ class WhisperEngine:
         if dtype == "fp8":
             dtype = FP8_DEFAULT
         self.dtype_name = dtype
-        self.tw_dtype = {"bf16": _cabi.TW_BF16, "f32": _cabi.TW_F32, "fp8a8": _cabi.TW_BF16_MXFP8, "fp8a16": _cabi.TW_BF16_W8A16}[dtype]
-        self.torch_dtype = {"bf16": torch.bfloat16, "f32": torch.float32, "fp8a8": torch.bfloat16, "fp8a16": torch.bfloat16}[dtype]
+        # "f16" = float16 context (round 4): the reference's streaming default dtype; same kernels instantiated for _Float16
+        self.tw_dtype = {"bf16": _cabi.TW_BF16, "f16": _cabi.TW_F16, "f32": _cabi.TW_F32, "fp8a8": _cabi.TW_BF16_MXFP8,
+                         "fp8a16": _cabi.TW_BF16_W8A16}[dtype]
+        self.torch_dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "fp8a8": torch.bfloat16,
+                            "fp8a16": torch.bfloat16}[dtype]
         self.alignment_heads = [tuple(map(int, x)) for x in (alignment_heads or [])]
         cfg = _cabi.tw_config()
         cfg.d_model = dims["d_model"]

@@ -180,11 +180,16 @@ class AMDWhisperForConditionalGeneration(WhisperForConditionalGeneration, _Engin
         T = int(1500 * (chunk_length_s / 30))  # same expression as R:thestage_speechkit/nvidia/asr_pipeline.py:16
         p0 = next(self.parameters())
         dt = dtype or p0.dtype
-        if dt == torch.float16:
-            logger.warning("fp16 requested: the MI355X engine computes in bf16 (same MFMA rate, wider range)")
-        eng_dtype = "f32" if dt == torch.float32 else "bf16"
+        # float16 requests run in a float16 context since round 4 (the reference's streaming default,
+        # R:thestage_speechkit/streaming/streaming_pipeline.py:369-370); THEWHISPER_FP16_AS_BF16=1 restores the bf16 mapping
+        import os
+
+        eng_dtype = {torch.float32: "f32", torch.float16: "f16"}.get(dt, "bf16")
+        if eng_dtype == "f16" and os.environ.get("THEWHISPER_FP16_AS_BF16", "0") == "1":
+            logger.warning("fp16 requested: THEWHISPER_FP16_AS_BF16=1, the MI355X engine computes in bf16")
+            eng_dtype = "bf16"
         if decoder_weights == "fp8":
-            if eng_dtype != "bf16":
+            if eng_dtype == "f32":
                 raise ValueError("decoder_weights='fp8' needs a bf16 (or fp16) torch_dtype")
             eng_dtype = "fp8"
         heads = getattr(self.generation_config, "alignment_heads", None) or []

@@ -51,8 +51,8 @@ class AMDWhisperBackend:
         from .asr_pipeline import ASRPipeline
 
         if torch_dtype is None:
-            # the reference defaults to fp16 (R:...:369-370); the MI355X engine's production dtype is bf16
-            torch_dtype = torch.bfloat16
+            # as the reference (R:...:369-370): float16 - a float16 context since round 4 (model.py: build_engine); bf16 before
+            torch_dtype = torch.float16
         self.chunk_length_s: float = chunk_length_s
         self.sample_rate: int = 16000
         self.device: str = "cuda"  # ROCm exposes MI355X as "cuda", as on the nvidia platform (R:...:365)
