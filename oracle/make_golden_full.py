@@ -53,6 +53,33 @@ RAND_LEN = {"full_large-v3_c10_b16": 170, "full_large-v3_c15_b4": 60}   # random
 WSCALE, QGAIN = 0.5, 8.0   # make_weights(scale, q_gain): see its docstring (unit-gain random models degenerate at 32 layers)
 LOGIT_STRIDE = 29   # strided sample of every logits row kept for the relative-L2 estimate
 ENC_TSTRIDE, ENC_DSTRIDE = 25, 16
+# Whole-row evidence for the cases whose strided sample is thin (round-3 review: 223 of 51 866 values per row cannot see a bug
+# confined to one vocabulary slice): per row and per sampler slice (32 slices of 1 622 ids, thewhisper_amd/csrc/k_decode.hip:
+# sampler_part_kernel) a RANDOM-SIGN PROJECTION sum(sign[v] * logits[v]) and the slice's L2 norm.  Any local corruption moves
+# the projection by about the norm of what it changed; honest rounding noise moves it by (relative error) x (slice norm).
+N_SLICES, SLICE_SEED = 32, 12345
+SLICE_CASES = {"full_large-v3_c10_b16", "full_large-v3_c15_b4"}
+
+
+def slice_len(V: int) -> int:
+    return ((V + 2 * N_SLICES - 1) // (2 * N_SLICES)) * 2
+
+
+def slice_signs(V: int) -> np.ndarray:
+    return (np.random.default_rng(SLICE_SEED).integers(0, 2, size=V) * 2 - 1).astype(np.float32)
+
+
+def slice_evidence(logits: np.ndarray):
+    """logits [..., V] -> (projection [..., 32], norm [..., 32]) per sampler slice."""
+    V = logits.shape[-1]
+    n = slice_len(V)
+    pad = N_SLICES * n - V
+    x = np.concatenate([logits, np.zeros(logits.shape[:-1] + (pad,), logits.dtype)], axis=-1).astype(np.float64)
+    sg = np.concatenate([slice_signs(V), np.zeros(pad, np.float32)]).astype(np.float64)
+    xs = x.reshape(logits.shape[:-1] + (N_SLICES, n))
+    proj = (xs * sg.reshape(N_SLICES, n)).sum(-1)
+    norm = np.sqrt((xs * xs).sum(-1))
+    return proj.astype(np.float32), norm.astype(np.float32)
 PROMPT = [50258, 50259, 50360]
 
 
@@ -140,8 +167,13 @@ def run_case(name: str):
     logits2 = model(input_features=mel, decoder_input_ids=torch.from_numpy(ids2)).logits.numpy()
     top2 = torch.topk(torch.from_numpy(logits2), 8, dim=-1)
 
+    extra = {}
+    if name in SLICE_CASES:
+        extra["logits_slice_proj"], extra["logits_slice_norm"] = slice_evidence(logits)
+        extra["rand_logits_slice_proj"], extra["rand_logits_slice_norm"] = slice_evidence(logits2)
     np.savez_compressed(
         os.path.join(OUT, f"{name}.npz"),
+        **extra,
         rand_ids=ids2.astype(np.int32),
         rand_logits_top=top2.values.numpy().astype(np.float32), rand_logits_top_idx=top2.indices.numpy().astype(np.int32),
         rand_logits_sample=logits2[:, :, ::stride].astype(np.float32),

@@ -197,12 +197,23 @@ def run_case(name, dtype, logit_tol, enc_tol, top_abs, ts_bounds, check_ids=True
         top1_bad = []   # (stream, step, golden margin) of a wrong arg-max above the margin bound
         bound_steps = [0, 0]   # steps on which the top-1 rule binds / all steps
 
-        def teacher(ids, tops, top_idx, sample):
+        slice_worst = [0.0]
+
+        def teacher(ids, tops, top_idx, sample, sl_proj=None, sl_norm=None):
             eng.decoder_reset(B)
             worst_rel, worst_top, flips = 0.0, 0.0, []
             for s in range(ids.shape[1]):
                 lg = eng.decode_step(ids[:, s].tolist()).cpu().numpy()
                 worst_rel = max(worst_rel, rel_l2(lg[:, ::stride], sample[:, s]))
+                if sl_proj is not None:
+                    # WHOLE-ROW evidence per sampler slice (oracle/make_golden_full.py: slice_evidence): the random-sign projection
+                    # of every one of the 32 vocabulary slices moves by at most (relative rounding error) x (slice norm); a bug
+                    # confined to a slice - which the strided sample of the row can miss - moves it by the norm of what it broke
+                    from oracle.make_golden_full import slice_evidence
+
+                    pe, _ = slice_evidence(lg)
+                    dev = np.abs(pe - sl_proj[:, s]) / np.maximum(sl_norm[:, s], 1e-6)
+                    slice_worst[0] = max(slice_worst[0], float(dev.max()))
                 for b in range(B):
                     worst_top = max(worst_top, float(np.abs(lg[b, top_idx[b, s]] - tops[b, s]).max()))
                     margin = tops[b, s, 0] - tops[b, s, 1]
@@ -216,8 +227,10 @@ def run_case(name, dtype, logit_tol, enc_tol, top_abs, ts_bounds, check_ids=True
             return worst_rel, worst_top, flips
 
         seq = z["sequences"].astype(np.int64)
+        has_slices = "logits_slice_proj" in z.files
         rep["greedy_path_logits_rel_l2"], rep["greedy_path_top8_maxabs"], rep["greedy_path_subm_flips"] = teacher(
-            seq[:, :-1], z["logits_top"], z["logits_top_idx"], z["logits_sample"])
+            seq[:, :-1], z["logits_top"], z["logits_top_idx"], z["logits_sample"],
+            z["logits_slice_proj"] if has_slices else None, z["logits_slice_norm"] if has_slices else None)
         # A11 given IDENTICAL ids by construction: the teacher-forced pass left the alignment heads' softmax rows of the
         # reference's own greedy path in the context, for every stream (whether or not the free-running loop below stays on it)
         Lg = seq.shape[1]
@@ -228,7 +241,12 @@ def run_case(name, dtype, logit_tol, enc_tol, top_abs, ts_bounds, check_ids=True
                                             ctrl=load_ctrl(name))
         rep.update(ts_rep)
         rep["rand_path_logits_rel_l2"], rep["rand_path_top8_maxabs"], rep["rand_path_subm_flips"] = teacher(
-            z["rand_ids"].astype(np.int64), z["rand_logits_top"], z["rand_logits_top_idx"], z["rand_logits_sample"])
+            z["rand_ids"].astype(np.int64), z["rand_logits_top"], z["rand_logits_top_idx"], z["rand_logits_sample"],
+            z["rand_logits_slice_proj"] if has_slices else None, z["rand_logits_slice_norm"] if has_slices else None)
+        if has_slices:
+            rep["slice_projection_worst_dev_over_slice_norm"] = slice_worst[0]
+            if slice_worst[0] > 4 * logit_tol:     # rounding noise adds up like a random walk under the random signs: ~ the rel-L2 itself
+                problems.append(f"a vocabulary slice's random-sign projection is off by {slice_worst[0]:.4f} of the slice norm (> {4 * logit_tol})")
         rep["top1_rule_binds_on_frac_of_steps"] = round(bound_steps[0] / max(1, bound_steps[1]), 3)
         if top1_bad:
             problems.append(f"top-1 differs above the margin bound at (stream, step, margin) {top1_bad[:8]}")
