@@ -45,6 +45,8 @@ struct tw_ctx {
   // "cross query ahead" (decode_core): the decoder's cross-attention query projection is folded into the two launches before
   // it, which saves one dependent launch per layer and step.  du = float32 [Bmax][d] pre-activation of that projection.
   bool fuse_cq = false;
+  bool enc_fold = true;   // encoder pre-LayerNorms folded into the QKV / fc1 GEMMs (GemmEpilogue::stats_*); TW_ENC_FOLD_LN=0: two LayerNorm launches per layer
+  float *ln_stats_a = nullptr, *ln_stats_b = nullptr;   // [rows][d / 32][2] partial row statistics of xa / xb
   float* du = nullptr;
   float* dstats = nullptr;   // [Bmax][d / tile rows][2] partial LayerNorm statistics of the residual stream (see GemvArgs::stats)
   unsigned char* logit_ws = nullptr;  // block scales of logit_w
@@ -302,6 +304,8 @@ static int create_ctx(const tw_config* cfg, const tw_ctx* share, tw_ctx** out) {
   {
     const char* fe = getenv("TW_FUSE_CQ_LAYOUT");   // 0: do not even lay the weights out for the fused sequence
     c->fuse_cq = c->d == c->H * 64 && !(fe && atoi(fe) == 0);
+    const char* ef = getenv("TW_ENC_FOLD_LN");
+    c->enc_fold = c->d % 64 == 0 && c->d <= 1280 && !(ef && atoi(ef) == 0);   // (k_gemm.hip: TW_LN_HALF partial statistics per thread)
   }
   auto bail = [&](int r) { g_create_error = c->err; tw_destroy(c); return r; };
 #define CALLOC(ptr, bytes, zero) do { int _r = dalloc(c, &(ptr), (bytes), (zero)); if (_r != TW_OK) return bail(_r); } while (0)
@@ -319,6 +323,7 @@ static int create_ctx(const tw_config* cfg, const tw_ctx* share, tw_ctx** out) {
   if (share) {
     c->shares_weights = true;
     c->fuse_cq = share->fuse_cq;
+    c->enc_fold = share->enc_fold;
     c->a16 = share->a16;
     c->conv1_w = share->conv1_w; c->conv1_b = share->conv1_b; c->conv2_w = share->conv2_w; c->conv2_b = share->conv2_b;
     c->enc_pos_raw = share->enc_pos_raw; c->enc_pos = share->enc_pos; c->enc_ln_g = share->enc_ln_g; c->enc_ln_b = share->enc_ln_b;
@@ -353,6 +358,12 @@ static int create_ctx(const tw_config* cfg, const tw_ctx* share, tw_ctx** out) {
     const size_t qkv_blocks = (decoder && c->fuse_cq) ? 4 : 3, o_blocks = (decoder && c->fuse_cq) ? 2 : 1;
     LA(L.ln1_g, d); LA(L.ln1_b, d); LA(L.wqkv, qkv_blocks * d * d); LA(L.bqkv, 3 * d); LA(L.wo, o_blocks * d * d); LA(L.bo, d);
     LA(L.ln2_g, d); LA(L.ln2_b, d); LA(L.w1, F * d); LA(L.b1, F); LA(L.w2, d * F); LA(L.b2, d);
+    if (!decoder && c->enc_fold) {
+      if ((r = dalloc(c, &L.qkv_gw, 3 * d * 4, true)) != TW_OK) return r;
+      if ((r = dalloc(c, &L.qkv_cb, 3 * d * 4, true)) != TW_OK) return r;
+      if ((r = dalloc(c, &L.fc1_gw, F * 4, true)) != TW_OK) return r;
+      if ((r = dalloc(c, &L.fc1_cb, F * 4, true)) != TW_OK) return r;
+    }
     if (decoder) {
       if ((r = dalloc(c, &L.qkv_gw, 4 * d * 4, true)) != TW_OK) return r;
       if ((r = dalloc(c, &L.qkv_cb, 4 * d * 4, true)) != TW_OK) return r;
@@ -397,6 +408,8 @@ static int create_ctx(const tw_config* cfg, const tw_ctx* share, tw_ctx** out) {
   CALLOC(c->xa, B * T * d * e, false);
   CALLOC(c->xb, B * T * d * e, false);
   CALLOC(c->lnbuf, B * T * d * e, false);
+  CALLOC(c->ln_stats_a, B * T * (d / 32) * 8, false);
+  CALLOC(c->ln_stats_b, B * T * (d / 32) * 8, false);
   CALLOC(c->qbuf, B * T * d * e, false);
   CALLOC(c->kbuf, B * T * d * e, false);
   CALLOC(c->vtbuf, B * H * 64 * Tp * e, true);      // key padding [T, Tp) stays zero
@@ -598,6 +611,13 @@ int tw_finalize_weights(tw_ctx* c, void* stream) {
   }
   HIPCHK(c, launch_fold_ln(c->dtype, c->logit_w, c->tok_emb, c->dec_ln_g, c->dec_ln_b, nullptr, c->logit_gw, c->logit_cb,
                            c->V, c->d, st));
+  // ... and the encoder's two per layer into its QKV / fc1 GEMMs (k_gemm.hip, GemmEpilogue::stats_in): same algebra, the row
+  // statistics come from the GEMM that wrote the residual stream
+  for (int l = 0; l < c->Le && c->enc_fold; ++l) {
+    LayerW& L = c->enc[l];
+    HIPCHK(c, launch_fold_ln(c->dtype, L.wqkv, L.wqkv, L.ln1_g, L.ln1_b, L.bqkv, L.qkv_gw, L.qkv_cb, 3 * c->d, c->d, st));
+    HIPCHK(c, launch_fold_ln(c->dtype, L.w1, L.w1, L.ln2_g, L.ln2_b, L.b1, L.fc1_gw, L.fc1_cb, c->ffn, c->d, st));
+  }
   // decoder projections are consumed by launch_gemv in the fragment-major layout (k_decode.hip: tile_weights_kernel)
   {
     const size_t e = c->esz;
@@ -716,6 +736,7 @@ int encode_core(tw_ctx* c, const void* mel, int32_t mel_dtype, int32_t B, int32_
   hipStream_t st = pick_stream(c, stream);
   const int d = c->d, T = c->T, C = c->C, H = c->H, F = c->ffn, dt = c->dtype;
   const size_t e = c->esz;
+  const bool fold = c->enc_fold;
   tic(c, 1, st);
   HIPCHK(c, launch_mel_transpose(dt, mel_dtype, mel, c->melT, B, c->n_mels, 2 * T, C, st));
   {  // conv1 (k3,p1) + GELU as a GEMM over overlapping 3-row windows of the padded token-major mel
@@ -731,35 +752,42 @@ int encode_core(tw_ctx* c, const void* mel, int32_t mel_dtype, int32_t B, int32_
     ep.res = c->enc_pos; ep.res_map = plain_rows(d); ep.res_mod = T;
     ep.c_map = plain_rows(d);
     ep.out = c->xa;
+    if (fold) ep.stats_out = c->ln_stats_a;
     HIPCHK(c, launch_gemm(dt, c->h1, RowMap{T, (long long)(2 * T + 2) * d, 2LL * d}, c->conv2_w, B * T, d, 3 * d, ep, st));
   }
   const int M = B * T;
   for (int l = 0; l < c->Le; ++l) {
     const LayerW& L = c->enc[l];
-    HIPCHK(c, launch_layernorm(dt, c->xa, L.ln1_g, L.ln1_b, c->lnbuf, M, d, st));
+    // pre-LayerNorms: folded into the consuming GEMM (weights carry the gain, the epilogue applies mean / rstd from the partial row
+    // statistics the producing GEMM left), or - TW_ENC_FOLD_LN=0 - a launch that writes a normalised copy
+    if (!fold) HIPCHK(c, launch_layernorm(dt, c->xa, L.ln1_g, L.ln1_b, c->lnbuf, M, d, st));
     {
       GemmEpilogue ep{};
       ep.bias = L.bqkv; ep.mode = EPI_QKV_ENC; ep.T = T; ep.Tp = c->Tp; ep.H = H;
       ep.out = c->qbuf; ep.out2 = c->kbuf; ep.out3 = c->vtbuf;
-      HIPCHK(c, launch_gemm(dt, c->lnbuf, plain_rows(d), L.wqkv, M, 3 * d, d, ep, st));
+      if (fold) { ep.bias = nullptr; ep.stats_in = c->ln_stats_a; ep.stats_in_parts = d / 32; ep.ln_gw = L.qkv_gw; ep.ln_cb = L.qkv_cb; }
+      HIPCHK(c, launch_gemm(dt, fold ? c->xa : c->lnbuf, plain_rows(d), L.wqkv, M, 3 * d, d, ep, st));
     }
     HIPCHK(c, launch_enc_attention(dt, c->qbuf, c->kbuf, c->vtbuf, c->attn, B, H, T, c->Tp, st));
     {
       GemmEpilogue ep{};
       ep.bias = L.bo; ep.mode = EPI_ROWMAJOR; ep.res = c->xa; ep.res_map = plain_rows(d); ep.c_map = plain_rows(d);
       ep.out = c->xb;
+      if (fold) ep.stats_out = c->ln_stats_b;
       HIPCHK(c, launch_gemm(dt, c->attn, plain_rows(d), L.wo, M, d, d, ep, st));
     }
-    HIPCHK(c, launch_layernorm(dt, c->xb, L.ln2_g, L.ln2_b, c->lnbuf, M, d, st));
+    if (!fold) HIPCHK(c, launch_layernorm(dt, c->xb, L.ln2_g, L.ln2_b, c->lnbuf, M, d, st));
     {
       GemmEpilogue ep{};
       ep.bias = L.b1; ep.gelu = 1; ep.mode = EPI_ROWMAJOR; ep.c_map = plain_rows(F); ep.out = c->ffnh;
-      HIPCHK(c, launch_gemm(dt, c->lnbuf, plain_rows(d), L.w1, M, F, d, ep, st));
+      if (fold) { ep.bias = nullptr; ep.stats_in = c->ln_stats_b; ep.stats_in_parts = d / 32; ep.ln_gw = L.fc1_gw; ep.ln_cb = L.fc1_cb; }
+      HIPCHK(c, launch_gemm(dt, fold ? c->xb : c->lnbuf, plain_rows(d), L.w1, M, F, d, ep, st));
     }
     {
       GemmEpilogue ep{};
       ep.bias = L.b2; ep.mode = EPI_ROWMAJOR; ep.res = c->xb; ep.res_map = plain_rows(d); ep.c_map = plain_rows(d);
       ep.out = c->xa;
+      if (fold && l + 1 < c->Le) ep.stats_out = c->ln_stats_a;
       HIPCHK(c, launch_gemm(dt, c->ffnh, plain_rows(F), L.w2, M, d, F, ep, st));
     }
   }

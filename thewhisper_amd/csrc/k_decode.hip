@@ -665,9 +665,10 @@ __global__ __launch_bounds__(256) void fold_ln_kernel(T* __restrict__ W, const T
   for (int k = lane; k < K; k += 64) {
     const float w = (float)Wsrc[(long long)n * K + k];
     const float gk = (float)g[k];
-    sg += gk * w;
+    const T wr = (T)(gk * w);
+    sg += (float)wr;   // of the weights AS STORED: rstd (x W'^T - mean gw) is then exactly rstd (x - mean) W'^T
     sb += (float)beta[k] * w;
-    W[(long long)n * K + k] = (T)(gk * w);
+    W[(long long)n * K + k] = wr;
   }
   sg = wave_sum(sg);
   sb = wave_sum(sb);

@@ -160,26 +160,84 @@ __device__ __forceinline__ bool tw_tile_of_block(int id, int Tm, int Tn, int swz
 }
 
 // ---- epilogue shared by the kernels below: a lane holds, per (a,b) MFMA tile, 4 consecutive columns n of row m ----
+// Folded pre-LayerNorm, consumer side (GemmEpilogue::stats_in): (mean, rstd) of the BM rows of a block tile into LDS.  Two threads
+// per row split the partial statistics the producing GEMM left (parts = K / 32 of them, 8 B each; at most 2 x TW_LN_HALF) and combine
+// with one lane swap.  The loads are REQUESTED first in the prologue and the first K tiles next, so the reduction (gemm_ln_publish)
+// waits on the oldest requests only; the main loop's first barrier publishes the result to the epilogue.
+constexpr int TW_LN_HALF = 20;   // d_model <= 1280 (api.hip falls back to LayerNorm launches above that)
+struct LnRaw { f32x2_t v[TW_LN_HALF]; };
+template <int BM, int NTHR>
+__device__ __forceinline__ void gemm_ln_request(const GemmEpilogue& ep, int m0, int M, int tid, LnRaw& raw) {
+  static_assert(2 * BM <= NTHR, "two threads per row of the tile");
+  const int parts = ep.stats_in_parts, half = parts >> 1;
+  const int m = min(m0 + (tid >> 1), M - 1);
+  const f32x2_t* sp = reinterpret_cast<const f32x2_t*>(ep.stats_in) + (long long)m * parts + (tid & 1) * half;
+#pragma unroll
+  for (int p = 0; p < TW_LN_HALF; ++p) raw.v[p] = sp[min(p, half - 1)];
+}
+template <int BM, int NTHR>
+__device__ __forceinline__ void gemm_ln_publish(const GemmEpilogue& ep, int tid, const LnRaw& raw, f32x2_t* ln_rows) {
+  const int half = ep.stats_in_parts >> 1;
+  const float inv_k = 1.0f / (float)(ep.stats_in_parts * 32);
+  float s = 0.f, ss = 0.f;
+#pragma unroll
+  for (int p = 0; p < TW_LN_HALF; ++p) {
+    s += p < half ? raw.v[p][0] : 0.f;
+    ss += p < half ? raw.v[p][1] : 0.f;
+  }
+  s += __shfl_xor(s, 1);
+  ss += __shfl_xor(ss, 1);
+  const float mean = s * inv_k;
+  const float rstd = 1.0f / sqrtf(fmaxf(ss * inv_k - mean * mean, 0.f) + 1e-5f);
+  const int row = tid >> 1;
+  if ((tid & 1) == 0 && row < BM) ln_rows[row] = f32x2_t{mean, rstd};
+}
+
 template <typename T, int NT, int MT>
 __device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[NT][MT], int m_base, int n_base, int M, int N,
-                                              const GemmEpilogue& ep, int fr, int fq) {
+                                              const GemmEpilogue& ep, int fr, int fq, const f32x2_t* ln_rows = nullptr) {
   const T* bias = reinterpret_cast<const T*>(ep.bias);
   const T* res = reinterpret_cast<const T*>(ep.res);
   const int dmodel = ep.H * 64;
+  // folded pre-LayerNorm, consumer side (GemmEpilogue): (mean, rstd) of this lane's MT rows were reduced into LDS by gemm_ln_rows
+  // while the first K tiles were on their way; the per-column companions are loaded once per column block
+  const bool ln = ln_rows != nullptr;
+  f32x4_t ln_gw[NT], ln_cb[NT];
+  if (ln) {
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+      const int n = min(n_base + a * 16 + fq * 4, N - 4);
+      ln_gw[a] = *reinterpret_cast<const f32x4_t*>(ep.ln_gw + n);
+      ln_cb[a] = *reinterpret_cast<const f32x4_t*>(ep.ln_cb + n);
+    }
+  }
 #pragma unroll
   for (int b = 0; b < MT; ++b) {
     const int m = m_base + b * 16 + fr;
-    if (m >= M) continue;
+    const bool row_ok = m < M;
+    float ln_nmean = 0.f, ln_rstd = 1.f;
+    if (ln) {
+      const f32x2_t v = ln_rows[b * 16 + fr];
+      ln_nmean = -v[0];
+      ln_rstd = v[1];
+    }
     long long roff = 0;
-    if (res) roff = rowmap(ep.res_map, ep.res_mod > 0 ? (m % ep.res_mod) : m);
+    if (res && row_ok) roff = rowmap(ep.res_map, ep.res_mod > 0 ? (m % ep.res_mod) : m);
+    float st_s[NT / 2 > 0 ? NT / 2 : 1], st_ss[NT / 2 > 0 ? NT / 2 : 1];   // producer side: per 32-column block (two 16-column tiles)
+#pragma unroll
+    for (int i = 0; i < (NT / 2 > 0 ? NT / 2 : 1); ++i) { st_s[i] = 0.f; st_ss[i] = 0.f; }
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
       const int n = n_base + a * 16 + fq * 4;
-      if (n >= N) continue;
+      const bool ok = row_ok && n < N;
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r];
-      if (bias) {
+      if (ln) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaf(ln_rstd, fmaf(ln_nmean, ln_gw[a][r], v[r]), ln_cb[a][r]);
+      }
+      if (bias && ok) {
         Vec4<T> bv;
         bv.load(bias + n);
 #pragma unroll
@@ -189,7 +247,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[NT][MT], int 
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_exact<T>(v[r]);
       }
-      if (res) {
+      if (res && ok) {
         Vec4<T> rv;
         rv.load(res + roff + n);
 #pragma unroll
@@ -198,6 +256,15 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[NT][MT], int 
       Vec4<T> ov;
 #pragma unroll
       for (int r = 0; r < 4; ++r) ov.set(r, v[r]);
+      if (ep.stats_out) {   // statistics of the values AS STORED (rounded to T): what the consumer's matrix product sees
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float x = ok ? ov.get(r) : 0.f;
+          st_s[a / 2] += x;
+          st_ss[a / 2] = fmaf(x, x, st_ss[a / 2]);
+        }
+      }
+      if (!ok) continue;
       if (ep.mode == EPI_ROWMAJOR) {
         ov.store(reinterpret_cast<T*>(ep.out) + rowmap(ep.c_map, m) + n);
       } else {
@@ -224,6 +291,16 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[NT][MT], int 
           T* base = reinterpret_cast<T*>(seg == 0 ? ep.out : ep.out2);
           ov.store(base + ((long long)(bidx * ep.H + h) * ep.T + t) * 64 + dd);
         }
+      }
+    }
+    if (ep.stats_out) {
+      // the 32 columns of a block live in the 4 lanes fq = 0..3 of row fr (8 values each): two lane swaps, lane fq = 0 stores
+#pragma unroll
+      for (int i = 0; i < (NT / 2 > 0 ? NT / 2 : 1); ++i) {
+        const float s = tw_xor32_sum(tw_xor16_sum(st_s[i])), ss = tw_xor32_sum(tw_xor16_sum(st_ss[i]));
+        const int nb = n_base + i * 32;
+        if (fq == 0 && row_ok && nb < N)
+          reinterpret_cast<f32x2_t*>(ep.stats_out)[(long long)m * (N / 32) + nb / 32] = f32x2_t{s, ss};
       }
     }
   }
@@ -328,6 +405,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const T* __restrict_
   static_assert(AV >= 1 && WV >= 1 && MT >= 1 && NT >= 1, "tile / wavefront layout");
   constexpr int STAGE = 8 * (BM + BN);       // 16-B vectors per ring stage
   __shared__ u32x4_t lds[ST * STAGE];
+  __shared__ f32x2_t ln_rows[BM];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -390,9 +468,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const T* __restrict_
     a_addr[kk] = tw_lds_addr(lds) + (unsigned)(row * 8 + ((kk * 4 + fq) ^ ((row >> 1) & 7))) * 16;
   }
   const unsigned w_addr = tw_lds_addr(lds) + (unsigned)(8 * BM + ((wn * RN) / 16) * 2 * 64 + lane) * 16;
+  LnRaw ln_raw;
+  if (ep.stats_in) gemm_ln_request<BM, NTHR>(ep, m0, M, tid, ln_raw);
 #pragma unroll
   for (int t = 0; t < ST - 1; ++t)
     if (t < nk) issue_tile(t, t);
+  if (ep.stats_in) gemm_ln_publish<BM, NTHR>(ep, tid, ln_raw, ln_rows);
   int buf = 0;
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt has landed: this wavefront's own DMA by vmcnt (requests retire in order; the ST-2 younger tiles may stay in
@@ -429,7 +510,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const T* __restrict_
     });
     if (++buf == ST) buf = 0;
   }
-  gemm_epilogue<T, NT, MT>(acc, m0 + wm * RM, n0 + wn * RN, M, N, ep, fr, fq);
+  gemm_epilogue<T, NT, MT>(acc, m0 + wm * RM, n0 + wn * RN, M, N, ep, fr, fq, ep.stats_in ? ln_rows + wm * RM : nullptr);
 }
 
 // Kernel 2 (large M: the batched encoder, the cross-K/V projection).  The round-1 kernel staged both operands through LDS in
@@ -454,6 +535,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_wreg_kernel(const T* __restri
   static_assert(BM % 16 == 0 && AV >= 1 && (ST == 2 || ST == 3), "tile layout");
   constexpr int STAGE = AV * NTHR;
   __shared__ u32x4_t lds[ST * STAGE];
+  __shared__ f32x2_t ln_rows[BM];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -498,11 +580,6 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_wreg_kernel(const T* __restri
   };
 
   f32x4_t acc[NT][MT];
-#pragma unroll
-  for (int a = 0; a < NT; ++a)
-#pragma unroll
-    for (int b = 0; b < MT; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
   const int nk = K / BKE;
   int buf = 0;
   unsigned a_addr[2];
@@ -540,17 +617,24 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_wreg_kernel(const T* __restri
     });
     if (++buf == ST) buf = 0;
   };
-  // request order: A(0), W(0), A(1) | per tile: W(kt+1), A(kt+ST-1)
+  // request order: [row statistics of a folded LayerNorm,] A(0), W(0), A(1) | per tile: W(kt+1), A(kt+ST-1)
+  LnRaw ln_raw;
+  if (ep.stats_in) gemm_ln_request<BM, NTHR>(ep, m0, M, tid, ln_raw);
   issue_a(0, 0);
   load_w(w0, 0);
   if (ST == 3) issue_a(min(1, nk - 1), 1);
+  if (ep.stats_in) gemm_ln_publish<BM, NTHR>(ep, tid, ln_raw, ln_rows);
+#pragma unroll
+  for (int a = 0; a < NT; ++a)   // (zeroed here, after the prologue's registers are free again)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   for (int kt = 0; kt < nk; kt += 2) {
     step(kt, w0, w1);
     if (kt + 1 < nk) step(kt + 1, w1, w0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant tail requests must not outlive the LDS allocation
   if (ep.mode == EPI_KV_CROSS8) gemm_epilogue_kv8<T, NT, MT>(acc, m0, n0, M, N, ep, fr, fq);
-  else gemm_epilogue<T, NT, MT>(acc, m0, n0, M, N, ep, fr, fq);
+  else gemm_epilogue<T, NT, MT>(acc, m0, n0, M, N, ep, fr, fq, ep.stats_in ? ln_rows : nullptr);
 }
 
 }  // namespace

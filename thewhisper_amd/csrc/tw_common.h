@@ -168,6 +168,15 @@ struct GemmEpilogue {
   void* out2;         // k (QKV_ENC) or v (KV_CROSS)
   void* out3;         // v transposed (QKV_ENC); KV_CROSS8: per-key scale bytes of K [B][H][Tp]
   void* out4;         // KV_CROSS8: per-key scale bytes of V^T [B][H][Tp]
+  // Folded pre-LayerNorm of the ENCODER (round 4; the decoder's projections have had it since round 1, k_decode.hip).
+  // Producer side (a GEMM that writes the residual stream, EPI_ROWMAJOR): stats_out[m][n / 32] = (sum, sum of squares) of the 32
+  // stored values of row m in that column block - the LayerNorm statistics of the row in N / 32 partials, fixed order, no atomics.
+  // Consumer side (the QKV / fc1 GEMM, whose weight carries the LayerNorm gain, tw_finalize_weights): the A operand is the RAW
+  // residual stream, y = rstd (acc - mean gw[n]) + cb[n] with (mean, rstd) of row m from stats_in[m][0 .. parts); `bias` is then null
+  // (cb contains it).  No normalised copy of the stream is written or read and two launches per layer disappear.
+  float* stats_out;
+  const float* stats_in; int stats_in_parts;
+  const float* ln_gw; const float* ln_cb;
 };
 
 // ---- launchers (one per kernel family); all enqueue on `st` and return hipGetLastError() ----
