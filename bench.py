@@ -273,36 +273,39 @@ def pipeline_leg(eng, dims, args, device_index, heads, latency_calls, hub_rounds
 
         # (b) free-running sessions (what B independent streaming schedulers are): every session asks again as soon as it has
         #     its answer; the hub fills each pass with whatever chunks need one (serving.py)
-        def free_running(hub, per_session):
+        def free_running(hub, per_session, sessions=B):
             def session(k):
                 be = hub.stream_backend()
                 for i in range(per_session):
                     be.transcribe(clips[(k + i) % B], 0.0, 16000)
 
-            th = [threading.Thread(target=session, args=(k,)) for k in range(B)]
+            th = [threading.Thread(target=session, args=(k,)) for k in range(sessions)]
             [t.start() for t in th]
             [t.join() for t in th]
 
         out = {}
 
-        def measure(prefix, **hub_kw):
+        def measure(prefix, sessions=B, rounds=hub_rounds, **hub_kw):
             hub = BatchingHub(backend, max_batch=B, max_wait_s=0.004, **hub_kw)
-            free_running(hub, 1)                       # warm-up: plan learning + graph capture for this batch size
+            free_running(hub, 1, sessions)             # warm-up: plan learning + graph capture for this batch size
             hub.latencies.clear(); hub.batches.clear(); counted["tok"] = 0
             p0, r0, f0 = hub.passes, hub.rows, hub.prefetched
+            ph0 = dict(hub.phase_s)
             t0 = time.perf_counter()
-            free_running(hub, hub_rounds)
+            free_running(hub, rounds, sessions)
             dt = time.perf_counter() - t0
             lats = sorted(hub.latencies)
             passes, rows = hub.passes - p0, hub.rows - r0
             res = {
-                f"{prefix}tok_per_s": round(counted["tok"] / dt, 1), f"{prefix}sessions": B, f"{prefix}requests": B * hub_rounds,
+                f"{prefix}tok_per_s": round(counted["tok"] / dt, 1), f"{prefix}sessions": sessions, f"{prefix}requests": sessions * rounds,
                 f"{prefix}mode": "continuous (seek passes of chunks)" if hub._codec is not None else "whole-call batches",
                 f"{prefix}request_p50_ms": round(lats[len(lats) // 2] * 1e3, 2) if lats else None,
                 f"{prefix}request_p90_ms": round(lats[min(len(lats) - 1, (len(lats) * 9) // 10)] * 1e3, 2) if lats else None,
                 f"{prefix}mean_rows_per_pass": round(rows / max(1, passes), 2), f"{prefix}passes": passes,
-                f"{prefix}passes_per_request": round(rows / max(1, B * hub_rounds), 2),
+                f"{prefix}passes_per_request": round(rows / max(1, sessions * rounds), 2),
                 f"{prefix}rows_prefetched": hub.prefetched - f0, f"{prefix}tokens": counted["tok"],
+                # batcher-thread wall time per pass by phase (ms): `greedy` = the engine call inside `run`, the rest of `run` is host work
+                f"{prefix}phase_ms_per_pass": {k: round((v - ph0.get(k, 0.0)) / max(1, passes) * 1e3, 2) for k, v in hub.phase_s.items()},
             }
             hub.close()
             return res
@@ -317,6 +320,17 @@ def pipeline_leg(eng, dims, args, device_index, heads, latency_calls, hub_rounds
             r = measure("hub_prefetch_", prefetch_cus=args.hub_prefetch_cus)
             out.update({k: r[k] for k in ("hub_prefetch_tok_per_s", "hub_prefetch_request_p50_ms", "hub_prefetch_request_p90_ms",
                                           "hub_prefetch_rows_prefetched")})
+        # (b2') two cohorts: 2 x B sessions on the same B-row passes.  The rows that sit a pass out - new arrivals AND chunks that need a
+        #      further seek iteration - are encoded on the side stream under the running pass's decode loop and adopted by the next
+        #      pass (serving.py: _Prefetcher.ahead): the encoder stage and the sessions' round trips leave the critical path, at twice
+        #      the request latency.  `hub_2x_*` with the side stream, `hub_2x_serial_*` without (passes encode their own rows).
+        if args.hub_two_cohorts and args.hub_prefetch_cus > 0:
+            keys = ("tok_per_s", "sessions", "requests", "request_p50_ms", "request_p90_ms", "phase_ms_per_pass", "mean_rows_per_pass", "passes", "rows_prefetched")
+            rounds2 = max(2, hub_rounds // 2)
+            r = measure("hub_2x_", sessions=2 * B, rounds=rounds2, prefetch_cus=args.hub_prefetch_cus)
+            out.update({f"hub_2x_{k}": r[f"hub_2x_{k}"] for k in keys})
+            r = measure("hub_2x_serial_", sessions=2 * B, rounds=rounds2)
+            out.update({f"hub_2x_serial_{k}": r[f"hub_2x_serial_{k}"] for k in keys[:6]})
         # (b3) short passes: `hub_short_tokens` new tokens per pass instead of 128.  A random-weight decoder closes timestamp pairs at
         #      random places, so a 10 s buffer needs 3-4 seek passes whatever the budget (a trained model: 1-2); with 24-token passes
         #      a request's wall time is what a trained model's ONE 128-token pass costs, which makes the reference scheduler's 0.5 s
@@ -475,6 +489,8 @@ def main(argv=None):
     ap.add_argument("--no-pipeline-leg", action="store_true", help="skip the measurement through ASRPipeline / BatchingHub")
     ap.add_argument("--no-secondary", action="store_true", help="skip the compact legs for BASELINE configs 2 (turbo, 30 s, 1 stream) and 5 (fp8, 15 s)")
     ap.add_argument("--hub-rounds", type=int, default=12, help="requests per session in the hub measurement")
+    ap.add_argument("--no-hub-two-cohorts", dest="hub_two_cohorts", action="store_false",
+                    help="skip the hub measurement with twice as many sessions as rows per pass (hub_2x_*)")
     ap.add_argument("--hub-prefetch-cus", type=int, default=96,
                     help="compute units of the side stream that encodes arrivals while a hub pass decodes (0 = off; serving.py)")
     ap.add_argument("--hub-short-tokens", type=int, default=24,
@@ -704,6 +720,9 @@ def main(argv=None):
                                       "definition: generated tokens over wall-clock from transcribe() entry to return, host buffers in, word "
                                       "dictionaries out, through AMDWhisperBackend / BatchingHub (pipeline.hub_tok_per_s)")
         result["value_api"] = (result.get("pipeline") or {}).get("hub_tok_per_s")
+        # the same API with two cohorts of sessions taking turns on the same passes (32 sessions for 16 rows): the encoder stage of the
+        # cohort that sits a pass out runs on the side stream under that pass's decode loop
+        result["value_api_two_cohorts"] = (result.get("pipeline") or {}).get("hub_2x_tok_per_s")
         if world == 1 and not stub and not args.no_secondary:
             legs = []
             for label, model, chunk_s, nb, dt_, k in (("configs[1]: large-v3-turbo, 30 s chunk, batch 1, bf16", "large-v3-turbo", 30, 1, "bf16", 5),

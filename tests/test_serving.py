@@ -234,6 +234,37 @@ def test_hub_prefetches_the_encoder_stage_of_arrivals_during_a_pass():
     assert prefetched >= 3, prefetched                                       # the late arrivals were encoded on the sibling
 
 
+def test_hub_encodes_the_rows_that_sit_a_pass_out_on_the_side():
+    """More requests in flight than a pass has rows, `prefetch_cus > 0`: the chunks that wait for the next pass - at whatever seek
+    position they have reached - are encoded by the prefetch thread under the running pass's decode loop and adopted by the next
+    pass (two cohorts taking turns).  Same results, every chunk-pass runs exactly once."""
+    from tests.test_shortform import build
+    from thewhisper_amd import AMDWhisperBackend
+    from thewhisper_amd.serving import BatchingHub
+
+    pipe = build(batch_size=4, chunk_s=30)
+    backend = AMDWhisperBackend(None, chunk_length_s=30, asr_pipeline=pipe)
+    backend._generate_kwargs = lambda: {"use_cache": True, "num_beams": 1, "do_sample": False, "max_new_tokens": 24, "language": "en"}
+    lens = [480000, 336000, 475679, 240000, 480000, 400000]
+    bufs = [(wo.synth_audio(n, 60 + i, ["speechlike", "noise", "speechlike", "sine", "noise", "speechlike"][i]), 0.5 * i, 16000)
+            for i, n in enumerate(lens)]
+    eng = pipe.model.engine
+    single, passes_single = [], []
+    for a, t0, sr in bufs:
+        n0 = eng.calls["generate"]
+        single.append(backend.transcribe(a.copy(), t0, sr))
+        passes_single.append(eng.calls["generate"] - n0)
+    assert max(passes_single) >= 2, passes_single       # chunks that need further seek iterations: rows that CONTINUE
+    hub = BatchingHub(backend, max_batch=2, max_wait_s=0.05, prefetch_cus=8)
+    futs = [hub.submit(a.copy(), t0, sr) for a, t0, sr in bufs]     # six requests, two rows per pass
+    got = [f.result(timeout=900) for f in futs]
+    batches, ahead = list(hub.batches), hub.prefetched_ahead
+    hub.close()
+    assert normalise(got) == normalise(single)
+    assert sum(batches) == sum(passes_single) and max(batches) == 2, (batches, passes_single)
+    assert ahead >= 2, ahead            # rows with seek > 0 or of parked requests went through the side context
+
+
 def test_hub_falls_back_to_whole_call_batches_when_the_call_is_not_eligible():
     from thewhisper_amd import AMDWhisperBackend
     from thewhisper_amd.serving import BatchingHub

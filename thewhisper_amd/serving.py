@@ -60,16 +60,24 @@ class _Prefetcher:
         self.cap = int(hub.max_batch)
         self.side = engine.sibling(self.cap)
         self.stream = None
+        self.main_stream = None
         dev = getattr(engine, "device", None)
         if dev is not None and dev.type == "cuda":     # (the CPU stand-in engine of the tests has no streams)
             total = torch.cuda.get_device_properties(dev).multi_processor_count
             n_cus = max(8, min(int(n_cus), total - 8))
             self.stream = masked_stream(total - n_cus, total, total, dev.index or 0)
             self.side.raw_stream = self.stream
+            # ... and the passes themselves on the OTHER compute units: a decode launch whose workgroups land behind the encoder's
+            # ~100 us tiles holds up the whole dependent chain (measured with the main stream unmasked: decode loop 194.7 instead of
+            # 178 ms per pass; thewhisper_amd/overlap.py masks both streams for the same reason)
+            self.main_prev = engine.raw_stream
+            self.main_stream = masked_stream(0, total - n_cus, total, dev.index or 0)
+            engine.raw_stream = self.main_stream
         self.lock = threading.Lock()          # held by this thread while it works on one request
         self.enabled = threading.Event()
         self.stop = False
         self.pre: "collections.deque" = collections.deque()    # (work, side slot, segment tensor), slot order
+        self.ahead: List[Any] = []            # chunks of requests in flight that sit the running pass out: encoded first, in one call
         self.new_jobs: List[Any] = []
         self.count = 0                        # filled slots of the sibling context
         self.thread = threading.Thread(target=self._run, name="thewhisper-prefetch", daemon=True)
@@ -112,6 +120,8 @@ class _Prefetcher:
 
                 self.side.raw_stream = None
                 _hiplib().stream_destroy(self.stream)     # synchronises first
+                self.main.raw_stream = self.main_prev
+                _hiplib().stream_destroy(self.main_stream)
             except Exception:  # noqa: BLE001
                 pass
         self.side.close()
@@ -138,6 +148,11 @@ class _Prefetcher:
                     return
                 item = _NOTHING
                 with self.lock:
+                    if self.enabled.is_set() and self.ahead:
+                        works, self.ahead = self.ahead[: self.cap - self.count], []
+                        if works:
+                            self._encode_ahead(works, shortform)
+                        continue
                     if self.enabled.is_set() and self.count < self.cap:
                         try:
                             item = self.hub._take(timeout=0.004)
@@ -154,6 +169,24 @@ class _Prefetcher:
                         self._prefetch(item, shortform)
                 if item is _NOTHING:
                     time.sleep(0.001)
+
+    def _encode_ahead(self, works, shortform):
+        """Next seek iteration of chunks that are NOT in the running pass (more requests in flight than a pass has rows): their
+        seek is final until they run again, so their encoder stage goes under this pass's decode loop, one batched call."""
+        import torch
+
+        n = len(works)
+        try:
+            segs = torch.stack([shortform.next_segment(w, self.side.T) for w in works], dim=0)
+            self.side.encode(segs, slot0=self.count) if self.count else self.side.encode(segs)
+            self.side.cross_kv(n, slot0=self.count) if self.count else self.side.cross_kv(n)
+        except Exception:  # noqa: BLE001  (the batcher encodes them itself, and reports what fails there)
+            return
+        for i, w in enumerate(works):
+            self.pre.append((w, self.count + i, segs))
+        self.count += n
+        self.hub.prefetched += n
+        self.hub.prefetched_ahead += n
 
     def _prefetch(self, item, shortform):
         import torch
@@ -226,6 +259,10 @@ class BatchingHub:
         self._prefetcher: Optional["_Prefetcher"] = None
         self._stopping = False
         self.prefetched = 0     # rows whose encoder stage ran under another pass's decode loop
+        self.prefetched_ahead = 0   # ... of which: rows of requests in flight that sat a pass out (more requests than rows per pass)
+        # wall time of the batcher loop by phase, summed over the passes (seconds): where a pass's time goes besides the decode loop
+        self.phase_s: Dict[str, float] = {"pause": 0.0, "adopt": 0.0, "encode_left": 0.0, "intake": 0.0, "encode_fresh": 0.0,
+                                          "run": 0.0, "after": 0.0}
         if continuous and hasattr(backend, "job_codec"):
             self._codec = backend.job_codec()
         self._post_q: "queue.Queue" = queue.Queue()
@@ -375,28 +412,34 @@ class BatchingHub:
             for j in jobs:
                 self._answer(j.future, exc=RuntimeError("BatchingHub closed before the request was served"))
 
+        ph = self.phase_s
+        t_mark = time.perf_counter()
+
+        def lap(name):
+            nonlocal t_mark
+            now = time.perf_counter()
+            ph[name] += now - t_mark
+            t_mark = now
+
         while True:
+            t_mark = time.perf_counter()
             pas = shortform.Pass(eng, codec.plan)
             if pf is not None:
                 pf.pause()            # from here to resume() this thread is the only user of the queue and of the sibling context
                 jobs.extend(j for j in pf.drain_jobs() if j not in jobs)
+            lap("pause")
             if self._stopping:
                 shutdown()
                 return
-            # 1. the chunks that need a further seek iteration go first: their encoder stage is enqueued NOW (asynchronous), so
-            #    the GPU is already busy while the sessions answered after the last pass are on their way back
-            pre_works = set(w for w, _, _ in pf.pre) if pf is not None else set()
-            left = [w for j in jobs for w in j.works if not w.done and w not in pre_works][: self.max_batch]
-            if left:
-                try:
-                    pas.add(left)
-                except Exception as e:  # noqa: BLE001  (engine failure)
-                    fail_jobs_of(left, e)
-                    continue
-            # 1b. rows whose first iteration was encoded under the previous pass's decode loop (_Prefetcher): a copy each
+            # 1. rows whose next iteration was encoded under the previous pass's decode loop (_Prefetcher: arrivals, and - with more
+            #    requests in flight than a pass has rows - the chunks that sat that pass out): a copy each
             adopted: List[Any] = []
-            if pf is not None and pf.pre and pas.free > 0:
-                ws, slot0, keep = pf.take(pas.free)
+
+            def room() -> int:          # rows this pass can still take
+                return min(pas.free, self.max_batch - len(pas.works))
+
+            if pf is not None and pf.pre and room() > 0:
+                ws, slot0, keep = pf.take(room())
                 try:
                     pas.adopt(ws, pf.side, slot0)
                     pas._keep.extend(keep)
@@ -404,12 +447,28 @@ class BatchingHub:
                 except Exception as e:  # noqa: BLE001
                     fail_jobs_of(ws, e)
                     continue
+            lap("adopt")
+            # 1b. the chunks that need a further seek iteration: their encoder stage is enqueued NOW (asynchronous), so the GPU is
+            #    already busy while the sessions answered after the last pass are on their way back
+            pre_works = set(id(w) for w, _, _ in pf.pre) if pf is not None else set()
+            taken = set(id(w) for w in adopted)
+            waiting = [w for j in jobs for w in j.works if not w.done and id(w) not in pre_works and id(w) not in taken]
+            left = waiting[: room()]
+            if left:
+                try:
+                    pas.add(left)
+                except Exception as e:  # noqa: BLE001  (engine failure)
+                    fail_jobs_of(left, e)
+                    continue
+            if pf is not None:
+                pf.ahead = waiting[len(left):]     # they sit this pass out: encoded on the side while it decodes
+            lap("encode_left")
             # 2. intake: block when there is nothing to decode; otherwise linger while rows are free - for max_wait_s, or for as
             #    long as the encoder stage of step 1 keeps the GPU busy anyway (~1.2 ms per chunk), whichever is longer
             fresh: List[Any] = []
             linger = max(self.max_wait_s, 0.0012 * len(left))
             deadline = time.monotonic() + linger if (left or adopted) else None
-            while pas.free - len(fresh) > 0:
+            while room() - len(fresh) > 0:
                 try:
                     if deadline is None:
                         item = self._take()
@@ -434,10 +493,11 @@ class BatchingHub:
             if stop:
                 shutdown()
                 return
+            lap("intake")
             # 3. the late arrivals join the pass as a further group (slots after the others'), then ONE greedy loop over all
-            works = list(left) + list(adopted)
+            works = list(adopted) + list(left)
             try:
-                take = fresh[: pas.free]
+                take = fresh[: room()]
                 if take:
                     pas.add(take)
                     works += take
@@ -448,7 +508,10 @@ class BatchingHub:
                 self.rows += len(works)
                 if pf is not None:
                     pf.resume()       # arrivals from now on are encoded on the side while this pass decodes
+                lap("encode_fresh")
                 pas.run()
+                lap("run")
+                ph["greedy"] = ph.get("greedy", 0.0) + getattr(pas, "greedy_s", 0.0)
                 for w in works:
                     if w.passes > shortform.MAX_SEEK_PASSES:
                         raise RuntimeError(f"a chunk needed more than {shortform.MAX_SEEK_PASSES} seek passes (the decoder keeps seeking to frame 0)")
@@ -464,6 +527,7 @@ class BatchingHub:
                 else:
                     still.append(j)
             jobs = still
+            lap("after")
 
     def _post_loop(self):
         while True:

@@ -26,6 +26,7 @@ floating-point bits: time offsets, token-timestamp offsets) and by test: tests/t
 from __future__ import annotations
 
 import dataclasses
+import time
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -185,9 +186,10 @@ class Pass:
         self.works.extend(works)
 
     def adopt(self, works: Sequence[ChunkWork], side_engine, side_slot0: int) -> None:
-        """The next rows of the pass are chunks whose FIRST seek iteration (seek = 0) was encoded elsewhere - by ``side_engine``,
-        a sibling context of the same weights, at its slots ``side_slot0 ..`` (serving.py: arrivals are encoded on a CU-masked
-        stream while the previous pass decodes): their cross K/V are copied into this pass's next slots (tw_adopt_cross_kv)."""
+        """The next rows of the pass are chunks whose next seek iteration (``next_segment`` at their CURRENT seek) was encoded
+        elsewhere - by ``side_engine``, a sibling context of the same weights, at its slots ``side_slot0 ..`` (serving.py: arrivals
+        and the chunks that sit a pass out are encoded on a CU-masked stream while the running pass decodes): their cross K/V are
+        copied into this pass's next slots (tw_adopt_cross_kv).  The caller guarantees the chunks have not run since."""
         n_new = len(works)
         if n_new == 0:
             return
@@ -195,9 +197,9 @@ class Pass:
             raise ValueError(f"a pass takes at most {self.engine.max_batch} chunks")
         nsf = 2 * int(self.engine.T)
         for w in works:
-            if w.seek != 0 or w.done:
-                raise ValueError("only chunks at their first seek iteration can be adopted")
-            self.snf.append(min(w.max_frames, nsf))
+            if w.done:
+                raise ValueError("finished chunk handed to a pass")
+            self.snf.append(min(w.max_frames - w.seek, nsf))
         self.engine.adopt_cross_kv(side_engine, side_slot0, n_new, len(self.works))
         self.works.extend(works)
 
@@ -216,7 +218,9 @@ class Pass:
                 raise ValueError("a pass takes forced prefixes of ONE length")
             n_forced = lens.pop()
             prompt = np.concatenate([prompt, np.stack([np.asarray(w.forced, dtype=np.int32) for w in works])], axis=1)
+        t0 = time.perf_counter()
         out = engine.generate_greedy(prompt, n_forced=n_forced, **plan.greedy) if n_forced else engine.generate_greedy(prompt, **plan.greedy)
+        self.greedy_s = time.perf_counter() - t0        # the engine call (blocks until the loop has finished); the rest of run() is host work
         self._keep.clear()
         seq = torch.from_numpy(np.ascontiguousarray(out["sequences"])).to(torch.long)
         L = int(seq.shape[1])
@@ -258,14 +262,21 @@ class Pass:
             w.passes += 1
 
 
-def first_segment(work: ChunkWork, T: int) -> torch.Tensor:
-    """The [n_mels, 2T] segment a chunk's first seek iteration encodes (what ``Pass.add`` cuts for seek = 0)."""
+def next_segment(work: ChunkWork, T: int) -> torch.Tensor:
+    """The [n_mels, 2T] segment a chunk's NEXT seek iteration encodes (what ``Pass.add`` cuts at the chunk's current seek)."""
     nsf = 2 * int(T)
-    n = min(work.max_frames, nsf)
-    s = work.feats[:, :n]
+    n = min(work.max_frames - work.seek, nsf)
+    s = work.feats[:, work.seek : work.seek + n]
     if n < nsf:
         s = F.pad(s, pad=(0, nsf - n))
     return s
+
+
+def first_segment(work: ChunkWork, T: int) -> torch.Tensor:
+    """``next_segment`` of a chunk that has not run yet (seek = 0)."""
+    if work.seek != 0:
+        raise ValueError("the chunk has run already")
+    return next_segment(work, T)
 
 
 def run_pass(engine, plan: ShortFormPlan, works: Sequence[ChunkWork]) -> None:
