@@ -404,8 +404,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const T* __restrict_
   constexpr int NT = RN / 16;                // along N
   static_assert(AV >= 1 && WV >= 1 && MT >= 1 && NT >= 1, "tile / wavefront layout");
   constexpr int STAGE = 8 * (BM + BN);       // 16-B vectors per ring stage
-  __shared__ u32x4_t lds[ST * STAGE];
-  __shared__ f32x2_t ln_rows[BM];
+  constexpr int PER = AV + WV;               // DMA requests per thread and stage
+  static_assert(ST >= 2 && (ST - 2) * PER <= 63, "ring depth against the 6-bit vmcnt");
+  // the ring lives in dynamic LDS (any depth the 160 KB of a CU and the 6-bit vmcnt allow; deep rings were tried, see gemm_dispatch)
+  extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];
+  u32x4_t* lds = reinterpret_cast<u32x4_t*>(gemm_smem);
+  f32x2_t* ln_rows = reinterpret_cast<f32x2_t*>(gemm_smem + (size_t)ST * STAGE * 16);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -479,8 +483,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const T* __restrict_
     // tile kt has landed: this wavefront's own DMA by vmcnt (requests retire in order; the ST-2 younger tiles may stay in
     // flight), the other wavefronts' by the barrier
     if (ST > 2 && kt + ST - 2 < nk) {
-      if constexpr (ST == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AV + WV) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AV + WV)) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * PER) : "memory");
+    } else if (ST > 3) {
+      // the last ST - 2 tiles: r = nk - 1 - kt younger tiles are in flight (r < ST - 2)
+      const int r = nk - 1 - kt;
+      tw_static_for<0, (ST > 3 ? ST - 2 : 1)>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if (r == i) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(i * PER) : "memory");
+      });
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -661,7 +671,12 @@ static hipError_t gemm_go(const void* A, RowMap amap, const void* W, int M, int 
   const int Tn = (N + BN - 1) / BN, Tm = (M + BM - 1) / BM;
   int swz;
   dim3 grid(gemm_grid(Tm, Tn, false, &swz));
-  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, ST>), grid, dim3(WM * WN * 64), 0, st, reinterpret_cast<const T*>(A), amap,
+  constexpr size_t lds_bytes = (size_t)ST * 8 * (BM + BN) * 16 + (size_t)BM * sizeof(f32x2_t);   // ring + folded-LayerNorm rows
+  static_assert(lds_bytes <= 160 * 1024, "LDS of a compute unit");
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, BM, BN, WM, WN, ST>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (attr != hipSuccess) return attr;
+  hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, ST>), grid, dim3(WM * WN * 64), lds_bytes, st, reinterpret_cast<const T*>(A), amap,
                      reinterpret_cast<const T*>(W), M, N, K, Tm, Tn, swz, ep);
   return hipGetLastError();
 }
@@ -686,7 +701,7 @@ static hipError_t gemm_dispatch(const void* A, RowMap amap, const void* W, int M
   //   5: 128 x 256, 4 wavefronts side by side, weights straight to registers, 3-stage activation ring (kernel 2)  - large M
   //   6: same, 2 stages;   8: 64 x 256 (narrow N at large M: twice the workgroups)
   //   4: 128 x 128, 4 wavefronts, both operands through a 2-stage LDS ring (the round-1 shape)
-  //   1: 128 x 64;  0: 64 x 64  - small M (single stream): enough workgroups to cover the chip
+  //   1: 128 x 64 (3 stages);  12: 64 x 64 (4 stages);  0: 64 x 64 (2 stages)  - small M (one to three streams)
   static const int forced = gemm_env("TW_GEMM_CFG", -1);
   static const int narrow = gemm_env("TW_GEMM_NARROW", 5);   // tile config for N <= 2048 at large M (experiments)
   // kernel 2 from this many 128 x 128 tiles on: 128 x 256 tiles need >= 256 workgroups to cover the chip.  One 30 s chunk's fc1
@@ -698,8 +713,18 @@ static hipError_t gemm_dispatch(const void* A, RowMap amap, const void* W, int M
     if (ElemTraits<T>::kCode != 1 || N % 64 != 0) return hipErrorInvalidValue;
     return gemm_wreg_go<T, 128, 4, 3>(A, amap, W, M, N, K, ep, st);
   }
+  // Below that: 128 x 64 tiles on a 3-stage ring, or - up to 1000 rows (one chunk of <= 20 s, two of 10 s) - 64 x 64 tiles on a
+  // 4-stage ring (64 KB: two workgroups per CU): one 10 s chunk 3.51 -> 3.04 ms, 15 s 3.90 -> 3.55, 2 x 10 s 4.32 -> 4.24; 30 s and
+  // 3 x 10 s lose with it (5.46 -> 5.71, 4.96 -> 5.22) and stay.  Same accumulation order as every other tile shape: results do not
+  // change.  Round 4 also tried DEEP rings on the theory that a single stream's K tiles each wait ~2 us for operands nobody has
+  // warmed in L2 (8 x 16 KB of a 64 x 64 tile, 6 x 24 KB of a 128 x 64 tile, one workgroup per CU): out-projection 15.5 -> 12.5 us and
+  // fc2 39.5 -> 30, but fc1 18.4 -> 34 and QKV 15.3 -> 24.5 - with one workgroup per CU the wide projections run 2.5 rounds and the
+  // launch is bound by the aggregate operand traffic of its small tiles (210 MB for fc1 at M = 500 = 6 TB/s), not by latency
+  // (profiles/r04_gemm_deep_ring_ab.txt).  TW_GEMM_SMALL_64=0 restores the round-3 choice.
+  static const int small64 = gemm_env("TW_GEMM_SMALL_64", 1);
   if (forced >= 0) cfg = forced;
   else if (N % 256 == 0 && b128 >= wreg_min) cfg = (N <= 2048) ? narrow : 5;
+  else if (small64 && M <= 1000) cfg = 12;
   else if (M > 64) cfg = 1;
   else cfg = 0;
   if (cfg == 5) {
@@ -734,6 +759,7 @@ static hipError_t gemm_dispatch(const void* A, RowMap amap, const void* W, int M
     case 8: return gemm_wreg_go<T, 64, 4, 3>(A, amap, W, M, N, K, ep, st);     // narrow N: twice the workgroups
     case 4: return gemm_go<T, 128, 128, 2, 2, 2>(A, amap, W, M, N, K, ep, st);
     case 1: return gemm_go<T, 128, 64, 2, 2, 3>(A, amap, W, M, N, K, ep, st);
+    case 12: return gemm_go<T, 64, 64, 2, 2, 4>(A, amap, W, M, N, K, ep, st);     // 64 KB: two workgroups per CU
     default: return gemm_go<T, 64, 64, 2, 2, 2>(A, amap, W, M, N, K, ep, st);
   }
 }
