@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <set>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -1164,6 +1165,10 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
   };
 
   // ---- the loop: step s consumes position s and produces the token at position s+1 ----
+  static const bool host_timing = getenv("TW_HOST_TIMING") != nullptr;   // where the CALL's wall time goes besides the device loop
+  const auto ht0 = std::chrono::steady_clock::now();
+  auto ht_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ht0).count(); };
+  double ht_first = 0, ht_loop = 0;
   tic(c, 3, st);
   // two steps per graph launch: measured +2 % at one turbo stream, +0.3 % at 16 large-v3 streams (4 per launch: +3 % / +0.8 %, but
   // up to 7 steps past the last <eos> instead of 5); the finished flags are read LAG launches behind so the host never waits
@@ -1207,12 +1212,20 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
       for (int b = 0; b < B; ++b) done &= (c->h_pinned[ps * 64 + b] != 0);
       all_done = done;
     }
+    if (launches == 0) ht_first = ht_ms();
     ++launches;
   }
   toc(c, 3, st);
+  ht_loop = ht_ms();
   c->last_steps = steps;
   HIPCHK(c, hipMemcpyAsync(hseq, c->seq, sizeof(int) * (size_t)B * P, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
+  if (host_timing) {
+    float dev_ms = 0.f;
+    (void)hipEventElapsedTime(&dev_ms, c->ev0[3], c->ev1[3]);
+    fprintf(stderr, "TW_HOST_TIMING generate_greedy B=%d steps=%d launches=%d: first launch submitted at %.3f ms, host loop done at %.3f ms, "
+                    "synchronised at %.3f ms; device loop (events) %.3f ms\n", B, steps, launches, ht_first, ht_loop, ht_ms(), dev_ms);
+  }
 
   // common sequence length exactly as HF's loop would have stopped: when the last row hit eos, or at max_len
   const int produced = s_start + steps + 1;  // positions 0 .. s_start + steps are filled

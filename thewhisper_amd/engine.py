@@ -43,6 +43,26 @@ class WhisperEngine:
             return C.c_void_p(self.raw_stream)
         return _stream_ptr(self.device)
 
+    def _decode_stream(self) -> Optional[int]:
+        """The stream the greedy loop runs on when the caller does not manage streams (``raw_stream`` is None): confined to 160 of
+        the 256 compute units.  Alone on the chip the loop is FASTER there than on all of them - 16 streams 1.3415 vs 1.3937 ms per
+        step (192 CUs: 1.3564; 128: 1.664), one stream 1.0615 vs 1.0724 (tools/dbg_decode_cu_mask.py,
+        profiles/r04_decode_cu_mask.txt): its launches have 160 or 320 workgroups.  THEWHISPER_DECODE_CUS=0 turns it off."""
+        d = self.__dict__
+        if "_dec_stream" not in d:
+            ds = None
+            try:
+                n = int(os.environ.get("THEWHISPER_DECODE_CUS", "160"))
+                total = torch.cuda.get_device_properties(self.device).multi_processor_count
+                if 0 < n < total:
+                    from .overlap import masked_stream
+
+                    ds = masked_stream(0, n, total, self.device.index or 0)
+            except Exception:  # noqa: BLE001  (no CU masks on this runtime: the loop runs on the caller's stream)
+                ds = None
+            d["_dec_stream"] = ds
+        return d["_dec_stream"]
+
     def _adopt(self, *tensors) -> None:
         """With ``raw_stream`` set the work runs on a stream torch's caching allocator knows nothing about: order that
         stream after torch's current stream (which produced the inputs: H2D copies, slicing, casts) and keep every tensor
@@ -144,7 +164,7 @@ class WhisperEngine:
         if not self._finalized:
             raise RuntimeError("sibling() needs loaded weights")
         new = object.__new__(type(self))
-        new.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("ctx", "_held", "raw_stream", "_owner")})
+        new.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("ctx", "_held", "raw_stream", "_owner", "_dec_stream")})
         new.max_batch = int(max_batch or self.max_batch)
         ctx = C.c_void_p()
         rc = self.lib.tw_create_sibling(self.ctx, new.max_batch, C.byref(ctx))
@@ -161,6 +181,14 @@ class WhisperEngine:
         for sib in self.__dict__.get("_siblings", []):   # they read this context's weights: they go first
             sib.close()
         self.__dict__["_siblings"] = []
+        ds = self.__dict__.pop("_dec_stream", None)
+        if ds is not None:
+            try:
+                from .overlap import _hiplib
+
+                _hiplib().stream_destroy(ds)     # synchronises first
+            except Exception:  # noqa: BLE001
+                pass
         if getattr(self, "ctx", None):
             self.lib.tw_destroy(self.ctx)
             self.ctx = None
@@ -325,9 +353,15 @@ class WhisperEngine:
         o.n_forced = int(n_forced)
         out = np.full((B, int(max_length)), pad_id, dtype=np.int32)
         out_len = C.c_int32(0)
+        sp = self._sp()
+        if self.raw_stream is None:
+            ds = self._decode_stream()
+            if ds is not None:      # behind everything enqueued so far (the encoder stage); the call synchronises it before returning
+                torch.cuda.ExternalStream(ds, device=self.device).wait_stream(torch.cuda.current_stream(self.device))
+                sp = C.c_void_p(ds)
         rc = self.lib.tw_generate_greedy(self.ctx, B, prompt.ctypes.data_as(C.POINTER(C.c_int32)), n0, C.byref(o),
                                          out.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(out_len),
-                                         self._sp())
+                                         sp)
         self._chk(rc, "tw_generate_greedy")
         self._release_held()   # the call returns after synchronising its stream, which is ordered after the encoder stage
         L = int(out_len.value)
