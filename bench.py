@@ -273,11 +273,17 @@ def pipeline_leg(eng, dims, args, device_index, heads, latency_calls, hub_rounds
 
         # (b) free-running sessions (what B independent streaming schedulers are): every session asks again as soon as it has
         #     its answer; the hub fills each pass with whatever chunks need one (serving.py)
+        first_done = {}
+
         def free_running(hub, per_session, sessions=B):
+            first_done.clear()
+
             def session(k):
                 be = hub.stream_backend()
                 for i in range(per_session):
                     be.transcribe(clips[(k + i) % B], 0.0, 16000)
+                # the first session to finish closes the steady-state window: until here every session had a request in flight
+                first_done.setdefault("t", (time.perf_counter(), counted["tok"]))
 
             th = [threading.Thread(target=session, args=(k,)) for k in range(sessions)]
             [t.start() for t in th]
@@ -296,8 +302,12 @@ def pipeline_leg(eng, dims, args, device_index, heads, latency_calls, hub_rounds
             dt = time.perf_counter() - t0
             lats = sorted(hub.latencies)
             passes, rows = hub.passes - p0, hub.rows - r0
+            t1, tok1 = first_done.get("t", (t0 + dt, counted["tok"]))
             res = {
                 f"{prefix}tok_per_s": round(counted["tok"] / dt, 1), f"{prefix}sessions": sessions, f"{prefix}requests": sessions * rounds,
+                # the same while EVERY session still has requests to send (window closed by the first session that finishes): the
+                # whole-run figure above also contains the passes that drain the last requests with fewer and fewer rows
+                f"{prefix}steady_tok_per_s": round(tok1 / max(1e-9, t1 - t0), 1),
                 f"{prefix}mode": "continuous (seek passes of chunks)" if hub._codec is not None else "whole-call batches",
                 f"{prefix}request_p50_ms": round(lats[len(lats) // 2] * 1e3, 2) if lats else None,
                 f"{prefix}request_p90_ms": round(lats[min(len(lats) - 1, (len(lats) * 9) // 10)] * 1e3, 2) if lats else None,
@@ -325,12 +335,12 @@ def pipeline_leg(eng, dims, args, device_index, heads, latency_calls, hub_rounds
         #      pass (serving.py: _Prefetcher.ahead): the encoder stage and the sessions' round trips leave the critical path, at twice
         #      the request latency.  `hub_2x_*` with the side stream, `hub_2x_serial_*` without (passes encode their own rows).
         if args.hub_two_cohorts and args.hub_prefetch_cus > 0:
-            keys = ("tok_per_s", "sessions", "requests", "request_p50_ms", "request_p90_ms", "phase_ms_per_pass", "mean_rows_per_pass", "passes", "rows_prefetched")
+            keys = ("tok_per_s", "steady_tok_per_s", "sessions", "requests", "request_p50_ms", "request_p90_ms", "phase_ms_per_pass", "mean_rows_per_pass", "passes", "rows_prefetched")
             rounds2 = max(2, hub_rounds // 2)
             r = measure("hub_2x_", sessions=2 * B, rounds=rounds2, prefetch_cus=args.hub_prefetch_cus)
             out.update({f"hub_2x_{k}": r[f"hub_2x_{k}"] for k in keys})
             r = measure("hub_2x_serial_", sessions=2 * B, rounds=rounds2)
-            out.update({f"hub_2x_serial_{k}": r[f"hub_2x_serial_{k}"] for k in keys[:6]})
+            out.update({f"hub_2x_serial_{k}": r[f"hub_2x_serial_{k}"] for k in keys[:7]})
         # (b3) short passes: `hub_short_tokens` new tokens per pass instead of 128.  A random-weight decoder closes timestamp pairs at
         #      random places, so a 10 s buffer needs 3-4 seek passes whatever the budget (a trained model: 1-2); with 24-token passes
         #      a request's wall time is what a trained model's ONE 128-token pass costs, which makes the reference scheduler's 0.5 s
@@ -723,6 +733,9 @@ def main(argv=None):
         # the same API with two cohorts of sessions taking turns on the same passes (32 sessions for 16 rows): the encoder stage of the
         # cohort that sits a pass out runs on the side stream under that pass's decode loop
         result["value_api_two_cohorts"] = (result.get("pipeline") or {}).get("hub_2x_tok_per_s")
+        # value_api over the window in which every session still has requests to send (no drain passes at the end of the finite run)
+        result["value_api_steady_state"] = (result.get("pipeline") or {}).get("hub_steady_tok_per_s")
+        result["value_api_two_cohorts_steady_state"] = (result.get("pipeline") or {}).get("hub_2x_steady_tok_per_s")
         if world == 1 and not stub and not args.no_secondary:
             legs = []
             for label, model, chunk_s, nb, dt_, k in (("configs[1]: large-v3-turbo, 30 s chunk, batch 1, bf16", "large-v3-turbo", 30, 1, "bf16", 5),
