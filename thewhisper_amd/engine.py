@@ -46,7 +46,7 @@ class WhisperEngine:
     def _decode_stream(self) -> Optional[int]:
         """The stream the greedy loop runs on when the caller does not manage streams (``raw_stream`` is None): confined to 160 of
         the 256 compute units.  Alone on the chip the loop is FASTER there than on all of them - 16 streams 1.3415 vs 1.3937 ms per
-        step (192 CUs: 1.3564; 128: 1.664), one stream 1.0615 vs 1.0724 (tools/dbg_decode_cu_mask.py,
+        step (192 CUs: 1.3564; 128: 1.664), one stream 1.0615 vs 1.0724 (tools/dbg/decode_cu_mask.py,
         profiles/r04_decode_cu_mask.txt): its launches have 160 or 320 workgroups.  THEWHISPER_DECODE_CUS=0 turns it off."""
         d = self.__dict__
         if "_dec_stream" not in d:

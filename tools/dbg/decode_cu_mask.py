@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Decode loop (large-v3, 128 forced tokens) on a stream confined to the first N compute units of the mask, nothing else running:
 device-loop ms per call for 16 streams and for one.  (Round 4 observation: alone on 160 masked CUs the loop is FASTER than on all
-256 - 173.1 vs 180.7 ms.)  python tools/dbg_decode_cu_mask.py [--cus 256,192,160,128,96,80]"""
+256 - 173.1 vs 180.7 ms.)  python tools/dbg/decode_cu_mask.py [--cus 256,192,160,128,96,80]"""
 import argparse, os, sys
 os.environ["THEWHISPER_DECODE_CUS"] = "0"   # the engine's own default mask off: this tool sets the stream itself
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import bench
 from thewhisper_amd.engine import WhisperEngine
