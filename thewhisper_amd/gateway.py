@@ -453,6 +453,10 @@ def build_host(argv: Optional[List[str]] = None):
     ap.add_argument("--auth-token", default="")
     ap.add_argument("--language", default="en")
     ap.add_argument("--dtype", default=None, choices=[None, "bf16", "fp16", "fp32"], help="compute dtype (default: the checkpoint's)")
+    ap.add_argument("--prefetch-cus", type=int, default=0,
+                    help="compute units of the side stream that encodes, under the running pass's decode loop, the rows that sit that "
+                         "pass out (arrivals; with more requests in flight than --max-batch also the chunks waiting for their next "
+                         "seek iteration).  96 for deployments with about two sessions per pass row; 0 (default) = off")
     args = ap.parse_args(argv)
     import torch
 
@@ -462,7 +466,7 @@ def build_host(argv: Optional[List[str]] = None):
 
         host = NodeRouter(args.gpus, "thewhisper_amd.node:default_host_factory",
                           dict(model=args.model, chunk_length_s=args.chunk_length_s, max_batch=args.max_batch, language=args.language,
-                               use_vad=args.vad, torch_dtype=args.dtype))
+                               use_vad=args.vad, torch_dtype=args.dtype, prefetch_cus=args.prefetch_cus))
     else:
         backend = AMDWhisperBackend(args.model, chunk_length_s=args.chunk_length_s, language=args.language, batch_size=args.max_batch,
                                     torch_dtype=dtype)
@@ -471,7 +475,7 @@ def build_host(argv: Optional[List[str]] = None):
             from .vad import VadService
 
             vad = VadService(max_streams=1024)
-        host = SessionHost(BatchingHub(backend, max_batch=args.max_batch), vad=vad)
+        host = SessionHost(BatchingHub(backend, max_batch=args.max_batch, prefetch_cus=args.prefetch_cus), vad=vad)
     return host, args
 
 

@@ -359,7 +359,7 @@ class NodeRouter:
 
 
 def default_host_factory(rank: int, world: int, model: str, chunk_length_s: int = 10, max_batch: int = 16, language: str = "en",
-                         use_vad: bool = False, torch_dtype: Optional[str] = None, **_):  # pragma: no cover - needs weights and GPUs
+                         use_vad: bool = False, torch_dtype: Optional[str] = None, prefetch_cus: int = 0, **_):  # pragma: no cover - needs weights and GPUs
     """What ``python -m thewhisper_amd.gateway --gpus N`` runs in every worker: the backend of GPU ``rank`` behind a hub."""
     os.environ["THEWHISPER_DEVICE"] = f"cuda:{rank}"
     from .gateway import SessionHost
@@ -375,4 +375,4 @@ def default_host_factory(rank: int, world: int, model: str, chunk_length_s: int 
         from .vad import VadService
 
         vad = VadService(max_streams=1024, device=rank)
-    return SessionHost(BatchingHub(backend, max_batch=max_batch), vad=vad)
+    return SessionHost(BatchingHub(backend, max_batch=max_batch, prefetch_cus=prefetch_cus), vad=vad)
