@@ -6,6 +6,8 @@ import os
 import threading
 import wave
 
+import time
+
 import numpy as np
 import pytest
 import torch
@@ -210,6 +212,9 @@ def test_websocket_session_streams_chunks_and_answers_like_the_process_route():
         ws.send_text("end")
     assert normalise(replies[-1]["uncommited_words"]) == normalise(backend.transcribe(clip, 0.0, 16000))
     assert normalise(replies[0]["uncommited_words"]) == normalise(backend.transcribe(clip[:8000], 0.0, 16000))   # one reply per chunk
+    t_end = time.monotonic() + 5.0    # ("end" has no reply: the handler drops the session on its own clock)
+    while client.get("/health").json()["sessions"] != 0 and time.monotonic() < t_end:
+        time.sleep(0.02)
     assert client.get("/health").json()["sessions"] == 0                 # closing ended the session
     with pytest.raises(Exception):
         with client.websocket_connect("/ws/stream?token=wrong"):

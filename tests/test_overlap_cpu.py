@@ -62,19 +62,20 @@ def fake(monkeypatch):
 
 def test_cu_masks_partition_the_chip(fake):
     o = ov.EncoderOverlap([_FakeEngine("a"), _FakeEngine("b")], encoder_cus=64)
-    (_, w0, dec_mask), (_, w1, enc_mask) = [c for c in fake.calls if c[0] == "stream"]
-    assert w0 == w1 == 8
+    (_, w0, dec_mask), (_, w1, enc_mask), (_, w2, all_mask) = [c for c in fake.calls if c[0] == "stream"]
+    assert w0 == w1 == w2 == 8
     dec_bits = sum(bin(m).count("1") for m in dec_mask)
     enc_bits = sum(bin(m).count("1") for m in enc_mask)
     assert (dec_bits, enc_bits) == (192, 64)
     assert all(a & b == 0 for a, b in zip(dec_mask, enc_mask))
+    assert all(a | b == c for a, b, c in zip(dec_mask, enc_mask, all_mask))   # the first batch's encoder stage: the whole range
     o.close()
     with pytest.raises(ValueError):
         ov.EncoderOverlap([_FakeEngine("a")], encoder_cus=64)
     with pytest.raises(ValueError):
         ov.EncoderOverlap([_FakeEngine("a"), _FakeEngine("b")], encoder_cus=256)
     o2 = ov.EncoderOverlap([_FakeEngine("a"), _FakeEngine("b")], encoder_cus=32, cu_range=(128, 256))
-    masks = [c[2] for c in fake.calls if c[0] == "stream"][-2:]
+    masks = [c[2] for c in fake.calls if c[0] == "stream"][-3:-1]
     assert sum(bin(m).count("1") for m in masks[0]) == 96 and all(m == 0 for m in masks[0][:4])
     o2.close()
 
@@ -87,7 +88,7 @@ def test_pipeline_order_exclusive_use_and_overlap(fake):
 
     def enc(e, b):
         assert e.busy.acquire(blocking=False), "context used by both stages at once"
-        assert e.raw_stream in (o.s_enc, o.s_dec)
+        assert e.raw_stream in (o.s_enc, o.s_all)
         if decoding.is_set():
             overlapped.append(b)
         time.sleep(0.01)
@@ -111,7 +112,7 @@ def test_pipeline_order_exclusive_use_and_overlap(fake):
     assert [x[1] for x in log if x[0] == "dec"] == list(range(7))
     assert [x[2] for x in log if x[0] == "dec"] == ["a", "b", "a", "b", "a", "b", "a"]
     first_enc = next(x for x in log if x[0] == "enc" and x[1] == 0)
-    assert first_enc[3] == o.s_dec                      # pipeline fill: batch 0 encodes on the decoder's idle CUs
+    assert first_enc[3] == o.s_all                      # pipeline fill: batch 0 encodes on every CU of the range (nothing else runs yet)
     assert all(x[3] == o.s_enc for x in log if x[0] == "enc" and x[1] > 0)
     assert len(overlapped) >= 3                         # later encoder stages ran while a decode was in progress
     assert all(e.raw_stream is None for e in engs)      # handed back to torch's current stream
