@@ -1421,13 +1421,9 @@ static hipError_t skinny_launch_nw(const GemvArgs& a0, hipStream_t st) {
   const int tiles = (a.N + TR - 1) / TR;
   // at most `max_blocks` workgroups: tall matrices (the tied logits projection) walk several tiles per workgroup
   static const int max_blocks = env_int("TW_SK_MAX_BLOCKS", 512);
-  // ... and the tall ones (more than 512 tiles: the logits) at most `max_blocks_tall`: 320 = two per CU of the 160 the loop runs on
-  // (round 4, same box: decode step 1.3866 -> 1.3811 ms against the 464 workgroups the 512 cap gave)
-  static const int max_blocks_tall = env_int("TW_SK_MAX_BLOCKS_TALL", 320);
   const int steps_per_wave = (a.K / E / 4 + NW - 1) / NW;
   const bool groups = a.B > 16;  // several groups of 16 streams: 5 fragments in flight, further rounds for longer K
-  const int cap = tiles > max_blocks ? std::min(max_blocks, max_blocks_tall) : max_blocks;
-  a.rg = (tiles + cap - 1) / cap;
+  a.rg = (tiles + max_blocks - 1) / max_blocks;
   if (a.rg < 1 || steps_per_wave > (groups ? 5 : 10)) a.rg = 1;  // several tiles per workgroup only with one round per tile
   dim3 grid((tiles + a.rg - 1) / a.rg);
   if constexpr (TR != 16) {
@@ -1458,9 +1454,7 @@ static hipError_t skinny_launch_w8(const GemvArgs& a0, hipStream_t st) {
   // its weight tile), so the 320-tile launches walk TWO tiles per workgroup and keep the activation fragments in registers
   // (64 streams x 15 s: 3.50 -> 3.32 ms per step, profiles/r04_b64_15s_two_tiles_per_workgroup.txt; neutral for the bf16 kernels)
   static const int max_blocks_groups = env_int("TW_SK_MAX_BLOCKS_W8_GROUPS", 160);
-  static const int max_blocks_tall = env_int("TW_SK_MAX_BLOCKS_TALL", 320);   // the logits (skinny_launch_nw)
-  const int cap = groups ? max_blocks_groups : (tiles > max_blocks ? std::min(max_blocks, max_blocks_tall) : max_blocks);
-  a.rg = (tiles + cap - 1) / cap;
+  a.rg = (tiles + (groups ? max_blocks_groups : max_blocks) - 1) / (groups ? max_blocks_groups : max_blocks);
   if (a.rg < 1 || steps_per_wave > (groups ? 2 : 3)) a.rg = 1;   // several tiles per workgroup only with one round per tile
   dim3 grid((tiles + a.rg - 1) / a.rg);
   if constexpr (TR != 16) {
