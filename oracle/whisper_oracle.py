@@ -20,6 +20,7 @@ Parity pinning: the reference ships no tests, fixtures or golden vectors for thi
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -84,6 +85,17 @@ class SpecialTokens:
 # --------------------------------------------------------------------------------------
 
 
+def uniform_at(seed: int, offset: int, shape) -> np.ndarray:
+    """float32 uniforms number ``offset, offset + 1, ...`` of the stream ``np.random.default_rng(seed).random(..., dtype=float32)``
+    produces when drawn in one go: PCG64 yields two float32 draws per 64-bit step, low half first, so the generator is advanced
+    ``offset // 2`` steps and, at an odd offset, one draw (the low half, which belongs to the value before) is discarded."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    g.bit_generator.advance(offset // 2)
+    if offset & 1:
+        g.random(1, dtype=np.float32)
+    return g.random(shape, dtype=np.float32)
+
+
 def make_weights(dims: WhisperDims, seed: int = 0, scale: float = 1.0, q_gain: float = 1.0) -> Dict[str, np.ndarray]:
     """Deterministic float32 weights keyed by HF parameter names.
 
@@ -98,12 +110,29 @@ def make_weights(dims: WhisperDims, seed: int = 0, scale: float = 1.0, q_gain: f
     goldens, oracle/make_golden_full.py) gives peaked attention, audio-dependent token paths and an active
     timestamp grammar - a harder parity target.
     """
-    rng = np.random.default_rng(seed)
     d, f, v = dims.d_model, dims.ffn, dims.vocab
     w: Dict[str, np.ndarray] = {}
+    # The values are those of ONE generator, np.random.default_rng(seed), drawing float32 uniforms tensor after tensor in the order
+    # below.  They are produced by several threads: every tensor gets its own copy of the generator, advanced to the tensor's place in
+    # that stream (PCG64 yields two float32 draws per 64-bit step, low half first), so the result is bit-identical to the sequential
+    # loop (tests/test_oracle_weights.py) while the 1.5 G parameters of large-v3 take tens of seconds instead of two minutes on the
+    # 8-core test containers (the loop is bound by first-touch page faults, which parallelise).
+    drawn = [0]
 
-    def uni(shape, amp):
-        return ((rng.random(shape, dtype=np.float32) - 0.5) * (2.0 * amp)).astype(np.float32)
+    def uni(shape, amp, plus_one=False):
+        n = int(np.prod(shape))
+        ticket = (shape if isinstance(shape, tuple) else (shape,), float(amp), drawn[0], plus_one)
+        drawn[0] += n
+        return ticket
+
+    def fill(ticket):
+        shape, amp, off, plus_one = ticket
+        x = uniform_at(seed, off, shape)
+        x -= np.float32(0.5)
+        x *= np.float32(2.0 * amp)             # the same float32 operations, in the same order, as (u - 0.5) * (2 * amp)
+        if plus_one:
+            x = (1.0 + x).astype(np.float32)
+        return x
 
     def lin(name, out_f, in_f, bias=True):
         amp = scale * 1.7 / math.sqrt(in_f)
@@ -112,7 +141,7 @@ def make_weights(dims: WhisperDims, seed: int = 0, scale: float = 1.0, q_gain: f
             w[name + ".bias"] = uni((out_f,), 0.05)
 
     def ln(name):
-        w[name + ".weight"] = (1.0 + uni((d,), 0.1)).astype(np.float32)
+        w[name + ".weight"] = uni((d,), 0.1, plus_one=True)
         w[name + ".bias"] = uni((d,), 0.05)
 
     def attn(prefix):
@@ -149,6 +178,12 @@ def make_weights(dims: WhisperDims, seed: int = 0, scale: float = 1.0, q_gain: f
         lin(p + ".fc2", d, f)
         ln(p + ".final_layer_norm")
     ln(dd + ".layer_norm")
+    from concurrent.futures import ThreadPoolExecutor
+
+    keys = [k for k, t in w.items() if isinstance(t, tuple)]
+    with ThreadPoolExecutor(max_workers=max(1, min(8, os.cpu_count() or 1))) as pool:
+        for k, x in zip(keys, pool.map(fill, [w[k] for k in keys])):
+            w[k] = x
     if q_gain != 1.0:
         for k in w:
             if ".q_proj." in k:
