@@ -495,6 +495,7 @@ def main(argv=None):
                          "batch k (thewhisper_amd/overlap.py); 0 = one context, strictly sequential stages.  96: the decode "
                          "launches have 160 or 320 workgroups, which 256 - 96 = 160 CUs take in exactly one or two rounds "
                          "(same box: 10 436 vs 10 340 tok/s with 64)")
+    ap.add_argument("--decoder-cus", type=int, default=0, help="with --encoder-cus: compute units of the decode loop (0 = all the others)")
     ap.add_argument("--latency-iters", type=int, default=100, help="single-stream chunk calls timed for the p50 (after 10 warm-ups; SURVEY.md section 8d)")
     ap.add_argument("--no-pipeline-leg", action="store_true", help="skip the measurement through ASRPipeline / BatchingHub")
     ap.add_argument("--no-secondary", action="store_true", help="skip the compact legs for BASELINE configs 2 (turbo, 30 s, 1 stream) and 5 (fp8, 15 s)")
@@ -550,7 +551,7 @@ def main(argv=None):
             from thewhisper_amd.overlap import EncoderOverlap
             eng2 = make_engine()
             eng2.load_state_dict(sd)
-            overlap = EncoderOverlap([eng, eng2], encoder_cus=args.encoder_cus)
+            overlap = EncoderOverlap([eng, eng2], encoder_cus=args.encoder_cus, decoder_cus=args.decoder_cus or None)
             overlap_note = (f"encoder stage of batch k+1 on {args.encoder_cus} CUs (second context) under the decode loop of "
                             f"batch k on the other CUs")
         except Exception as e:  # noqa: BLE001 - the overlap is a schedule, not a requirement: run the stages back to back

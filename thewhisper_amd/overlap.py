@@ -92,9 +92,11 @@ class EncoderOverlap:
     """Runs ``encode_fn(engine, batch)`` of batch k + 1 on ``encoder_cus`` compute units while ``decode_fn(engine, batch,
     encoded)`` of batch k runs on the others.  ``engines``: two contexts built from the same weights, same device."""
 
-    def __init__(self, engines: Sequence[WhisperEngine], encoder_cus: int = 64, cu_range: Optional[Sequence[int]] = None):
+    def __init__(self, engines: Sequence[WhisperEngine], encoder_cus: int = 64, cu_range: Optional[Sequence[int]] = None,
+                 decoder_cus: Optional[int] = None):
         """``cu_range = (first, last)`` restricts the whole pipeline to a slice of the chip (several pipelines side by side);
-        default: all compute units.  The last ``encoder_cus`` CUs of the range run the encoder stage."""
+        default: all compute units.  The last ``encoder_cus`` CUs of the range run the encoder stage, the first ``decoder_cus``
+        (default: all the others) the decode loop."""
         if len(engines) != 2:
             raise ValueError("EncoderOverlap needs exactly two contexts")
         self.engines = list(engines)
@@ -106,7 +108,10 @@ class EncoderOverlap:
         self.encoder_cus, self.n_cus = int(encoder_cus), int(n_cus)
         hip = _hiplib()
         dev = self.device.index or 0
-        self.s_dec = masked_stream(lo, hi - encoder_cus, n_cus, dev)
+        n_dec = hi - lo - encoder_cus if decoder_cus is None else int(decoder_cus)
+        if not 0 < n_dec <= hi - lo - encoder_cus:
+            raise ValueError(f"bad CU partition: {n_dec} decoder CUs next to {encoder_cus} encoder CUs in [{lo}, {hi})")
+        self.s_dec = masked_stream(lo, lo + n_dec, n_cus, dev)
         self.s_enc = masked_stream(hi - encoder_cus, hi, n_cus, dev)
         self.s_all = masked_stream(lo, hi, n_cus, dev)     # the first batch's encoder stage: nothing else is running yet
         self._events: List[int] = [hip.event_create(dev) for _ in range(2)]
