@@ -263,6 +263,47 @@ def test_w8a16_groups_of_streams_match_single_group():
         make_engine(dims, w, T=T, max_batch=B, dtype="fp8a8")
 
 
+def test_the_greedy_loop_on_its_own_stream_gives_the_callers_stream_results(monkeypatch):
+    """`WhisperEngine.generate_greedy` runs the loop on a stream confined to 160 compute units when the caller manages no streams
+    (engine.py: _decode_stream; THEWHISPER_DECODE_CUS=0 keeps the caller's stream).  Same kernels, ordered behind the encoder stage
+    by an event: ids, lengths and token timestamps are identical, also when calls alternate with encoder stages of new audio (the
+    ordering between the two streams is what could go wrong) and for a forced-prefix call (which keeps the caller's stream)."""
+    dims = dims_variant("micro", enc_layers=2, dec_layers=2)
+    w = wo.make_weights(dims, 21)
+    T, B = 150, 3
+    heads = [(0, 1), (1, 0)]
+    kinds = (["speechlike", "noise", "sine"], ["noise", "sine", "speechlike"], ["sine", "speechlike", "zeros"])
+    mels = [torch.from_numpy(wo.log_mel(clips(T * 320, k), dims.n_mels)).cuda() for k in kinds]
+    prompt = np.tile(np.array(PROMPT), (B, 1))
+
+    def run():
+        eng = make_engine(dims, w, T=T, max_batch=B, dtype="bf16", heads=heads, use_graph=True)
+        out = []
+        for mel in mels:
+            eng.encode(mel)
+            eng.cross_kv(B)
+            g = eng.generate_greedy(prompt, max_new_tokens=24, timestamps=True, want_alignment=True)
+            ts = eng.token_timestamps(B, prompt.shape[1], g["length"], [2 * T] * B)
+            out.append((g["sequences"].copy(), ts.copy()))
+        forced = np.concatenate([prompt, out[-1][0][:, prompt.shape[1] : prompt.shape[1] + 4].astype(np.int32)], axis=1)
+        if not (forced[:, prompt.shape[1] :] == 50257).any():
+            g = eng.generate_greedy(forced, max_new_tokens=24, timestamps=True, want_alignment=True, n_forced=4)
+            out.append((g["sequences"].copy(), None))
+        used = eng.__dict__.get("_dec_stream")
+        eng.close()
+        return out, used
+
+    monkeypatch.setenv("THEWHISPER_DECODE_CUS", "0")
+    plain, used0 = run()
+    monkeypatch.setenv("THEWHISPER_DECODE_CUS", "160")
+    masked, used1 = run()
+    assert used0 is None and used1 is not None
+    assert len(plain) == len(masked)
+    for (a, ta), (b, tb) in zip(plain, masked):
+        assert np.array_equal(a, b)
+        assert (ta is None and tb is None) or np.array_equal(ta, tb)
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp8a16"])
 def test_sibling_context_and_adopted_cross_kv_are_bit_identical(dtype):
     """tw_create_sibling + tw_adopt_cross_kv (the serving loop's prefetch path): clips encoded by a sibling context (shared
