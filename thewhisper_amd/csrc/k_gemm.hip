@@ -306,6 +306,126 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[NT][MT], int 
   }
 }
 
+// Epilogue of the large-M kernel for 16-bit outputs whose rows are CONTIGUOUS over the wavefront's 64 columns (EPI_ROWMAJOR; the q and
+// k segments of EPI_QKV_ENC, where the 64 columns are one head), staged through LDS.  Measured with the epilogue compiled out
+// (profiles/r04_gemm_parts.txt): it was 40-45 % of every encoder GEMM (fc1 141 -> 77 us, QKV 103 -> 62, out-projection 44 -> 27) - in
+// gemm_epilogue a lane owns 4 consecutive columns of one row, so a store instruction writes sixteen 32-byte pieces and a 128-byte line
+// of the output is written by four instructions (and the residual read by four).  Here the wavefront writes its float32 values into its
+// share of the (idle) activation ring, RB x 16 rows at a time, and reads them back so that 8 lanes cover one row: every store - and the
+// residual load - is 16 bytes per lane, 8 full lines per instruction.  The values are staged in float32: bias / LayerNorm fold / GELU
+// before, residual add and the ONE rounding to T after, exactly as in gemm_epilogue.  LDS operations of a wavefront execute in order, so
+// no barrier is needed between its writes and its reads.  Row stride 68 floats (16-byte aligned, rows 4 banks apart).
+constexpr int TW_STAGE_LD = 68;
+template <typename T, int NT, int MT, int RB>
+__device__ __forceinline__ void gemm_epilogue_staged(const f32x4_t (&acc)[NT][MT], int m_base, int n_base, int M, int N,
+                                                     const GemmEpilogue& ep, int fr, int fq, int lane, const f32x2_t* ln_rows,
+                                                     float* stage) {
+  static_assert(NT == 4 && sizeof(T) == 2, "64 columns of 16-bit elements per wavefront");
+  const T* bias = reinterpret_cast<const T*>(ep.bias);
+  const T* res = reinterpret_cast<const T*>(ep.res);
+  const bool ln = ln_rows != nullptr;
+  f32x4_t ln_gw[NT], ln_cb[NT], bv[NT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a) {
+    const int n = n_base + a * 16 + fq * 4;
+    bv[a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (ln) {
+      ln_gw[a] = *reinterpret_cast<const f32x4_t*>(ep.ln_gw + n);
+      ln_cb[a] = *reinterpret_cast<const f32x4_t*>(ep.ln_cb + n);
+    } else if (bias) {
+      Vec4<T> b4;
+      b4.load(bias + n);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[a][r] = b4.get(r);
+    }
+  }
+  // where this wavefront's rows go: EPI_ROWMAJOR out + cmap(m) + n; EPI_QKV_ENC (segment 0 / 1) ((b*H + h)*T + t)*64 + dd
+  const int dmodel = ep.H * 64;
+  const int seg = ep.mode == EPI_QKV_ENC ? n_base / dmodel : 0;
+  const int head = ep.mode == EPI_QKV_ENC ? (n_base - seg * dmodel) >> 6 : 0;
+  T* const obase = reinterpret_cast<T*>(seg == 0 ? ep.out : ep.out2);
+  const int prow = lane >> 3, pcol = (lane & 7) * 8;   // read-back role: row prow (+ 8 i) of the chunk, columns pcol .. pcol + 7
+#pragma unroll
+  for (int b0 = 0; b0 < MT; b0 += RB) {
+    constexpr int dummy = 0; (void)dummy;
+    const int nb = (MT - b0) < RB ? (MT - b0) : RB;     // 16-row tiles in this chunk (compile-time after unrolling)
+#pragma unroll
+    for (int bb = 0; bb < RB; ++bb) {
+      if (bb >= nb) break;
+      const int b = b0 + bb;
+      float ln_nmean = 0.f, ln_rstd = 1.f;
+      if (ln) {
+        const f32x2_t v = ln_rows[b * 16 + fr];
+        ln_nmean = -v[0];
+        ln_rstd = v[1];
+      }
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        f32x4_t v = acc[a][b];
+        if (ln) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaf(ln_rstd, fmaf(ln_nmean, ln_gw[a][r], v[r]), ln_cb[a][r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += bv[a][r];
+        }
+        if (ep.gelu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_exact<T>(v[r]);
+        }
+        *reinterpret_cast<f32x4_t*>(stage + (bb * 16 + fr) * TW_STAGE_LD + a * 16 + fq * 4) = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * RB; ++i) {
+      if (i >= 2 * nb) break;
+      const int row = i * 8 + prow;
+      const int m = m_base + b0 * 16 + row;
+      const bool ok = m < M;
+      const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(stage + row * TW_STAGE_LD + pcol);
+      const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(stage + row * TW_STAGE_LD + pcol + 4);
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      if (res && ok) {
+        const long long roff = rowmap(ep.res_map, ep.res_mod > 0 ? (m % ep.res_mod) : m);
+        const uint4 rq = *reinterpret_cast<const uint4*>(res + roff + n_base + pcol);
+        const T* rt = reinterpret_cast<const T*>(&rq);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += (float)rt[r];
+      }
+      Vec4<T> o0, o1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { o0.set(r, v[r]); o1.set(r, v[4 + r]); }
+      if (ep.stats_out) {   // (sum, sum of squares) of the values AS STORED, per row and 32-column block: 4 lanes x 8 columns
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float x0 = ok ? o0.get(r) : 0.f, x1 = ok ? o1.get(r) : 0.f;
+          s += x0 + x1;
+          ss = fmaf(x0, x0, fmaf(x1, x1, ss));
+        }
+        s += __shfl_xor(s, 1);
+        ss += __shfl_xor(ss, 1);
+        s += __shfl_xor(s, 2);
+        ss += __shfl_xor(ss, 2);
+        if ((lane & 3) == 0 && ok)
+          reinterpret_cast<f32x2_t*>(ep.stats_out)[(long long)m * (N / 32) + (n_base + pcol) / 32] = f32x2_t{s, ss};
+      }
+      if (!ok) continue;
+      T* dst;
+      if (ep.mode == EPI_ROWMAJOR) {
+        dst = obase + rowmap(ep.c_map, m) + n_base + pcol;
+      } else {
+        const int bidx = m / ep.T, t = m - bidx * ep.T;
+        dst = obase + ((long long)(bidx * ep.H + head) * ep.T + t) * 64 + pcol;
+      }
+      uint4 q;
+      *reinterpret_cast<uint2*>(&q.x) = *reinterpret_cast<const uint2*>(o0.e);
+      *reinterpret_cast<uint2*>(&q.z) = *reinterpret_cast<const uint2*>(o1.e);
+      *reinterpret_cast<uint4*>(dst) = q;
+    }
+  }
+}
+
 // Epilogue of the cross-K/V projection in TW_BF16_MXFP8 contexts: the wavefront's 64 columns are exactly one head of K or of
 // V, so the per-key maximum over the head is 16 in-lane values and two lane swaps; every key gets one power-of-two scale
 // byte (sb = max(E - 7, 1), E = biased exponent of the maximum: the rule of sk_quant_mx8 in k_decode.hip) and its 64 values
@@ -643,6 +763,20 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_wreg_kernel(const T* __restri
     if (kt + 1 < nk) step(kt + 1, w1, w0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant tail requests must not outlive the LDS allocation
+  if constexpr (sizeof(T) == 2) {
+    // rows contiguous over this wavefront's 64 columns: the epilogue staged through this wavefront's share of the ring
+    constexpr int WAVE_FLOATS = ST * STAGE * 4 / NW;
+    constexpr int RB = WAVE_FLOATS >= 2 * 16 * TW_STAGE_LD ? 2 : 1;
+    static_assert(WAVE_FLOATS >= 16 * TW_STAGE_LD, "a 16-row chunk per wavefront");
+    const bool rows64 = n0 + 64 <= N && (ep.mode == EPI_ROWMAJOR || (ep.mode == EPI_QKV_ENC && n0 < 2 * ep.H * 64));
+    if (ep.staged && rows64) {   // (wavefront-uniform; the barrier below is reached by every wavefront: ep.staged is a launch constant)
+      tw_barrier_only();         // every wavefront has read its last fragments and every DMA has landed: the ring is free
+      gemm_epilogue_staged<T, NT, MT, RB>(acc, m0, n0, M, N, ep, fr, fq, lane, ep.stats_in ? ln_rows : nullptr,
+                                          reinterpret_cast<float*>(lds) + wave * WAVE_FLOATS);
+      return;
+    }
+    if (ep.staged) tw_barrier_only();   // (the V^T tiles of the QKV projection: keep the barrier count equal across the workgroup)
+  }
   if (ep.mode == EPI_KV_CROSS8) gemm_epilogue_kv8<T, NT, MT>(acc, m0, n0, M, N, ep, fr, fq);
   else gemm_epilogue<T, NT, MT>(acc, m0, n0, M, N, ep, fr, fq, ep.stats_in ? ln_rows : nullptr);
 }
@@ -765,7 +899,10 @@ static hipError_t gemm_dispatch(const void* A, RowMap amap, const void* W, int M
 }
 
 hipError_t launch_gemm(int dtype, const void* A, RowMap amap, const void* W, int M, int N, int K,
-                       const GemmEpilogue& ep, hipStream_t st) {
+                       const GemmEpilogue& ep0, hipStream_t st) {
+  static const int staged = gemm_env("TW_GEMM_STAGED", 1);   // 0: the round-3 epilogue everywhere (A/B runs)
+  GemmEpilogue ep = ep0;
+  ep.staged = staged;
   if (dtype == 1) return gemm_dispatch<bf16_t>(A, amap, W, M, N, K, ep, st);
   if (dtype == 2) return gemm_dispatch<f16_t>(A, amap, W, M, N, K, ep, st);
   return gemm_dispatch<float>(A, amap, W, M, N, K, ep, st);

@@ -175,6 +175,7 @@ struct GemmEpilogue {
   // residual stream, y = rstd (acc - mean gw[n]) + cb[n] with (mean, rstd) of row m from stats_in[m][0 .. parts); `bias` is then null
   // (cb contains it).  No normalised copy of the stream is written or read and two launches per layer disappear.
   float* stats_out;
+  int staged;   // set by launch_gemm: the large-M kernel stages row-contiguous 16-bit outputs through LDS (gemm_epilogue_staged)
   const float* stats_in; int stats_in_parts;
   const float* ln_gw; const float* ln_cb;
 };
