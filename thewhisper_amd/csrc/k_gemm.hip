@@ -426,6 +426,74 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4_t (&acc)[NT][MT
   }
 }
 
+// The V segment of EPI_QKV_ENC through the same staging: the output is V^T ([stream, head][64 dims][Tp keys]), so the wavefront writes
+// its values TRANSPOSED into LDS ([dim][token of the chunk], conflict-free: 16 tokens x 4 dims apart by 16 banks) and every lane reads
+// 4 consecutive tokens of one dim back: 8-byte stores, 8 lanes = 64 contiguous bytes of a V^T row, instead of one 2-byte store per
+// element.  4 consecutive tokens never straddle two clips (the caller guarantees T % 4 == 0 and the chunk starts on a multiple of 16).
+template <typename T, int NT, int MT, int RB>
+__device__ __forceinline__ void gemm_epilogue_staged_vt(const f32x4_t (&acc)[NT][MT], int m_base, int n_base, int M, int N,
+                                                        const GemmEpilogue& ep, int fr, int fq, int lane, const f32x2_t* ln_rows,
+                                                        float* stage) {
+  static_assert(NT == 4 && sizeof(T) == 2, "64 columns of 16-bit elements per wavefront");
+  constexpr int LD = RB * 16 + 4;     // floats per dim row of the transposed chunk
+  const T* bias = reinterpret_cast<const T*>(ep.bias);
+  const bool ln = ln_rows != nullptr;
+  f32x4_t ln_gw[NT], ln_cb[NT], bv[NT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a) {
+    const int n = n_base + a * 16 + fq * 4;
+    bv[a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (ln) {
+      ln_gw[a] = *reinterpret_cast<const f32x4_t*>(ep.ln_gw + n);
+      ln_cb[a] = *reinterpret_cast<const f32x4_t*>(ep.ln_cb + n);
+    } else if (bias) {
+      Vec4<T> b4;
+      b4.load(bias + n);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[a][r] = b4.get(r);
+    }
+  }
+  const int dmodel = ep.H * 64;
+  const int head = (n_base - 2 * dmodel) >> 6;
+  T* const obase = reinterpret_cast<T*>(ep.out3);
+#pragma unroll
+  for (int b0 = 0; b0 < MT; b0 += RB) {
+    const int nb = (MT - b0) < RB ? (MT - b0) : RB;
+#pragma unroll
+    for (int bb = 0; bb < RB; ++bb) {
+      if (bb >= nb) break;
+      const int b = b0 + bb;
+      float ln_nmean = 0.f, ln_rstd = 1.f;
+      if (ln) {
+        const f32x2_t v = ln_rows[b * 16 + fr];
+        ln_nmean = -v[0];
+        ln_rstd = v[1];
+      }
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[a][b][r];
+          v = ln ? fmaf(ln_rstd, fmaf(ln_nmean, ln_gw[a][r], v), ln_cb[a][r]) : v + bv[a][r];
+          stage[(a * 16 + fq * 4 + r) * LD + bb * 16 + fr] = v;
+        }
+      }
+    }
+    const int G = nb * 4;                 // groups of 4 tokens per dim in this chunk
+    for (int task = lane; task < 64 * G; task += 64) {
+      const int dd = task / G, g = task - dd * G;
+      const f32x4_t v = *reinterpret_cast<const f32x4_t*>(stage + dd * LD + g * 4);
+      const int m = m_base + b0 * 16 + g * 4;
+      if (m >= M) continue;               // (M % 4 == 0: the 4 tokens are in or out together)
+      const int bidx = m / ep.T, t = m - bidx * ep.T;
+      Vec4<T> o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o.set(r, v[r]);
+      *reinterpret_cast<uint2*>(obase + ((long long)(bidx * ep.H + head) * 64 + dd) * ep.Tp + t) = *reinterpret_cast<const uint2*>(o.e);
+    }
+  }
+}
+
 // Epilogue of the cross-K/V projection in TW_BF16_MXFP8 contexts: the wavefront's 64 columns are exactly one head of K or of
 // V, so the per-key maximum over the head is 16 in-lane values and two lane swaps; every key gets one power-of-two scale
 // byte (sb = max(E - 7, 1), E = biased exponent of the maximum: the rule of sk_quant_mx8 in k_decode.hip) and its 64 values
@@ -775,7 +843,14 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_wreg_kernel(const T* __restri
                                           reinterpret_cast<float*>(lds) + wave * WAVE_FLOATS);
       return;
     }
-    if (ep.staged) tw_barrier_only();   // (the V^T tiles of the QKV projection: keep the barrier count equal across the workgroup)
+    if (ep.staged) tw_barrier_only();   // (keep the barrier count equal across the workgroup)
+    constexpr int RBT = WAVE_FLOATS >= 64 * (2 * 16 + 4) ? 2 : 1;
+    static_assert(WAVE_FLOATS >= 64 * (16 + 4), "a transposed 16-token chunk per wavefront");
+    if (ep.staged == 1 && ep.mode == EPI_QKV_ENC && n0 >= 2 * ep.H * 64 && n0 + 64 <= N && ep.T % 4 == 0 && M % 4 == 0) {   // the V segment
+      gemm_epilogue_staged_vt<T, NT, MT, RBT>(acc, m0, n0, M, N, ep, fr, fq, lane, ep.stats_in ? ln_rows : nullptr,
+                                              reinterpret_cast<float*>(lds) + wave * WAVE_FLOATS);
+      return;
+    }
   }
   if (ep.mode == EPI_KV_CROSS8) gemm_epilogue_kv8<T, NT, MT>(acc, m0, n0, M, N, ep, fr, fq);
   else gemm_epilogue<T, NT, MT>(acc, m0, n0, M, N, ep, fr, fq, ep.stats_in ? ln_rows : nullptr);
@@ -900,7 +975,7 @@ static hipError_t gemm_dispatch(const void* A, RowMap amap, const void* W, int M
 
 hipError_t launch_gemm(int dtype, const void* A, RowMap amap, const void* W, int M, int N, int K,
                        const GemmEpilogue& ep0, hipStream_t st) {
-  static const int staged = gemm_env("TW_GEMM_STAGED", 1);   // 0: the round-3 epilogue everywhere (A/B runs)
+  static const int staged = gemm_env("TW_GEMM_STAGED", 1);   // 0: the round-3 epilogue everywhere, 2: not for the V^T segment (A/B runs)
   GemmEpilogue ep = ep0;
   ep.staged = staged;
   if (dtype == 1) return gemm_dispatch<bf16_t>(A, amap, W, M, N, K, ep, st);
