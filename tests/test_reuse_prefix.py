@@ -54,6 +54,19 @@ def check_same_buffer_is_exact(plain, reuse):
     other = reuse.transcribe(audio.copy(), 4.0, 16000)
     assert reuse.reuse_stats["reused"] == 1
     assert [w["text"] for w in other] == [w["text"] for w in want]
+    # same start time and length but OTHER audio (a second session on a shared backend, a restarted stream): nothing is forced,
+    # the result is the plain backend's
+    other_audio = wo.synth_audio(16000 * 6, 8, "speechlike")
+    reuse.transcribe(other_audio.copy(), 4.0, 16000)
+    assert reuse.reuse_stats["reused"] == 1
+    again2 = reuse.transcribe(audio.copy(), 4.0, 16000)
+    assert reuse.reuse_stats["reused"] == 1 and [w["text"] for w in again2] == [w["text"] for w in want]
+    # reset(): what a scheduler's clear() calls - the same buffer again is decoded afresh
+    reuse.reset()
+    reuse.transcribe(audio.copy(), 4.0, 16000)
+    assert reuse.reuse_stats["reused"] == 1
+    reuse.transcribe(audio.copy(), 4.0, 16000)
+    assert reuse.reuse_stats["reused"] == 2
 
 
 def test_off_by_default_and_exact_when_the_premise_holds():

@@ -318,3 +318,76 @@ def test_continuous_hub_isolates_bad_requests_and_survives_an_engine_fault():
     finally:
         eng.generate_greedy = inner
         hub.close()
+
+
+class _NoEngineBackend:
+    """Just enough of a backend for a hub whose worker never sees a request (bookkeeping tests)."""
+
+    class _P:
+        class model:
+            class engine:
+                max_batch = 4
+
+    asr_pipeline = _P()
+
+
+def test_gather_window_decays_and_answer_table_is_pruned():
+    """the turnaround estimate must not outlive the closed-loop callers that produced it, and the table of answered
+    streams is pruned whether or not anybody gathers."""
+    import time
+    from concurrent.futures import Future
+
+    from thewhisper_amd.serving import BatchingHub
+
+    hub = BatchingHub(_NoEngineBackend(), max_batch=4, continuous=False)
+    try:
+        now = time.monotonic()
+        with hub._lock:
+            for i in range(8):                                     # a burst of closed-loop callers, 20-90 ms turnaround
+                hub._turns.append((now - 0.5, 0.02 + 0.01 * i))
+            hub._refresh_turnaround(now)
+        assert 0.07 <= hub._turn_ema <= 0.091                     # 90th percentile of the recent samples
+        hub._answered[1] = now
+        hub._last_answer_t = now
+        assert hub._gather_until(now) > now                        # a stream answered a moment ago: the intake stays open
+        # ... ten seconds later nobody of that burst is around any more: no estimate, no gathering
+        with hub._lock:
+            hub._turns.clear()
+            for i in range(8):
+                hub._turns.append((now - 60.0, 0.05))
+            hub._answered[2] = time.monotonic()
+            hub._last_answer_t = time.monotonic()
+        d = time.monotonic() + 0.001
+        assert hub._gather_until(d) == d and hub._turn_ema == 0.0
+        # real-time sessions only (_turn_ema stays 0): one entry per stream id, pruned by _answer itself
+        old = time.monotonic() - 5.0
+        with hub._lock:
+            hub._answered = {1000 + k: old for k in range(300)}
+        f = Future()
+        f.stream_id = 7
+        f.t_submit = time.monotonic()
+        hub._answer(f, result=[])
+        assert set(hub._answered) == {7}
+    finally:
+        hub.close()
+
+
+def test_prefetcher_take_skips_rows_of_failed_requests():
+    import collections
+    import threading
+
+    from thewhisper_amd.serving import _Prefetcher
+
+    pf = _Prefetcher.__new__(_Prefetcher)
+    pf.lock, pf.dead, pf.ahead, pf.count = threading.Lock(), set(), [], 5
+    w = [object() for _ in range(5)]
+    pf.pre = collections.deque((w[i], i, f"seg{i}") for i in range(5))
+    pf.ahead = [w[4], object()]
+    pf.drop({id(w[0]), id(w[2]), id(w[4])})
+    assert len(pf.ahead) == 1
+    works, slot0, keep = pf.take(4)
+    assert works == [w[1]] and slot0 == 1 and keep == ["seg1"]    # the run of consecutive slots ends in front of a dead row
+    works, slot0, _ = pf.take(4)
+    assert works == [w[3]] and slot0 == 3
+    works, slot0, _ = pf.take(4)
+    assert works == [] and pf.count == 0 and not pf.dead

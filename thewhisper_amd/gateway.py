@@ -452,7 +452,9 @@ def build_host(argv: Optional[List[str]] = None):
     ap.add_argument("--port", type=int, default=8000)
     ap.add_argument("--auth-token", default="")
     ap.add_argument("--language", default="en")
-    ap.add_argument("--dtype", default=None, choices=[None, "bf16", "fp16", "fp32"], help="compute dtype (default: the checkpoint's)")
+    ap.add_argument("--dtype", default=None, choices=[None, "bf16", "fp16", "fp32"], help="compute dtype of the engine context (default: fp16 - what the reference's streaming backend asks its platform "
+                         "pipelines for, R:thestage_speechkit/streaming/streaming_pipeline.py:369-370; a float16 CONTEXT since round 4, "
+                         "rounds 1-3 ran such requests in bf16: pass bf16 for that arithmetic)")
     ap.add_argument("--prefetch-cus", type=int, default=0,
                     help="compute units of the side stream that encodes, under the running pass's decode loop, the rows that sit that "
                          "pass out (arrivals; with more requests in flight than --max-batch also the chunks waiting for their next "

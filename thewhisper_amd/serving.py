@@ -78,6 +78,7 @@ class _Prefetcher:
         self.stop = False
         self.pre: "collections.deque" = collections.deque()    # (work, side slot, segment tensor), slot order
         self.ahead: List[Any] = []            # chunks of requests in flight that sit the running pass out: encoded first, in one call
+        self.dead: set = set()                # ids of pre-encoded chunks whose request has failed (drop)
         self.new_jobs: List[Any] = []
         self.count = 0                        # filled slots of the sibling context
         self.thread = threading.Thread(target=self._run, name="thewhisper-prefetch", daemon=True)
@@ -101,6 +102,11 @@ class _Prefetcher:
         """Up to `free` pre-encoded rows from the front (consecutive sibling slots): ([works], first slot, [tensors to keep])."""
         works, keep, slot0 = [], [], None
         while self.pre and len(works) < free:
+            if id(self.pre[0][0]) in self.dead:     # a chunk of a request that has failed meanwhile (drop): nobody waits for it
+                if works:
+                    break                           # ... and the run of CONSECUTIVE slots ends in front of it
+                self.pre.popleft()
+                continue
             w, slot, seg = self.pre.popleft()
             if slot0 is None:
                 slot0 = slot
@@ -108,7 +114,15 @@ class _Prefetcher:
             keep.append(seg)
         if not self.pre:
             self.count = 0        # tw_adopt_cross_kv orders the sibling's next launches behind the copies
+            self.dead.clear()
         return works, slot0, keep
+
+    def drop(self, dead_ids):
+        """(batcher thread, prefetcher paused)  Forget the chunks of failed requests: not encoded ahead any more, and their
+        pre-encoded rows are skipped by `take` (their sibling slots stay unused until the queue has drained)."""
+        with self.lock:       # (the prefetcher may be running: a failed pass.run() is reported after resume())
+            self.ahead = [w for w in self.ahead if id(w) not in dead_ids]
+            self.dead |= set(dead_ids)
 
     def shutdown(self):
         self.stop = True
@@ -200,7 +214,11 @@ class _Prefetcher:
         job.future = fut
         n = len(job.works)
         if self.count + n > self.cap:
-            # does not fit the sibling's free slots: the batcher takes it through the ordinary path (opened already)
+            # does not fit the sibling's free slots: the batcher takes it through the ordinary path (opened already).  Its log-mel
+            # was enqueued on THIS thread's stream and the batcher slices it on its own: nothing but the legacy null stream's
+            # implicit ordering would hold the two apart, so the hand-over waits for the features (rare path, ~0.1 ms)
+            if self.stream is not None:
+                torch.cuda.current_stream().synchronize()
             self.new_jobs.append(job)
             return
         try:
@@ -240,7 +258,8 @@ class BatchingHub:
         self.gather_s = float(gather_s)
         self._last_answer_t = 0.0
         self._turn_ema = 0.0                       # seconds; 0 = no closed-loop caller seen (reported by /health)
-        self._turns: "collections.deque[float]" = collections.deque(maxlen=64)   # recent turnaround samples
+        self._turns: "collections.deque[Tuple[float, float]]" = collections.deque(maxlen=64)   # recent (when, turnaround) samples
+        self.turn_horizon_s = 10.0                 # samples older than this no longer describe who is calling: the estimate decays to 0
         self._answered: Dict[int, float] = {}      # stream id -> when its last request was answered (cleared when it asks again)
         self._q: "queue.Queue[Optional[Tuple[np.ndarray, float, int, Future]]]" = queue.Queue(maxsize=max_pending)
         self._closed = False
@@ -289,14 +308,23 @@ class BatchingHub:
             if stream_id is not None:
                 t_ans = self._answered.pop(stream_id, None)
                 if t_ans is not None and fut.t_submit - t_ans < 0.25:      # type: ignore[attr-defined]
-                    d = fut.t_submit - t_ans                               # type: ignore[attr-defined]
-                    self._turns.append(d)
-                    # the window has to cover the SLOW returners (a pass started without them leaves them a pass of their own):
-                    # 90th percentile of the recent samples
-                    srt = sorted(self._turns)
-                    self._turn_ema = srt[min(len(srt) - 1, int(0.9 * len(srt)))]
+                    self._turns.append((fut.t_submit, fut.t_submit - t_ans))  # type: ignore[attr-defined]
+                    self._refresh_turnaround(fut.t_submit)                 # type: ignore[attr-defined]
             self._q.put_nowait((np.asarray(audio), float(buffer_start_time), int(sample_rate), fut))
         return fut
+
+    def _refresh_turnaround(self, now: float):
+        """(lock held)  The gather window has to cover the SLOW returners (a pass started without them leaves them a pass of their
+        own): 90th percentile of the turnaround samples taken within the last `turn_horizon_s`.  Samples only ever arrive from
+        closed-loop callers (< 0.25 s), so without the horizon one burst of them (a benchmark, a fast client) would keep later
+        real-time sessions waiting for streams that are not coming back; with none recent the estimate is 0 = no gathering."""
+        while self._turns and now - self._turns[0][0] > self.turn_horizon_s:
+            self._turns.popleft()
+        if not self._turns:
+            self._turn_ema = 0.0
+            return
+        srt = sorted(d for _, d in self._turns)
+        self._turn_ema = srt[min(len(srt) - 1, int(0.9 * len(srt)))]
 
     def close(self):
         """Stops the worker; requests still parked are failed (their sessions would otherwise wait forever)."""
@@ -330,6 +358,8 @@ class BatchingHub:
             self._last_answer_t = now
             if sid is not None:
                 self._answered[sid] = now
+                if len(self._answered) > 256:    # streams that went away: forget answers older than any turnaround that counts
+                    self._answered = {k: t for k, t in self._answered.items() if now - t < 0.25}
         if exc is not None:
             fut.set_exception(exc)
         else:
@@ -369,8 +399,9 @@ class BatchingHub:
             return deadline
         now = time.monotonic()
         with self._lock:
-            if len(self._answered) > 256:    # streams that went away: forget answers older than any turnaround that counts
-                self._answered = {k: t for k, t in self._answered.items() if now - t < 0.25}
+            self._refresh_turnaround(now)    # the estimate decays: no closed-loop caller for `turn_horizon_s` = no gathering
+            if self._turn_ema <= 0.0:
+                return deadline
             pending = any(now - t < 0.25 for t in self._answered.values())
             last = self._last_answer_t
         if not pending:
@@ -404,6 +435,11 @@ class BatchingHub:
             for j in hit:
                 self._answer(j.future, exc=exc)
             jobs = [j for j in jobs if j not in hit]
+            if pf is not None and hit:
+                # their other chunks must not be adopted or encoded ahead any more: the futures are answered, the rows would only
+                # occupy later passes (and a chunk of a dead job that exceeds MAX_SEEK_PASSES would fail the LIVE jobs of its pass)
+                dead = set(id(w) for j in hit for w in j.works)
+                pf.drop(dead)
 
         def shutdown():
             if pf is not None:
@@ -441,7 +477,8 @@ class BatchingHub:
             if pf is not None and pf.pre and room() > 0:
                 ws, slot0, keep = pf.take(room())
                 try:
-                    pas.adopt(ws, pf.side, slot0)
+                    if ws:
+                        pas.adopt(ws, pf.side, slot0)
                     pas._keep.extend(keep)
                     adopted = ws
                 except Exception as e:  # noqa: BLE001

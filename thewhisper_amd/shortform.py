@@ -260,6 +260,7 @@ class Pass:
             w.seek += offset
             w.segments += segments
             w.passes += 1
+            w.forced = None        # a prefix is forced ONCE: a chunk whose seek stays at 0 decodes its next iteration afresh
 
 
 def next_segment(work: ChunkWork, T: int) -> torch.Tensor:

@@ -47,7 +47,11 @@ class AMDWhisperBackend:
         buffer's end to the greedy loop as forced output - one batched prefill (tw_greedy_opts::n_forced) instead of one decode
         step each - and decodes only the tail.  The audio those tokens belong to is unchanged, but the encoder is not causal and
         the log-mel clamp is global, so the forced tokens need not be what a fresh decode would pick: an approximation, whose
-        delta bench.py / tests measure.  ``reuse_stats`` counts calls, reused calls and forced tokens."""
+        delta bench.py / tests measure.  ``reuse_stats`` counts calls, reused calls and forced tokens.
+        The option needs ONE BACKEND PER STREAM (the state of the previous call lives in the backend): besides the start time and the
+        length, a call must begin with exactly the samples of its predecessor's buffer to reuse anything - a backend shared between
+        sessions (gateway._LockedBackend, two schedulers on one pipeline) therefore never forces tokens of other audio, it just
+        decodes afresh - and ``reset()`` (what a scheduler's ``clear()`` should call) forgets the previous call."""
         from .asr_pipeline import ASRPipeline
 
         if torch_dtype is None:
@@ -91,13 +95,24 @@ class AMDWhisperBackend:
         return self._to_tokens(result, len(audio) / sample_rate, buffer_start_time)
 
     # -- decoder-side reuse between the ticks of one stream (opt-in) -------------------------------
-    def _forced_prefix(self, n_samples: int, buffer_start_time: float, sample_rate: int) -> Optional[np.ndarray]:
+    def reset(self) -> None:
+        """Forget the previous call (``reuse_committed_prefix``): the next buffer is decoded afresh.  For the owner of the stream to
+        call when its scheduler restarts at t = 0 (R:thestage_speechkit/streaming/streaming_pipeline.py:953-976 ``clear``)."""
+        self._last = None
+
+    def _forced_prefix(self, audio: np.ndarray, buffer_start_time: float, sample_rate: int) -> Optional[np.ndarray]:
         """Tokens of the previous call that may be forced in this one, or None.  Eligible: same buffer start, buffer not shorter
         (the scheduler appended audio; a trimmed buffer starts elsewhere and is decoded afresh).  Kept: the longest prefix whose
         token timestamps (DTW, seconds from the buffer start) end ``reuse_margin_s`` before the OLD buffer's end - the audio
         behind them has had its right context for at least that long."""
         last = self._last
+        n_samples = len(audio)
         if last is None or abs(last["start"] - buffer_start_time) > 1e-6 or n_samples < last["n_samples"] or last["sr"] != sample_rate:
+            return None
+        # ... and it must BE the previous buffer plus new audio: same start and length alone also match another session's buffer or
+        # a restarted stream (0.64 MB compared per 10 s: ~0.1 ms)
+        prev = last["audio"]
+        if audio.dtype != prev.dtype or not np.array_equal(audio[: len(prev)], prev):
             return None
         ids, ts = last["ids"], last["ts"]
         if ids is None or ts is None or len(ids) == 0:
@@ -132,7 +147,7 @@ class AMDWhisperBackend:
             self._last = None
             forced = None
         else:
-            forced = self._forced_prefix(len(audio), buffer_start_time, sample_rate)
+            forced = self._forced_prefix(audio, buffer_start_time, sample_rate)
             budget = int(codec.plan.greedy.get("max_new_tokens", 128))
             if forced is not None and len(forced) >= budget - 1:
                 forced = forced[: max(0, budget - 2)]
@@ -148,7 +163,8 @@ class AMDWhisperBackend:
         if len(job.works) == 1 and job.works[0].first_pass is not None:
             ids, ts = job.works[0].first_pass
             self.reuse_stats["decoded_tokens"] += int(len(ids)) - (int(len(forced)) if forced is not None else 0)
-            self._last = {"start": buffer_start_time, "n_samples": len(audio), "sr": sample_rate, "ids": ids, "ts": ts}
+            self._last = {"start": buffer_start_time, "n_samples": len(audio), "sr": sample_rate, "ids": ids, "ts": ts,
+                          "audio": np.array(audio, copy=True)}
         return codec.close(job)
 
     def transcribe_many(self, requests, batch_size: Optional[int] = None) -> List[List[Dict[str, Any]]]:
