@@ -189,9 +189,12 @@ int tw_generate_greedy(tw_ctx* ctx, int32_t B, const int32_t* prompt_host, int32
 
 /* A11.  Replaces: _extract_token_timestamps + _median_filter + _dynamic_time_warping
  * (HF:models/whisper/generation_whisper.py:241-381, :43-61, :64-115) on the alignment rows recorded by the
- * last tw_generate_greedy(want_alignment=1).  num_frames_host[b] = valid mel frames: columns are cropped with
- * Python-slice semantics `[: num_frames // 2]` exactly like HF (floor division; a negative bound counts from the end);
- * out_ts_host: float32 [B, seq_len] seconds (seq_len = out_len of the greedy call). */
+ * last tw_generate_greedy(want_alignment=1).  num_frames_host[b] = valid mel frames: the time columns of row b are
+ * cropped ONCE with Python-slice semantics `[: num_frames // 2]` (floor division; a negative bound counts from the end;
+ * nothing left = HF's DTW on the empty matrix: every generated token at -1 * time_precision).  HF itself applies that
+ * slice once or twice depending on the type and uniformity of its `num_frames` argument (:310-330, :357-359); which
+ * bound reproduces HF's result for a given generate() batch is the host mirror's business
+ * (thewhisper_amd/shortform.py::hf_kept_columns).  out_ts_host: float32 [B, seq_len] seconds (seq_len = out_len of the greedy call). */
 int tw_token_timestamps(tw_ctx* ctx, int32_t B, int32_t n_prompt, int32_t seq_len, const int32_t* num_frames_host,
                         double time_precision, float* out_ts_host, void* stream);
 /* Debug/parity access: copy the recorded alignment rows [B, n_align_heads, n_rows, T] (float32) to host. */

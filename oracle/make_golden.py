@@ -15,7 +15,6 @@ from __future__ import annotations
 import json
 import os
 import sys
-import types
 
 import numpy as np
 import torch
@@ -32,32 +31,30 @@ CASES = [
     ("micro_c10", "micro", 10, 23, "speechlike", 5, 4, 32),
     ("micro80_c30", "micro80", 30, 41, "speechlike", 7, 2, 24),
     ("micro_c10_noise", "micro", 10, 12, "noise", 3, 4, 32),
+    # BASELINE configs[0] literally: whisper-tiny.en dimensions, ONE 30 s clip of
+    # default_rng(0).standard_normal * 0.1, chunk_length_s = 30, greedy, through the reference's nvidia.ASRPipeline on CPU in fp32,
+    # called as R:examples/run_nvidia_asr.py:15-36 calls it (chunk_length_s - 1 at call time)
+    ("tiny_en_c30", "tiny.en", 30, 30, "noise", 0, 1, 48),
 ]
+# weights of a case when not make_weights' defaults (stored with the case; the consumers regenerate them from this)
+WEIGHT_KW = {
+    # unit-gain random weights attend almost uniformly; over 1500 frames the word-timestamp surface is then flat to rounding error and
+    # its DTW arg-min a coin toss between implementations (seconds apart).  Sharper queries give a surface with structure.
+    "tiny_en_c30": {"scale": 1.0, "q_gain": 6.0},
+}
 
 
 def _import_reference():
-    if REF not in sys.path:
-        sys.path.insert(0, REF)
-    import transformers  # noqa: F401  (must be imported before the stubs)
+    from .ref_bundle import import_reference
 
-    if "sounddevice" not in sys.modules:  # audio I/O deps of streams.py, absent here and not on the hot path
-        sd = types.ModuleType("sounddevice")
-        sd.InputStream = type("InputStream", (), {})
-        sys.modules["sounddevice"] = sd
-    if "librosa" not in sys.modules:
-        lb = types.ModuleType("librosa")
-        lb.load = lb.resample = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("librosa stub"))
-        sys.modules["librosa"] = lb
-    from thestage_speechkit.nvidia import ASRPipeline
-    from thestage_speechkit.streaming import streaming_pipeline as sp
-
+    ASRPipeline, sp, _streams = import_reference(REF)
     return ASRPipeline, sp
 
 
-def build_reference_pipeline(preset: str, chunk_s: int, batch_size: int, weight_seed: int = 0):
+def build_reference_pipeline(preset: str, chunk_s: int, batch_size: int, weight_seed: int = 0, weight_kw=None):
     ASRPipeline, _ = _import_reference()
     dims = wo.PRESETS[preset]
-    w = wo.make_weights(dims, weight_seed)
+    w = wo.make_weights(dims, weight_seed, **(weight_kw or {}))
     model = hr.build_hf_model(dims, w)
     pipe = ASRPipeline(model, feature_extractor=hr.build_feature_extractor(dims, chunk_s), tokenizer=hr.build_tokenizer(dims),
                        chunk_length_s=chunk_s, device="cpu", torch_dtype=torch.float32, batch_size=batch_size)
@@ -72,12 +69,19 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     _, sp = _import_reference()
     summary = {}
+    only = set(sys.argv[1:])       # `python -m oracle.make_golden tiny_en_c30`: regenerate the named cases, keep the others
+    if only:
+        summary = json.load(open(os.path.join(OUT, "pipeline_golden.json")))
     for name, preset, chunk_s, secs, kind, seed, bs, max_new in CASES:
-        pipe, dims, w = build_reference_pipeline(preset, chunk_s, bs)
+        if only and name not in only:
+            continue
+        pipe, dims, w = build_reference_pipeline(preset, chunk_s, bs, weight_kw=WEIGHT_KW.get(name))
         audio = wo.synth_audio(16000 * secs, seed, kind)
         gk = {"num_beams": 1, "do_sample": False, "use_cache": True, "language": "en", "max_new_tokens": max_new}
         rec = {"preset": preset, "chunk_s": chunk_s, "seconds": secs, "kind": kind, "seed": seed, "batch_size": bs,
                "max_new_tokens": max_new, "weight_seed": 0, "outputs": {}}
+        if name in WEIGHT_KW:
+            rec["weight_kw"] = WEIGHT_KW[name]
         for rt in (False, True, "word"):
             out = pipe(audio.copy(), generate_kwargs=dict(gk), chunk_length_s=chunk_s - 1, return_timestamps=rt)
             rec["outputs"][str(rt)] = json.loads(json.dumps(out))  # tuples -> lists
@@ -99,6 +103,11 @@ def main():
         )
         summary[name] = rec
 
+    if only:
+        with open(os.path.join(OUT, "pipeline_golden.json"), "w") as f:
+            json.dump(summary, f, indent=1)
+        print("rewrote", sorted(only))
+        return
     # streaming: the reference scheduler + its LocalWhisperBackend.transcribe body around the CPU pipeline
     pipe, dims, w = build_reference_pipeline("micro", 10, 1)
     backend = sp.LocalWhisperBackend.__new__(sp.LocalWhisperBackend)
@@ -134,6 +143,14 @@ def main():
         "calls": json.loads(json.dumps(calls)), "committed": json.loads(json.dumps(committed_all)),
         "uncommitted": json.loads(json.dumps(last_uncommitted)),
     }
+    # BASELINE config 3's call pattern from the reference's scheduler + stepper (oracle/config3_trace.py)
+    from . import config3_trace
+    from .ref_bundle import import_reference
+
+    _, sp3, streams3 = import_reference(REF)
+    tr = config3_trace.trace(sp3, streams3)
+    with open(os.path.join(OUT, "config3_trace.json"), "w") as f:
+        json.dump(tr, f, separators=(",", ":"))
     import transformers
 
     summary["_meta"] = {"transformers": transformers.__version__, "torch": torch.__version__,

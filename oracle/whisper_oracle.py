@@ -879,32 +879,68 @@ def dtw(matrix: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     return np.array(ti[::-1]), np.array(tj[::-1])
 
 
+def hf_kept_columns(num_frames, batch: int, t_cols: int) -> List[int]:
+    """Columns of the alignment matrix HF's ``_extract_token_timestamps`` keeps per row (HF:models/whisper/
+    generation_whisper.py:310-330 and :357-359), as the literal Python slices it applies:
+
+      * an ``int``: ``weights[..., : n // 2]`` once, for the whole batch;
+      * a list / tuple / array / tensor whose values are ALL EQUAL: the same slice for the whole batch (:317-321) AND, in the
+        per-row loop, ``weights[b, ..., : num_frames[b] // 2]`` again on the already cropped matrix (:357-359).  For a
+        non-negative bound the second slice changes nothing; for a NEGATIVE one (``num_frames - seek < 0``: a seek iteration
+        past the end of a clip shorter than the chunk, :1152-1155) it removes ``|n // 2|`` columns a second time - with fewer
+        columns than that left, none remain and every token gets the empty-matrix DTW's time index -1;
+      * values that differ: the per-row slice only.
+
+    Floor division; a negative bound counts from the end, as Python slices do."""
+    def crop(length: int, k: int) -> int:
+        return min(length, k) if k >= 0 else max(0, length + k)
+
+    if num_frames is None:
+        return [t_cols] * batch
+    if isinstance(num_frames, (int, np.integer)):
+        return [crop(t_cols, int(num_frames) // 2)] * batch
+    nf = [int(x) for x in (num_frames.tolist() if hasattr(num_frames, "tolist") else list(num_frames))]
+    if len(nf) != batch:
+        nf = [int(x) for x in np.repeat(nf, batch // len(nf))]
+    if len(set(nf)) == 1:
+        k = nf[0] // 2
+        return [crop(crop(t_cols, k), k)] * batch
+    return [crop(t_cols, n // 2) for n in nf]
+
+
 def token_timestamps(
-    cross: np.ndarray, num_input_ids: int, num_frames: Optional[Sequence[int]] = None, time_precision: float = 0.02,
-    median_width: int = 7,
+    cross: np.ndarray, num_input_ids: int, num_frames=None, time_precision: float = 0.02,
+    median_width: int = 7, columns: Optional[Sequence[int]] = None,
 ) -> np.ndarray:
     """``_extract_token_timestamps`` (HF:models/whisper/generation_whisper.py:241-381), 5.15.0 semantics (D4):
-    ``cross`` float32 [B, Ha, N_rows, T] (rows = prompt + generated[:-1]); drop the prompt rows,
-    z-score over the token axis, median filter over time, mean over heads, DTW on ``-matrix``,
-    ``[0]*prompt ++ jump_times ++ [last]``.  Returns float32 [B, N_rows + 1]."""
+    ``cross`` float32 [B, Ha, N_rows, T] (rows = prompt + generated[:-1]); crop the time axis as HF does for this
+    ``num_frames`` (an int, or one value per row: ``hf_kept_columns``), drop the prompt rows, z-score over the token axis,
+    median filter over time, mean over heads, DTW on ``-matrix``, ``[0]*prompt ++ jump_times ++ [last]``.
+    ``columns`` (instead of ``num_frames``): the number of leading time columns to keep per row, given outright - the C ABI's
+    level (tw_token_timestamps takes one bound per row; the batch-level rules above are the host mirror's business).
+    Returns float32 [B, N_rows + 1]."""
     cross = np.asarray(cross, dtype=np.float32)
-    b, _, n_rows, _ = cross.shape
+    b, _, n_rows, t_cols = cross.shape
     out = np.zeros((b, n_rows + 1), dtype=np.float32)
+    cols = [int(c) for c in columns] if columns is not None else hf_kept_columns(num_frames, b, t_cols)
     for bi in range(b):
-        w = cross[bi]
-        if num_frames is not None:
-            w = w[..., : int(num_frames[bi]) // 2]
+        w = cross[bi][..., : cols[bi]]
         w = w[:, num_input_ids:, :]
         if w.shape[1] == 0:
             continue
-        std = w.std(axis=-2, keepdims=True)  # population std (unbiased=False)
-        mean = w.mean(axis=-2, keepdims=True)
-        w = (w - mean) / std
-        w = median_filter(w, median_width)
-        mat = w.mean(axis=0)
-        text_idx, time_idx = dtw(-mat.astype(np.float64))
-        jumps = np.pad(np.diff(text_idx), (1, 0), constant_values=1).astype(bool)
-        jump_times = (time_idx[jumps] * time_precision).astype(np.float32)
+        if w.shape[2] == 0:
+            # HF runs its DTW on the empty matrix: the back-trace walks the token axis at time index -1 (:88-115)
+            jump_times = np.full(w.shape[1], np.float32(-1 * time_precision), dtype=np.float32)
+        else:
+            with np.errstate(divide="ignore", invalid="ignore"):
+                std = w.std(axis=-2, keepdims=True)  # population std (unbiased=False)
+                mean = w.mean(axis=-2, keepdims=True)
+                w = (w - mean) / std
+            w = median_filter(w, median_width)
+            mat = w.mean(axis=0)
+            text_idx, time_idx = dtw(-mat.astype(np.float64))
+            jumps = np.pad(np.diff(text_idx), (1, 0), constant_values=1).astype(bool)
+            jump_times = (time_idx[jumps] * time_precision).astype(np.float32)
         out[bi] = np.concatenate([np.zeros(num_input_ids, np.float32), jump_times, jump_times[-1:]])
     return out
 

@@ -102,7 +102,11 @@ class OracleEngine:
 
     def token_timestamps(self, B, n_prompt, seq_len, num_frames=None, time_precision=0.02):
         self.calls["dtw"] += 1
-        return wo.token_timestamps(self._cross[:B, :, : seq_len - 1], n_prompt, num_frames, time_precision)
+        cols = None
+        if num_frames is not None:   # the C ABI's rule (include/thewhisper.h): ONE Python-slice crop `[: n // 2]` per row
+            T = self._cross.shape[-1]
+            cols = [min(T, int(n) // 2) if int(n) // 2 >= 0 else max(0, T + int(n) // 2) for n in num_frames]
+        return wo.token_timestamps(self._cross[:B, :, : seq_len - 1], n_prompt, None, time_precision, columns=cols)
 
 
 def oracle_engine_factory(dims, T, max_batch, dtype, alignment_heads, device_index):

@@ -17,11 +17,11 @@ def load_case(name):
     return meta, np.load(os.path.join(GOLD, name + ".npz"))
 
 
-@pytest.mark.parametrize("name", ["micro_c10", "micro80_c30", "micro_c10_noise"])
+@pytest.mark.parametrize("name", ["micro_c10", "micro80_c30", "micro_c10_noise", "tiny_en_c30"])
 def test_oracle_reproduces_reference_vectors(name):
     meta, z = load_case(name)
     dims = wo.PRESETS[meta["preset"]]
-    w = wo.make_weights(dims, meta["weight_seed"])
+    w = wo.make_weights(dims, meta["weight_seed"], **meta.get("weight_kw", {}))
     T = 50 * meta["chunk_s"]
     audio = wo.synth_audio(16000 * meta["seconds"], meta["seed"], meta["kind"])
     clip = audio[: meta["chunk_s"] * 16000]

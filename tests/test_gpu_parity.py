@@ -424,6 +424,13 @@ def test_greedy_ids_alignment_and_timestamps(preset, T, B, max_new, graph, min_n
         nf[1] = -(T // 2) - 1                                              # negative bound: HF slices from the end (seek loop)
     ts = eng.token_timestamps(B, 3, L, nf)
     assert np.abs(ts - wo.token_timestamps(ref["cross"], 3, nf)).max() <= 0.0201
+    # a bound that leaves NO column (HF's double crop of a negative uniform bound ends here, shortform.hf_kept_columns): the
+    # reference still runs its DTW, on the empty matrix - every generated token at -1 frame; and bounds of exactly one / all columns
+    nf2 = [(-2 * T - 10, 2, 2 * T + 50)[i % 3] for i in range(B)]
+    want = wo.token_timestamps(ref["cross"], 3, None, columns=[(0, 1, T)[i % 3] for i in range(B)])
+    ts2 = eng.token_timestamps(B, 3, L, nf2)
+    assert np.array_equal(ts2[0], want[0]) and (ts2[0, 3:] == np.float32(-0.02)).all() and (ts2[0, :3] == 0).all()
+    assert np.abs(ts2 - want).max() <= 0.0201
     eng.close()
 
 
@@ -554,7 +561,7 @@ def _assert_same_transcript(out, gold, ts_tol):
     return worst
 
 
-@pytest.mark.parametrize("name", ["micro_c10", "micro80_c30"])
+@pytest.mark.parametrize("name", ["micro_c10", "micro80_c30", "tiny_en_c30"])   # tiny_en_c30 = BASELINE configs[0] literally
 def test_pipeline_on_gpu_matches_reference_golden(name):
     """thewhisper_amd.ASRPipeline on cuda (strict-f32 engine) reproduces what the reference's nvidia.ASRPipeline (HF
     branch, CPU) returned for the same audio: text and segment timestamps byte for byte, word timestamps (DTW on float32
@@ -562,7 +569,7 @@ def test_pipeline_on_gpu_matches_reference_golden(name):
     from tests.test_pipeline_glue import build_amd_pipeline, normalise
 
     g = json.load(open(os.path.join(GOLD, "pipeline_golden.json")))[name]
-    pipe = build_amd_pipeline(g["preset"], g["chunk_s"], g["batch_size"], device="cuda", engine_factory=None)
+    pipe = build_amd_pipeline(g["preset"], g["chunk_s"], g["batch_size"], device="cuda", engine_factory=None, weight_kw=g.get("weight_kw"))
     audio = wo.synth_audio(16000 * g["seconds"], g["seed"], g["kind"])
     gk = {"num_beams": 1, "do_sample": False, "use_cache": True, "language": "en", "max_new_tokens": g["max_new_tokens"]}
     for rt in (False, True, "word"):

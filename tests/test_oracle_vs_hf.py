@@ -1,5 +1,7 @@
 """Pins the numpy oracle (oracle/whisper_oracle.py) against the arithmetic the reference actually runs:
 the installed Hugging Face Whisper (transformers 5.15.0) on CPU.  CPU-only, a few seconds."""
+import json
+
 import numpy as np
 import pytest
 import torch
@@ -125,3 +127,47 @@ def test_logits_processor_edge_cases():
     # after "<ts> text": a following timestamp may not go backwards
     out = wo.apply_logits_processors(s, [50258, 50259, 50360, ts0 + 10, 400], 3, opt)
     assert np.isneginf(out[ts0 : ts0 + 11]).all() and np.isfinite(out[ts0 + 11])
+
+
+@pytest.mark.parametrize("num_frames", [None, 3000, 1067, -1721, [3000, 3000], [-1721, -1721], [-400, -400], [-2999, -2999],
+                                        [-3000, -3000], [1067, 2900], [-1721, 900], "t:[-1721]", "t:[-400, -400]", "t:[-400, 700]",
+                                        "a:[-1000, -1000]"])
+def test_token_timestamp_cropping_matches_hf_for_every_num_frames_flavour(micro, num_frames):
+    """HF crops the alignment matrix with Python slices whose effect depends on the TYPE and UNIFORMITY of `num_frames`
+    (int: once; equal values: twice - which matters for negative bounds, `num_frames - seek < 0` in a seek iteration past the end
+    of a short clip; different values: once per row; nothing left: the empty-matrix DTW).  The restatement reproduces HF's own
+    `_extract_token_timestamps` (HF:models/whisper/generation_whisper.py:241-381) bit for bit in every case."""
+    import warnings
+
+    dims, w, hf = micro
+    rng = np.random.default_rng(5)
+    B, Ha, N, T = 2, 2, 9, 1500
+    heads = [tuple(h) for h in hf.generation_config.alignment_heads][:Ha]
+    if isinstance(num_frames, str):
+        kind, lst = num_frames.split(":")
+        vals = json.loads(lst)
+        nf_hf = torch.tensor(vals) if kind == "t" else np.array(vals)
+        nf_or = vals
+    else:
+        nf_hf = nf_or = num_frames
+    if isinstance(nf_or, list) and len(nf_or) == 1:
+        B = 1
+    probs = rng.random((B, Ha, N, T)).astype(np.float32)
+    probs /= probs.sum(-1, keepdims=True)
+    # HF takes the cross attentions as a tuple over generation steps of per-layer tensors [B, H, 1, T]
+    L, H = dims.dec_layers, dims.heads
+    steps = []
+    for i in range(N):
+        layers = [torch.zeros(B, H, 1, T) for _ in range(L)]
+        for a, (l, h) in enumerate(heads):
+            layers[l][:, h, 0, :] = torch.from_numpy(probs[:, a, i, :])
+        steps.append(tuple(layers))
+    seqs = torch.zeros((B, N + 1), dtype=torch.long)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from transformers.generation.utils import GenerateEncoderDecoderOutput
+
+        go = GenerateEncoderDecoderOutput(sequences=seqs, cross_attentions=tuple(steps))
+        ref = hf._extract_token_timestamps(go, heads, num_frames=nf_hf, num_input_ids=3)
+    got = wo.token_timestamps(probs, 3, nf_or)
+    assert np.array_equal(got, ref.numpy()), (num_frames, got[:, :8], ref.numpy()[:, :8])

@@ -22,11 +22,11 @@ def golden():
 
 
 def build_amd_pipeline(preset, chunk_s, batch_size, device="cpu", engine_factory=oracle_engine_factory,
-                       dtype=torch.float32):
+                       dtype=torch.float32, weight_kw=None):
     from thewhisper_amd import ASRPipeline
 
     dims = wo.PRESETS[preset]
-    w = wo.make_weights(dims, 0)
+    w = wo.make_weights(dims, 0, **(weight_kw or {}))
     model = hr.build_hf_model(dims, w)
     kw = {} if engine_factory is None else {"engine_factory": engine_factory}
     return ASRPipeline(model, feature_extractor=hr.build_feature_extractor(dims, chunk_s), tokenizer=hr.build_tokenizer(dims),
@@ -37,10 +37,10 @@ def normalise(out):
     return json.loads(json.dumps(out))
 
 
-@pytest.mark.parametrize("name", ["micro_c10", "micro_c10_noise", "micro80_c30"])
+@pytest.mark.parametrize("name", ["micro_c10", "micro_c10_noise", "micro80_c30", "tiny_en_c30"])
 def test_offline_pipeline_matches_reference_golden(name):
     g = golden()[name]
-    pipe = build_amd_pipeline(g["preset"], g["chunk_s"], g["batch_size"])
+    pipe = build_amd_pipeline(g["preset"], g["chunk_s"], g["batch_size"], weight_kw=g.get("weight_kw"))
     audio = wo.synth_audio(16000 * g["seconds"], g["seed"], g["kind"])
     gk = {"num_beams": 1, "do_sample": False, "use_cache": True, "language": "en", "max_new_tokens": g["max_new_tokens"]}
     for rt in (False, True, "word"):

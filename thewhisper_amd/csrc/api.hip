@@ -1289,7 +1289,7 @@ int tw_token_timestamps(tw_ctx* c, int32_t B, int32_t n_prompt, int32_t seq_len,
       if (nc < 0) nc += c->T;
     }
     if (nc > c->T) nc = c->T;
-    if (nc < 1) nc = 1;
+    if (nc < 0) nc = 0;    // nothing left: HF's DTW on the empty matrix puts every token at time index -1 (dtw_kernel)
     cols[b] = nc;
   }
   HIPCHK(c, hipMemcpy(c->n_cols, cols.data(), sizeof(int) * B, hipMemcpyHostToDevice));

@@ -81,7 +81,11 @@ __global__ __launch_bounds__(512) void dtw_kernel(DtwArgs a) {
   const int N = a.n_rows - a.n_prompt;
   float* ts = a.out_ts + (long long)b * (a.n_rows + 1);
   if (N <= 0 || M <= 0) {
-    for (int k = i; k < a.n_rows + 1; k += 512) ts[k] = 0.f;
+    // M == 0 (every column cropped away): the reference still runs its DTW, on an [N, 0] matrix - the back-trace walks the
+    // token axis at time index -1 (HF:models/whisper/generation_whisper.py:88-115), so every generated token (and the
+    // duplicate of the last one) gets -1 * time_precision; the prompt positions stay 0
+    const float v = (N > 0) ? (float)(-1.0 * a.time_precision) : 0.f;
+    for (int k = i; k < a.n_rows + 1; k += 512) ts[k] = k >= a.n_prompt ? v : 0.f;
     return;
   }
   const float* mat = a.mat + (long long)b * N * a.T;

@@ -355,14 +355,10 @@ class AMDWhisperForConditionalGeneration(WhisperForConditionalGeneration, _Engin
         if st["B"] != B or st["len"] != L:
             raise RuntimeError("token timestamps requested for a generate() call the engine no longer holds")
         n_in = int(num_input_ids if num_input_ids is not None else st["n_prompt"])
-        if num_frames is None:
-            nf = None
-        elif isinstance(num_frames, int):
-            nf = [num_frames] * B
-        else:
-            nf = [int(x) for x in (num_frames.tolist() if hasattr(num_frames, "tolist") else list(num_frames))]
-            if len(nf) != B:
-                nf = list(np.repeat(nf, B // len(nf)))
+        # which columns HF keeps depends on the type and uniformity of `num_frames` (shortform.hf_kept_columns); the engine crops once per row
+        from .shortform import columns_as_num_frames, hf_kept_columns
+
+        nf = None if num_frames is None else columns_as_num_frames(hf_kept_columns(num_frames, B, int(eng.T)))
         if L - 1 <= n_in:  # one generated token: no cross-attention rows after the prompt -> zeros (HF :341-344)
             return torch.zeros((B, L), dtype=torch.float32, device=seq.device)
         ts = eng.token_timestamps(B, n_in, L, nf, time_precision)

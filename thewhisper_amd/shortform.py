@@ -141,6 +141,36 @@ def retrieve_segment(seek_sequence: torch.Tensor, result: Any, token_timestamps,
     return segments, int(segment_offset)
 
 
+def hf_kept_columns(num_frames, batch: int, t_cols: int) -> List[int]:
+    """How many leading columns of the [tokens, frames] alignment matrix HF's ``_extract_token_timestamps`` keeps per row for a
+    given ``num_frames`` argument (HF:models/whisper/generation_whisper.py:310-330, :357-359).  HF crops with Python slices
+    ``[..., : n // 2]`` (floor division, a negative bound counts from the end) and WHICH slices it applies depends on the type
+    and uniformity of the argument: an int - one slice for the batch; equal values in a list / array / tensor - that slice for
+    the batch AND the per-row slice again (a no-op for n >= 0, a SECOND removal of |n // 2| columns for n < 0, which happens
+    when a seek iteration starts past the end of a clip shorter than the chunk: ``num_frames - seek < 0``, :1152-1155);
+    different values - the per-row slice only.  With no column left HF's DTW walks the token axis at time index -1.
+    The engine (tw_token_timestamps) crops ONCE per row; this function gives it the bound that reproduces HF's result."""
+    def crop(length: int, k: int) -> int:
+        return min(length, k) if k >= 0 else max(0, length + k)
+
+    if num_frames is None:
+        return [t_cols] * batch
+    if isinstance(num_frames, (int, np.integer)):
+        return [crop(t_cols, int(num_frames) // 2)] * batch
+    nf = [int(x) for x in (num_frames.tolist() if hasattr(num_frames, "tolist") else list(num_frames))]
+    if len(nf) != batch:
+        nf = [int(x) for x in np.repeat(nf, batch // len(nf))]
+    if len(set(nf)) == 1:
+        k = nf[0] // 2
+        return [crop(crop(t_cols, k), k)] * batch
+    return [crop(t_cols, n // 2) for n in nf]
+
+
+def columns_as_num_frames(cols: Sequence[int]) -> List[int]:
+    """The per-row ``num_frames`` of tw_token_timestamps that keep exactly ``cols[i]`` leading columns (its rule: ``[: n // 2]``)."""
+    return [2 * int(c) for c in cols]
+
+
 class Pass:
     """One seek iteration (HF:...:785-903) for up to ``engine.max_batch`` chunks, assembled in GROUPS: ``add(works)`` cuts the
     groups' segments and enqueues their encoder + cross-K/V stage at the next free slots (asynchronous launches), ``run()``
@@ -203,7 +233,10 @@ class Pass:
         self.engine.adopt_cross_kv(side_engine, side_slot0, n_new, len(self.works))
         self.works.extend(works)
 
-    def run(self) -> None:
+    def run(self, kept_columns: Optional[Sequence[int]] = None) -> None:
+        """``kept_columns``: alignment-matrix columns per row as HF would keep them for the BATCH these rows are part of
+        (``generate_shortform``); None = every row is a ``generate`` call of its own (the hub: one request = one call of the
+        reference backend's pipeline with batch size 1), i.e. HF's equal-values rule applies to each row by itself."""
         engine, plan, works, snf = self.engine, self.plan, self.works, self.snf
         B = len(works)
         if B < 1:
@@ -230,8 +263,10 @@ class Pass:
                 ts = torch.zeros((B, L), dtype=torch.float32)
             else:
                 nf = None
-                if works[0].num_frames is not None:
-                    nf = [int(w.num_frames) - int(w.seek) for w in works]     # HF:...:1152-1155
+                if kept_columns is not None:
+                    nf = columns_as_num_frames(kept_columns)
+                elif works[0].num_frames is not None:                          # HF:...:1152-1155: num_frames - seek
+                    nf = columns_as_num_frames([hf_kept_columns([int(w.num_frames) - int(w.seek)], 1, int(engine.T))[0] for w in works])
                 ts = torch.from_numpy(engine.token_timestamps(B, n_prompt, L, nf, plan.time_precision))
         for i, w in enumerate(works):
             if plan.result_is_dict:
@@ -280,14 +315,14 @@ def first_segment(work: ChunkWork, T: int) -> torch.Tensor:
     return next_segment(work, T)
 
 
-def run_pass(engine, plan: ShortFormPlan, works: Sequence[ChunkWork]) -> None:
+def run_pass(engine, plan: ShortFormPlan, works: Sequence[ChunkWork], kept_columns: Optional[Sequence[int]] = None) -> None:
     """One seek iteration for every work in ``works`` (all unfinished, len <= engine.max_batch): segment cut-out, encoder +
     cross-K/V + greedy loop (+ token timestamps) on the engine, segment slicing, seek advance."""
     if len(works) < 1 or len(works) > engine.max_batch:
         raise ValueError(f"a pass takes 1..{engine.max_batch} chunks, got {len(works)}")
     p = Pass(engine, plan)
     p.add(works)
-    p.run()
+    p.run(kept_columns)
 
 
 def work_tokens(plan: ShortFormPlan, w: ChunkWork) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]]:
@@ -345,8 +380,12 @@ def generate_shortform(engine, plan: ShortFormPlan, input_features: torch.Tensor
         active = [w for w in works if not w.done]                              # HF:...:790-795 (the batch shrinks)
         if not active:
             break
+        cols = None
+        if plan.return_token_timestamps and active[0].num_frames is not None:
+            # HF hands `(num_frames - seek)[batch_idx_map]` of the WHOLE active batch to `_extract_token_timestamps` (:1152-1155)
+            cols = hf_kept_columns([int(w.num_frames) - int(w.seek) for w in active], len(active), int(engine.T))
         for i in range(0, len(active), cap):                                   # a call wider than the engine: several passes per iteration
-            run_pass(engine, plan, active[i : i + cap])
+            run_pass(engine, plan, active[i : i + cap], None if cols is None else cols[i : i + cap])
         if any(w.passes > MAX_SEEK_PASSES for w in active):
             # a decoder that keeps closing its segments at <|0.00|> never advances `seek`; HF's loop spins forever on such a row
             raise RuntimeError(f"a chunk needed more than {MAX_SEEK_PASSES} seek passes (the decoder keeps seeking to frame 0)")
