@@ -88,7 +88,8 @@ def _cpu_baseline_worker(model_name, chunk_s, new_tokens, calls):
     R:thestage_speechkit/nvidia/asr_pipeline.py:57-60) with device="cpu", fp32, greedy, word timestamps on as the reference's
     streaming backend runs it (R:thestage_speechkit/streaming/streaming_pipeline.py:395-410), `calls` calls x `new_tokens`
     forced tokens.  Where /root/reference is absent (the GPU box) the class it subclasses without changing any arithmetic -
-    transformers' AutomaticSpeechRecognitionPipeline - is called the same way; the JSON says which one ran."""
+    transformers' AutomaticSpeechRecognitionPipeline - is called the same way; the JSON says which one ran.  (Since round 5 the GPU
+    box has the reference's package too: oracle/ref_bundle.py.)"""
     from oracle import hf_reference as hr
     from oracle import whisper_oracle as wo
     from transformers import WhisperForConditionalGeneration
@@ -112,16 +113,15 @@ def _cpu_baseline_worker(model_name, chunk_s, new_tokens, calls):
     model.eval()
     hr.fill_generation_config(model.generation_config, dims)
     fe, tok = hr.build_feature_extractor(dims, chunk_s), hr.build_tokenizer(dims)
-    ref = os.environ.get("TW_REFERENCE_DIR", "/root/reference")
-    if os.path.isdir(os.path.join(ref, "thestage_speechkit")):
-        sys.path.insert(0, ref)
-        from thestage_speechkit.nvidia import ASRPipeline  # the reference's own class (also installs its LCS patch)
+    from oracle import ref_bundle   # /root/reference here; on the GPU box the package __graft_entry__.build() packed into oracle/_ref/
 
+    if ref_bundle.reference_dir() is not None:
+        ASRPipeline, _sp, _streams = ref_bundle.import_reference()   # the reference's own class (importing it also installs its LCS patch)
         pipe = ASRPipeline(model, feature_extractor=fe, tokenizer=tok, chunk_length_s=chunk_s, device="cpu",
                            torch_dtype=torch.float32, batch_size=1)
         enc = model.model.encoder   # version-drift fix D1: 5.x looks positions up through num_embeddings
         enc.embed_positions.num_embeddings = enc.embed_positions.weight.shape[0]
-        which = "thestage_speechkit.nvidia.ASRPipeline (the reference's class, HF branch)"
+        which = f"thestage_speechkit.nvidia.ASRPipeline (the reference's class, HF branch; imported from {ref_bundle.which()})"
     else:
         from transformers import AutomaticSpeechRecognitionPipeline
 
@@ -146,6 +146,15 @@ def _cpu_baseline_worker(model_name, chunk_s, new_tokens, calls):
                                         "which": which}), flush=True)
 
 
+def _reference_available() -> bool:
+    try:
+        from oracle import ref_bundle
+
+        return ref_bundle.reference_dir() is not None
+    except Exception:  # noqa: BLE001
+        return False
+
+
 def cpu_baseline(model_name, chunk_s, new_tokens, calls, budget_s=240):
     """Bounded sample in a child process with a hard wall-clock budget.  oracle/ is imported only here."""
     cores = _host_cores()
@@ -167,7 +176,7 @@ def cpu_baseline(model_name, chunk_s, new_tokens, calls, budget_s=240):
                           f"+{d['init']:.0f} s untimed model init)"}
     except subprocess.TimeoutExpired:
         return {"value": round(new_tokens * calls / budget_s, 3), "unit": "tok/s", "cores": cores,
-                "kind": "reference" if os.path.isdir(os.path.join(os.environ.get("TW_REFERENCE_DIR", "/root/reference"), "thestage_speechkit")) else "hf-pipeline",
+                "kind": "reference" if _reference_available() else "hf-pipeline",
                 "sample": what + f": did NOT finish within the {budget_s} s budget - value is an upper bound"}
 
 
@@ -213,49 +222,79 @@ def pipeline_leg(eng, dims, args, device_index, heads, latency_calls, hub_rounds
             backend.transcribe(clips[i % B], 0.0, 16000)
             lat.append((time.perf_counter() - t0) * 1e3)
         lat.sort()
-        # the call pattern the reference scheduler produces for one stream (SURVEY.md section 3.2 probe: the rolling buffer grows
-        # 2.0, 2.5, ... 10.5 s, then oscillates between ~6.8 and ~8.9 s as committed audio is trimmed): ragged buffers, one call
-        # per 0.5 s of new audio - the p50 of THIS sequence is what a streaming session sees (R:...streaming_pipeline.py:740-822)
-        ragged = [2.0 + 0.5 * i for i in range(18)] + [6.8 + 0.5 * (i % 5) for i in range(40)]
-        # ... as ONE stream (round 4): the buffer's end advances 0.5 s per call and its start jumps when the scheduler trims, so that
-        # four of five calls extend their predecessor - the premise of the opt-in decoder-side reuse
-        stream = (np.random.default_rng(11).standard_normal(int((2.0 + 0.5 * len(ragged) + 1) * 16000)) * 0.1).clip(-1, 1).astype(np.float32)
+        # BASELINE config 3: the call pattern of ONE 60 s stream as the REFERENCE'S OWN scheduler + stepper produce it
+        # (tests/golden/config3_trace.json: reference StreamingPipeline(chunk_length_s=10, min_process_chunk_s=0.5, use_vad=False) fed by
+        # the reference ArrayStream(step_size_s=0.05, real_time=False), R:thestage_speechkit/streaming/streaming_pipeline.py:740-822,
+        # R:thestage_speechkit/streaming/streams.py:16-81; generated by oracle/make_golden.py, re-derived from the reference by
+        # tests/test_config3_trace.py; rounds 1-4 replayed a hand-written list of buffer lengths here).  Per call: which samples of
+        # the stream the rolling buffer holds and the buffer_start_time the scheduler passed; the audio is SURVEY 8d's seed-0 stream.
+        trace = json.load(open(os.path.join(ROOT, "tests", "golden", "config3_trace.json")))
+        stream = (np.random.default_rng(trace["seed"]).standard_normal(16000 * trace["seconds"]) * 0.1).clip(-1, 1).astype(np.float32)
+        n_init = 3   # decoder prompt (sot, language, task): ids after it are what a call produced
+        seen_ids = []
 
         def run_pattern(be):
-            lat_ms, words = [], []
-            for i, secs in enumerate(ragged if latency_calls > 0 else []):
-                end = 2.0 + 0.5 * i
-                secs = min(secs, end, float(args.chunk_s))
-                start = round(end - secs, 3)
-                buf = stream[int(start * 16000) : int(end * 16000)]
+            lat_ms, ids = [], []
+            for c in (trace["calls"] if latency_calls > 0 and args.chunk_s == trace["chunk_length_s"] else []):
+                buf = stream[c["offset"] : c["offset"] + c["n"]]
+                seen_ids.clear()
                 t0 = time.perf_counter()
-                words.append(be.transcribe(buf, start, 16000))
+                be.transcribe(buf, c["t0"], 16000)
                 lat_ms.append((time.perf_counter() - t0) * 1e3)
-            return lat_ms, words
+                ids.append(np.concatenate(seen_ids) if seen_ids else np.zeros(0, np.int64))   # every seek pass of the call, eos-trimmed
+            return lat_ms, ids
 
-        rag, plain_words = run_pattern(backend)
-        rag.sort()
+        def counting_ids(prompt, **kw):   # on top of `counting`: the ids a call decoded, BEFORE tokenizer / gibberish filter / word merge
+            out = counting(prompt, **kw)
+            eos = int(kw.get("eos_id", 50257))
+            for row in out["sequences"][:, n_init:]:
+                hit = np.nonzero(row == eos)[0]
+                seen_ids.append(np.asarray(row[: int(hit[0])] if len(hit) else row, dtype=np.int64))
+            return out
+
+        eng.generate_greedy = counting_ids
+        rag, plain_ids = run_pattern(backend)
+        rag_sorted = sorted(rag)
         reuse_out = {}
-        if latency_calls > 0 and args.chunk_s <= 10:
+        config3 = None
+        if rag:
+            audio_s = trace["seconds"]
+            config3 = {
+                "definition": trace["definition"], "trace": "tests/golden/config3_trace.json", "stream_seconds": audio_s, "calls": len(rag),
+                "calls_per_audio_s": round(len(rag) / audio_s, 3),
+                "p50_ms": round(rag_sorted[len(rag) // 2], 2), "p90_ms": round(rag_sorted[min(len(rag) - 1, (len(rag) * 9) // 10)], 2),
+                "max_ms": round(rag_sorted[-1], 2), "sum_ms": round(sum(rag), 1),
+                # the whole stream's backend time over its duration: < 1 = the stream is served faster than it is spoken
+                "backend_busy_per_audio_s": round(sum(rag) * 1e-3 / audio_s, 4),
+                "buffer_seconds_p50": round(float(np.median([c["n"] for c in trace["calls"]])) / 16000, 2),
+                "model": f"whisper-{args.model} dims, random weights, {args.dtype}; AMDWhisperBackend.transcribe on host float32 buffers",
+            }
+        if latency_calls > 0 and rag and args.chunk_s <= 10:
             rb = AMDWhisperBackend(None, chunk_length_s=args.chunk_s, asr_pipeline=pipe, reuse_committed_prefix=True)
-            rl, reuse_words = run_pattern(rb)
+            rl, reuse_ids = run_pattern(rb)
             rl.sort()
             ident = []
-            for a, b in zip(plain_words, reuse_words):
+            for a, b in zip(plain_ids, reuse_ids):
                 n = max(len(a), len(b))
                 if n:
-                    ident.append(sum(1 for x, y in zip(a, b) if x["text"] == y["text"]) / n)
+                    m = min(len(a), len(b))
+                    ident.append(float((a[:m] == b[:m]).sum()) / n)
             st = rb.reuse_stats
             reuse_out = {
                 "reuse_scheduler_pattern_p50_ms": round(rl[len(rl) // 2], 2), "reuse_scheduler_pattern_p90_ms": round(rl[(len(rl) * 9) // 10], 2),
                 "reuse_calls": st["calls"], "reuse_calls_with_forced_prefix": st["reused"],
                 "reuse_forced_token_share": round(st["forced_tokens"] / max(1, st["forced_tokens"] + st["decoded_tokens"]), 3),
-                "reuse_word_identity_mean": round(float(np.mean(ident)), 3) if ident else None,
+                "reuse_token_identity_mean": round(float(np.mean(ident)), 3) if ident else None,
                 "reuse_note": "AMDWhisperBackend(reuse_committed_prefix=True), opt-in: the previous tick's tokens whose word timestamps end >= 1 s "
                               "before the old buffer's end are forced through a batched prefill (tw_greedy_opts::n_forced), only the tail "
-                              "is decoded; word identity = share of words equal (same index, same text) to the plain backend's on the same "
-                              "calls - random weights, so a chaotic lower bound",
+                              "is decoded; token identity = share of the decoded token ids (all seek passes of a call, before the tokenizer and the "
+                              "reference's gibberish filter - which empties every large-v3 random-weight transcript) equal, position by position, to "
+                              "the plain backend's on the same call - random weights, so a chaotic lower bound",
             }
+            if config3 is not None:
+                config3["with_reuse_committed_prefix"] = {"p50_ms": reuse_out["reuse_scheduler_pattern_p50_ms"], "p90_ms": reuse_out["reuse_scheduler_pattern_p90_ms"],
+                                                          "calls_with_forced_prefix": st["reused"], "token_identity_mean": reuse_out["reuse_token_identity_mean"]}
+        eng.generate_greedy = counting
         # (a) lock-step rounds (continuity with rounds 1-2: all sessions ask at once and wait for the slowest), classic whole-call
         #     batches: what the hub did until round 3
         def lockstep(hub, rounds):
@@ -365,16 +404,17 @@ def pipeline_leg(eng, dims, args, device_index, heads, latency_calls, hub_rounds
             "backend_transcribe_p50_ms": round(lat[len(lat) // 2], 2) if lat else None,
             "backend_transcribe_p90_ms": round(lat[min(len(lat) - 1, (len(lat) * 9) // 10)], 2) if lat else None,
             "backend_transcribe_calls": len(lat),
-            "scheduler_pattern_p50_ms": round(rag[len(rag) // 2], 2) if rag else None,
-            "scheduler_pattern_p90_ms": round(rag[min(len(rag) - 1, (len(rag) * 9) // 10)], 2) if rag else None,
+            "scheduler_pattern_p50_ms": round(rag_sorted[len(rag) // 2], 2) if rag else None,
+            "scheduler_pattern_p90_ms": round(rag_sorted[min(len(rag) - 1, (len(rag) * 9) // 10)], 2) if rag else None,
             "scheduler_pattern_calls": len(rag),
+            "config3": config3,
             **reuse_out,
             "note": f"host float32 {args.chunk_s} s buffers through thewhisper_amd.AMDWhisperBackend.transcribe (reference contract "
                     f"R:thestage_speechkit/streaming/streaming_pipeline.py:388-435: word timestamps on, max_new_tokens=128, natural eos); "
                     f"hub_*: {B} free-running session threads share one engine through BatchingHub, {hub_rounds} requests each, tokens "
                     f"counted over every seek pass (a random-weight model needs ~3 passes per 10 s buffer); hub_lockstep_*: all "
                     f"sessions ask at once and the round ends with the slowest (whole-call batches, as in rounds 1-2); "
-                    f"scheduler_pattern_* = the ragged 2-10.5 s rolling buffers the reference scheduler sends for one stream",
+                    f"scheduler_pattern_* / config3 = the rolling buffers the reference scheduler sends for one 60 s stream (committed trace)",
         })
         return out
     finally:
@@ -474,6 +514,168 @@ def load_pmc_traffic(args):
     return best
 
 
+class TimedRun:
+    """One timed configuration: contexts (+ the encoder-overlap pipeline) of one dtype, W warm-up steps, K timed steps bracketed by
+    barriers, per-stage HIP-event times.  A STEP = every stream of this GPU's share once through the whole hot path: `passes`
+    engine passes of up to `B` streams each (weak scaling: one pass of --streams; strong scaling: ceil(share / 64) passes)."""
+
+    def __init__(self, args, dims, dtype, rep, local, dev, stub, B, passes):
+        self.args, self.dims, self.dtype, self.rep, self.B, self.passes = args, dims, dtype, rep, B, passes
+        T = self.T = 50 * args.chunk_s
+        heads = self.heads = alignment_heads(dims)
+        if stub:
+            mod, fn = stub.split(":")
+            make_engine = getattr(importlib.import_module(mod), fn)
+        else:
+            from thewhisper_amd.engine import WhisperEngine
+
+            def make_engine():
+                return WhisperEngine(dims, T, max_batch=B, dtype=dtype, alignment_heads=heads, device=local, use_graph=not args.no_graph)
+
+        self.eng = eng = make_engine()
+        self.engines = [eng]
+        sd = None if stub else random_state_dict(dims, dev, seed=0)
+        if sd is not None:
+            eng.load_state_dict(sd)
+        self.overlap, self.overlap_note = None, "off"
+        if args.encoder_cus > 0 and not stub:
+            try:
+                from thewhisper_amd.overlap import EncoderOverlap
+
+                eng2 = make_engine()
+                self.engines.append(eng2)
+                eng2.load_state_dict(sd)
+                self.overlap = EncoderOverlap([eng, eng2], encoder_cus=args.encoder_cus, decoder_cus=args.decoder_cus or None)
+                self.overlap_note = (f"encoder stage of pass k+1 on {args.encoder_cus} CUs (second context) under the decode loop of "
+                                     f"pass k on the other CUs")
+            except Exception as e:  # noqa: BLE001 - the overlap is a schedule, not a requirement: run the stages back to back
+                self.overlap = None
+                self.overlap_note = f"off (could not set up CU-masked streams: {e!r})"
+        del sd
+        if not stub:
+            torch.cuda.empty_cache()
+        self.dev = dev
+        self.batches = []      # set_share(): the streams of this GPU, `passes` batches of <= B
+        self.prompt = np.tile(np.array([[50258, 50259, 50360]], dtype=np.int32), (B, 1))
+        self.n_prompt = 3
+
+    def set_share(self, share):
+        """Cut this GPU's `share` streams into the batches of a step."""
+        args, B = self.args, self.B
+        g = torch.Generator(device=self.dev)
+        g.manual_seed(1000 + self.rep.rank)
+        self.share = share
+        self.batches = []
+        left = share
+        while left > 0:
+            nb = min(B, left)
+            self.batches.append((torch.randn((nb, args.chunk_s * 16000), device=self.dev, generator=g, dtype=torch.float32) * 0.1).clamp_(-1, 1))
+            left -= nb
+
+    # -- the two stages of a pass (asynchronous launches; the greedy call blocks) -------------------------------------------
+    @staticmethod
+    def encode_stage(e, pc):      # log-mel + encoder + cross-K/V
+        mel = e.logmel(pc)
+        e.encode(mel)
+        e.cross_kv(pc.shape[0])
+        return mel                # kept alive until the batch is decoded: the launches above are still reading it
+
+    def decode_stage(self, e, pc, _enc):
+        args, nb, host = self.args, pc.shape[0], self.host
+        t_a = time.perf_counter()
+        out = e.generate_greedy(self.prompt[:nb], max_new_tokens=args.new_tokens, min_new_tokens=args.new_tokens,
+                                timestamps=True, want_alignment=True)
+        t_b = time.perf_counter()
+        L = out["length"]
+        e.token_timestamps(nb, self.n_prompt, L, [2 * self.T] * nb)
+        t_c = time.perf_counter()
+        tm = e.last_timings()
+        t_d = time.perf_counter()
+        host["greedy_call_ms"] += (t_b - t_a) * 1e3
+        host["timestamps_call_ms"] += (t_c - t_b) * 1e3
+        host["timings_call_ms"] += (t_d - t_c) * 1e3
+        host["calls"] += 1
+        return (L - self.n_prompt) * nb, tm
+
+    def run_steps(self, n):
+        """n steps = n x `passes` engine passes; with the overlap the encoder stage of pass i+1 runs on its own CUs while pass i
+        decodes (same kernels, same results, different schedule)."""
+        seq = self.batches * n
+        if self.overlap is not None:
+            return self.overlap.run(seq, self.encode_stage, self.decode_stage)
+        res = []
+        for pc in seq:
+            self.encode_stage(self.eng, pc)
+            res.append(self.decode_stage(self.eng, pc, None))
+        return res
+
+    def timed(self):
+        args, rep = self.args, self.rep
+        self.host = {"greedy_call_ms": 0.0, "timestamps_call_ms": 0.0, "timings_call_ms": 0.0, "calls": 0}
+        if args.warmup > 0:  # with the overlap at least two passes, so that both contexts capture their step graph untimed
+            self.run_steps(max(args.warmup, 2 if (self.overlap is not None and len(self.batches) == 1) else args.warmup))
+        rep.barrier()                          # dist.barrier() + torch.cuda.synchronize()
+        self.host.update(greedy_call_ms=0.0, timestamps_call_ms=0.0, timings_call_ms=0.0, calls=0)
+        stage = {"logmel_ms": 0.0, "encode_ms": 0.0, "cross_kv_ms": 0.0, "greedy_ms": 0.0, "token_timestamps_ms": 0.0}
+        dec_steps = new_tok = 0
+        t0 = time.perf_counter()
+        for ntok, tm in self.run_steps(args.steps):
+            new_tok += ntok
+            for k in stage:
+                stage[k] += tm[k]
+            dec_steps += tm["decode_steps"]
+        rep.barrier()
+        dt_local = time.perf_counter() - t0
+        return {"dt_local": dt_local, "new_tok": new_tok, "stage": stage, "dec_steps": dec_steps, "host": dict(self.host)}
+
+    def roofline(self, r, dt):
+        """Decode step: SURVEY 8d's algorithmic bytes over the HIP-event time of the loop (per engine pass of B streams)."""
+        args, dims, B, T = self.args, self.dims, self.B, self.T
+        esz = 4 if self.dtype == "f32" else 2
+        wsz = 1.0 + 1.0 / 32 if self.dtype.startswith("fp8") else None
+        n_pass = max(1, args.steps * len(self.batches))
+        steps_per_call = r["dec_steps"] // n_pass
+        # (strong scaling: the passes of a step may differ in size; the byte count uses each pass's own stream count)
+        alg_total = 0
+        for pc in self.batches:
+            a, W = algorithmic_decode_bytes(dims, pc.shape[0], T, self.n_prompt, steps_per_call, esz, wsz)
+            alg_total += a
+        alg_bytes, W = int(alg_total / len(self.batches)), int(W)
+        greedy_ms = r["stage"]["greedy_ms"] / n_pass
+        achieved = alg_bytes / (greedy_ms * 1e-3) / 1e9 if greedy_ms > 0 else 0.0
+        return {"alg_bytes": alg_bytes, "W": W, "greedy_ms": greedy_ms, "achieved": achieved, "steps_per_call": steps_per_call,
+                "avg_step_ms": greedy_ms / max(1, steps_per_call), "esz": esz, "wsz": wsz}
+
+    def close(self):
+        if self.overlap is not None:
+            self.overlap.close()
+        for e in self.engines:
+            e.close()
+        self.engines, self.batches = [], []
+
+
+def full_depth_parity(dtype):
+    """`streams_with_identical_ids` and friends of the headline-shaped parity case (16 clips x 163 positions at full depth, fp32
+    reference goldens) from the newest committed log of the GPU suite: what the id-identity claim of a dtype rests on."""
+    logs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gpu_tests_full_depth.log")))
+    for path in reversed(logs):
+        for line in open(path, errors="replace"):
+            if line.startswith(f"FULLDEPTH full_large-v3_c10_b16 {dtype}:"):
+                out = {"source": f"profiles/{os.path.basename(path)} (tests/test_gpu_full_depth.py, case full_large-v3_c10_b16: 16 clips, 160 free-running "
+                                 f"greedy tokens each, HF fp32 reference)", "clips": 16}
+                for key, name in (("streams_with_identical_ids", "ids_identical_clips"), ("greedy_path_logits_rel_l2", "logits_rel_l2"),
+                                  ("token_ts_within_1_frame_frac", "token_timestamps_within_1_frame_frac"), ("enc_rel_l2", "encoder_rel_l2")):
+                    k = line.find(key + "=")
+                    if k >= 0:
+                        v = line[k + len(key) + 1 :].split(",")[0].strip()
+                        try:
+                            out[name] = int(v) if name == "ids_identical_clips" else round(float(v), 6)
+                        except ValueError:
+                            pass
+                return out
+    return None
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
@@ -483,6 +685,10 @@ def main(argv=None):
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--chunk-s", type=int, default=10)
     ap.add_argument("--streams", type=int, default=16, help="concurrent streams per GPU (1..64; 16 = the per-GPU share of BASELINE configs[3])")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): --streams per GPU whatever N (configs[3]: 16 x N streams).  strong: --total-streams over ALL GPUs "
+                         "(SURVEY.md section 8d row 4, 'fixed-128'): every GPU takes total / N of them, in passes of at most 64")
+    ap.add_argument("--total-streams", type=int, default=128, help="with --scaling strong: streams of the whole job (BASELINE configs[3]: 128)")
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32", "fp8", "fp8a8", "fp8a16"],
                     help="fp8 = bf16 activations/encoder + MXFP8 decoder projection weights (BASELINE config 5)")
@@ -498,7 +704,7 @@ def main(argv=None):
     ap.add_argument("--decoder-cus", type=int, default=0, help="with --encoder-cus: compute units of the decode loop (0 = all the others)")
     ap.add_argument("--latency-iters", type=int, default=100, help="single-stream chunk calls timed for the p50 (after 10 warm-ups; SURVEY.md section 8d)")
     ap.add_argument("--no-pipeline-leg", action="store_true", help="skip the measurement through ASRPipeline / BatchingHub")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the compact legs for BASELINE configs 2 (turbo, 30 s, 1 stream) and 5 (fp8, 15 s)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the compact legs for BASELINE configs 2 (turbo, 30 s, 1 stream) and 5 (fp8, 15 s) and the float16 block")
     ap.add_argument("--hub-rounds", type=int, default=12, help="requests per session in the hub measurement")
     ap.add_argument("--no-hub-two-cohorts", dest="hub_two_cohorts", action="store_false",
                     help="skip the hub measurement with twice as many sessions as rows per pass (hub_2x_*)")
@@ -515,7 +721,7 @@ def main(argv=None):
     stub = os.environ.get("TW_BENCH_ENGINE")
     if not stub and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    from thewhisper_amd.dist import Replicas
+    from thewhisper_amd.dist import Replicas, shard_streams
 
     local = int(os.environ.get("TW_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))  # TW_BENCH_DEVICE: plumbing tests only
     dev = torch.device("cpu") if stub else torch.device("cuda", local)
@@ -529,110 +735,35 @@ def main(argv=None):
 
     dims = DIMS[args.model]
     T = 50 * args.chunk_s
-    B = args.streams
-    heads = alignment_heads(dims)
-    if stub:
-        mod, fn = stub.split(":")
-        make_engine = getattr(importlib.import_module(mod), fn)
+    if args.scaling == "strong":
+        # streams sharded like sessions: stream i lives on rank i % world (dist.shard_streams); a GPU takes its share in passes of <= 64
+        share = len(shard_streams(args.total_streams, rank, world))
+        if share < 1:
+            raise SystemExit(f"--total-streams {args.total_streams} leaves rank {rank} of {world} without a stream")
+        passes = (share + 63) // 64
+        B = (share + passes - 1) // passes           # equal passes (128 on one GPU: 2 x 64; 32 per GPU: 1 x 32)
     else:
-        from thewhisper_amd.engine import WhisperEngine
+        share, passes, B = args.streams, 1, args.streams
+    run = TimedRun(args, dims, args.dtype, rep, local, dev, stub, B, passes)
+    run.set_share(share)
+    eng, heads, prompt, n_prompt = run.eng, run.heads, run.prompt, run.n_prompt
+    r = run.timed()
+    dt_local = r["dt_local"]
+    dt = rep.max_float(dt_local)           # max over ranks
+    per_rank = rep.gather_floats(r["new_tok"] / dt_local)   # tokens/s of every rank on its own clock
+    new_tok = rep.sum_int(r["new_tok"])    # whole-job token count
+    stage, host = r["stage"], r["host"]
 
-        def make_engine():
-            return WhisperEngine(dims, T, max_batch=B, dtype=args.dtype, alignment_heads=heads, device=local, use_graph=not args.no_graph)
-
-    eng = make_engine()
-    sd = None if stub else random_state_dict(dims, dev, seed=0)
-    if sd is not None:
-        eng.load_state_dict(sd)
-    overlap = None
-    overlap_note = "off"
-    if args.encoder_cus > 0 and not stub:
-        try:
-            from thewhisper_amd.overlap import EncoderOverlap
-            eng2 = make_engine()
-            eng2.load_state_dict(sd)
-            overlap = EncoderOverlap([eng, eng2], encoder_cus=args.encoder_cus, decoder_cus=args.decoder_cus or None)
-            overlap_note = (f"encoder stage of batch k+1 on {args.encoder_cus} CUs (second context) under the decode loop of "
-                            f"batch k on the other CUs")
-        except Exception as e:  # noqa: BLE001 - the overlap is a schedule, not a requirement: run the stages back to back
-            overlap = None
-            overlap_note = f"off (could not set up CU-masked streams: {e!r})"
-    del sd
-    if not stub:
-        torch.cuda.empty_cache()
-
-    n_samples = args.chunk_s * 16000
-    g = torch.Generator(device=dev)
-    g.manual_seed(1000 + rank)
-    pcm = (torch.randn((B, n_samples), device=dev, generator=g, dtype=torch.float32) * 0.1).clamp_(-1, 1)
-    prompt = np.tile(np.array([[50258, 50259, 50360]], dtype=np.int32), (B, 1))
-    n_prompt = prompt.shape[1]
-
-    def step(nb=B, pc=pcm, pr=prompt):
-        mel = eng.logmel(pc[:nb])
+    def step(nb):
+        pc = run.batches[0][:nb]
+        mel = eng.logmel(pc)
         eng.encode(mel)
         eng.cross_kv(nb)
-        out = eng.generate_greedy(pr[:nb], max_new_tokens=args.new_tokens, min_new_tokens=args.new_tokens,
+        out = eng.generate_greedy(prompt[:nb], max_new_tokens=args.new_tokens, min_new_tokens=args.new_tokens,
                                   timestamps=True, want_alignment=True)
         L = out["length"]
         eng.token_timestamps(nb, n_prompt, L, [2 * T] * nb)
         return L - n_prompt
-
-    stage = {"logmel_ms": 0.0, "encode_ms": 0.0, "cross_kv_ms": 0.0, "greedy_ms": 0.0, "token_timestamps_ms": 0.0}
-    dec_steps = 0
-    new_tok = 0
-
-    def encode_stage(e, pc):      # log-mel + encoder + cross-K/V: asynchronous launches
-        mel = e.logmel(pc)
-        e.encode(mel)
-        e.cross_kv(pc.shape[0])
-        return mel                # kept alive until the batch is decoded: the launches above are still reading it
-
-    host = {"greedy_call_ms": 0.0, "timestamps_call_ms": 0.0, "timings_call_ms": 0.0, "calls": 0}
-
-    def decode_stage(e, pc, _enc):
-        nb = pc.shape[0]
-        t_a = time.perf_counter()
-        out = e.generate_greedy(prompt[:nb], max_new_tokens=args.new_tokens, min_new_tokens=args.new_tokens,
-                                timestamps=True, want_alignment=True)
-        t_b = time.perf_counter()
-        L = out["length"]
-        e.token_timestamps(nb, n_prompt, L, [2 * T] * nb)
-        t_c = time.perf_counter()
-        tm = e.last_timings()
-        t_d = time.perf_counter()
-        host["greedy_call_ms"] += (t_b - t_a) * 1e3
-        host["timestamps_call_ms"] += (t_c - t_b) * 1e3
-        host["timings_call_ms"] += (t_d - t_c) * 1e3
-        host["calls"] += 1
-        return (L - n_prompt) * nb, tm
-
-    def run_steps(n):
-        """n passes of the hot path over one batch each; with the overlap the encoder stage of pass i+1 runs on its own CUs
-        while pass i decodes (same kernels, same results, different schedule)."""
-        if overlap is not None:
-            return overlap.run([pcm] * n, encode_stage, decode_stage)
-        res = []
-        for _ in range(n):
-            encode_stage(eng, pcm)
-            res.append(decode_stage(eng, pcm, None))
-        return res
-
-    if args.warmup > 0:  # with the overlap at least two passes, so that both contexts capture their step graph untimed
-        run_steps(max(args.warmup, 2) if overlap is not None else args.warmup)
-    rep.barrier()                          # dist.barrier() + torch.cuda.synchronize()
-    host.update(greedy_call_ms=0.0, timestamps_call_ms=0.0, timings_call_ms=0.0, calls=0)
-    t0 = time.perf_counter()
-    for ntok, tm in run_steps(args.steps):
-        new_tok += ntok
-        for k in stage:
-            stage[k] += tm[k]
-        dec_steps += tm["decode_steps"]
-    rep.barrier()
-    dt_local = time.perf_counter() - t0
-    dt = rep.max_float(dt_local)           # max over ranks
-    per_rank = rep.gather_floats(new_tok / dt_local)   # tokens/s of every rank on its own clock
-    new_tok = rep.sum_int(new_tok)         # whole-job token count
 
     # single-stream chunk latency (config 3 shape) on the raw engine: same context, B = 1, PCM already in HBM
     lat = []
@@ -651,15 +782,19 @@ def main(argv=None):
                 tick[k] += tm[k] / args.latency_iters
 
     if rank == 0:
-        esz = 4 if args.dtype == "f32" else 2
-        wsz = 1.0 + 1.0 / 32 if args.dtype.startswith("fp8") else None
-        steps_per_call = dec_steps // max(1, args.steps)
-        alg_bytes, W = algorithmic_decode_bytes(dims, B, T, n_prompt, steps_per_call, esz, wsz)
-        alg_bytes, W = int(alg_bytes), int(W)
-        greedy_ms = stage["greedy_ms"] / args.steps
-        achieved = alg_bytes / (greedy_ms * 1e-3) / 1e9 if greedy_ms > 0 else 0.0
-        avg_step_ms = greedy_ms / max(1, steps_per_call)
-        pmc = load_pmc_traffic(args)
+        rf = run.roofline(r, dt)
+        alg_bytes, W, greedy_ms, achieved, steps_per_call, avg_step_ms = (rf[k] for k in ("alg_bytes", "W", "greedy_ms", "achieved", "steps_per_call", "avg_step_ms"))
+        esz, wsz = rf["esz"], rf["wsz"]
+        n_pass = args.steps * passes
+        args_for_pmc = argparse.Namespace(**{**vars(args), "streams": B})
+        pmc = load_pmc_traffic(args_for_pmc)
+        if args.scaling == "strong":
+            workload = (f"whisper-{args.model}, {args.chunk_s} s chunks, {args.total_streams} concurrent streams over ALL GPUs (configs[3], fixed total: "
+                        f"{share} on this GPU in {passes} pass(es) of {B}), {args.new_tokens} new tokens/stream forced (min=max), timestamp grammar + "
+                        f"word-timestamp DTW on")
+        else:
+            workload = (f"whisper-{args.model}, {args.chunk_s} s chunks, {B} concurrent streams per GPU (configs[3] per-GPU share), "
+                        f"{args.new_tokens} new tokens/stream forced (min=max), timestamp grammar + word-timestamp DTW on")
         result = {
             "metric": "transcription tokens/sec (node), whisper-large-v3 10s chunks" if args.model == "large-v3" and args.chunk_s == 10
             else f"transcription tokens/sec (node), whisper-{args.model} {args.chunk_s}s chunks",
@@ -670,24 +805,24 @@ def main(argv=None):
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": (f"bf16 activations, MXFP8 (e4m3 + block scales) decoder weights [{args.dtype}]" if args.dtype.startswith("fp8") else args.dtype),
             "data": "synthetic 16 kHz gaussian audio (sigma 0.1), random-init weights of the named architecture",
             "config": {
-                "workload": f"whisper-{args.model}, {args.chunk_s} s chunks, {B} concurrent streams per GPU (configs[3] per-GPU share), "
-                            f"{args.new_tokens} new tokens/stream forced (min=max), timestamp grammar + word-timestamp DTW on",
-                "streams_per_gpu": B, "chunk_seconds": args.chunk_s, "new_tokens": args.new_tokens,
+                "workload": workload,
+                "streams_per_gpu": share, "streams_per_pass": B, "passes_per_step": passes, "chunk_seconds": args.chunk_s, "new_tokens": args.new_tokens,
+                "total_streams": (args.total_streams if args.scaling == "strong" else share * world),
                 "parallelism": f"replicas x{world} (streams sharded, no collective on the data path)",
                 "decode_step_graph": not args.no_graph,
-                "encoder_overlap": overlap_note,
+                "encoder_overlap": run.overlap_note,
             },
             "per_rank_tok_per_s": [round(x, 1) for x in per_rank],
             "stage_ms_per_step": {k: round(v / args.steps, 3) for k, v in stage.items()},
             "decode_tok_per_s": round(B * args.new_tokens / (greedy_ms * 1e-3), 1) if greedy_ms > 0 else None,
-            # wall time of the host calls per step, beside the HIP-event time of the loop inside tw_generate_greedy (greedy_ms):
+            # wall time of the host calls per pass, beside the HIP-event time of the loop inside tw_generate_greedy (greedy_ms):
             # what ms_per_step holds besides the decode loop (call set-up / tear-down, DTW call, pipeline fill of the first batch)
-            "host_call_ms_per_step": {k: round(v / max(1, host["calls"]), 3) for k, v in host.items() if k != "calls"},
+            "host_call_ms_per_step": {k: round(v / max(1, host["calls"]) * passes, 3) for k, v in host.items() if k != "calls"},
             "roofline": {
                 "kernel": "decode step (the captured graph replays two at a time; weight-streaming projections + single-query attention "
                           "over the K/V caches + sampler); averaged over all steps of a greedy call",
@@ -704,6 +839,7 @@ def main(argv=None):
                 # section 4) than SURVEY's 14 d^2; `achieved` / `frac` stay on SURVEY's algorithmic bytes, `traffic` is the counter
                 "weight_bytes_streamed_per_step": int(W + (wsz if wsz is not None else esz) * dims["dec_layers"] * 2 * dims["d_model"] ** 2),
                 "avg_step_ms": round(avg_step_ms, 4),
+                "streams_per_launch": B,
             },
         }
         if lat:
@@ -720,30 +856,42 @@ def main(argv=None):
                                                           "8f-3 closed on this number: encoder reuse could remove at most encoder_side_share "
                                                           "of a tick while changing results (non-causal encoder), DESIGN.md section 7"}
             result["chunk_latency_note"] = (f"raw engine, 1 stream, {args.chunk_s} s chunk resident in HBM, {args.new_tokens} tokens + DTW, "
-                                            f"{len(lat)} calls; the API-level latency is pipeline.backend_transcribe_p50_ms")
-        if world == 1 and not stub and not args.no_pipeline_leg:
+                                            f"{len(lat)} calls; the contract's latency (one backend call, host buffer in, words out) is "
+                                            f"p50_chunk_latency_contract_ms")
+        if world == 1 and not stub and not args.no_pipeline_leg and args.scaling == "weak":
             try:
-                result["pipeline"] = pipeline_leg(eng, dims, args, local, heads, args.latency_iters, args.hub_rounds)
+                pargs = argparse.Namespace(**{**vars(args), "streams": B})
+                result["pipeline"] = pipeline_leg(eng, dims, pargs, local, heads, args.latency_iters, args.hub_rounds)
             except Exception as e:  # noqa: BLE001
                 result["pipeline"] = {"error": repr(e)}
+        pl = result.get("pipeline") or {}
+        # ---- the CONTRACT's definitions first (R:thestage_speechkit/streaming/streaming_pipeline.py:388-435), the
+        # engine-level readings beside them
+        result["value_contract"] = pl.get("hub_tok_per_s")
+        result["p50_chunk_latency_contract_ms"] = pl.get("backend_transcribe_p50_ms")
+        result["p90_chunk_latency_contract_ms"] = pl.get("backend_transcribe_p90_ms")
+        result["hub_request_p50_ms"] = pl.get("hub_request_p50_ms")
+        result["hub_request_p90_ms"] = pl.get("hub_request_p90_ms")
+        result["config3"] = pl.get("config3")
         result["value_definition"] = ("value = tokens/s of the hot path driven through the C ABI with the PCM resident in HBM (what a host written "
-                                      "against include/thewhisper.h gets; the contract's definition). value_api = SURVEY.md section 8d's "
-                                      "definition: generated tokens over wall-clock from transcribe() entry to return, host buffers in, word "
-                                      "dictionaries out, through AMDWhisperBackend / BatchingHub (pipeline.hub_tok_per_s)")
-        result["value_api"] = (result.get("pipeline") or {}).get("hub_tok_per_s")
+                                      "against include/thewhisper.h gets; bench.py's contract: inputs resident when the timed region starts). "
+                                      "value_contract (= value_api) = SURVEY.md section 8d's definition: generated tokens over wall-clock from "
+                                      "transcribe() entry to return, host buffers in, word dictionaries out, 16 free-running sessions through "
+                                      "AMDWhisperBackend / BatchingHub (pipeline.hub_tok_per_s).  p50_chunk_latency_contract_ms = median wall time of one "
+                                      "AMDWhisperBackend.transcribe call on a 10 s host buffer (8d: 'one backend call'), p50_chunk_latency_ms = the raw "
+                                      "engine on resident PCM.  config3 = the reference scheduler's own 60 s call trace replayed through the backend")
+        result["value_api"] = pl.get("hub_tok_per_s")
         # the same API with two cohorts of sessions taking turns on the same passes (32 sessions for 16 rows): the encoder stage of the
         # cohort that sits a pass out runs on the side stream under that pass's decode loop
-        result["value_api_two_cohorts"] = (result.get("pipeline") or {}).get("hub_2x_tok_per_s")
+        result["value_api_two_cohorts"] = pl.get("hub_2x_tok_per_s")
         # value_api over the window in which every session still has requests to send (no drain passes at the end of the finite run)
-        result["value_api_steady_state"] = (result.get("pipeline") or {}).get("hub_steady_tok_per_s")
-        result["value_api_two_cohorts_steady_state"] = (result.get("pipeline") or {}).get("hub_2x_steady_tok_per_s")
+        result["value_api_steady_state"] = pl.get("hub_steady_tok_per_s")
+        result["value_api_two_cohorts_steady_state"] = pl.get("hub_2x_steady_tok_per_s")
         if world == 1 and not stub and not args.no_secondary:
             legs = []
             for label, model, chunk_s, nb, dt_, k in (("configs[1]: large-v3-turbo, 30 s chunk, batch 1, bf16", "large-v3-turbo", 30, 1, "bf16", 5),
-                                                        ("configs[4]: large-v3, MXFP8 decoder weights + fp8 cross-K/V, 15 s chunks, word timestamps", "large-v3", 15, B, "fp8", 3),
-                                                        ("configs[4] shape in bf16 (for the fp8 / bf16 ratio)", "large-v3", 15, B, "bf16", 3),
-                                                        ("the headline configuration in float16 (the reference's streaming default dtype; same kernels "
-                                                         "instantiated for _Float16)", "large-v3", args.chunk_s, B, "f16", 3)):
+                                                        ("configs[4]: large-v3, MXFP8 decoder weights + fp8 cross-K/V, 15 s chunks, word timestamps", "large-v3", 15, min(B, 16), "fp8", 3),
+                                                        ("configs[4] shape in bf16 (for the fp8 / bf16 ratio)", "large-v3", 15, min(B, 16), "bf16", 3)):
                 try:
                     legs.append(secondary_leg(label, model, chunk_s, nb, dt_, k, args.new_tokens, local, use_graph=not args.no_graph))
                 except Exception as e:  # noqa: BLE001
@@ -753,13 +901,40 @@ def main(argv=None):
                 sys.path.insert(0, os.path.join(ROOT, "benchmark"))
                 import run_rtfx
 
-                r = run_rtfx.measure("large-v3-turbo", minutes=4.0, batch_sizes=(1, 32), device_index=local)
+                rr = run_rtfx.measure("large-v3-turbo", minutes=4.0, batch_sizes=(1, 32), device_index=local)
                 result["rtfx"] = {"definition": "audio seconds / wall seconds of ASRPipeline(audio, batch_size=bs) on one long clip "
                                                 "(R:benchmark/eval_utils.py:149-154); TTFT = inference start -> first token",
-                                  "model": r["model"], "audio_s": r["audio_s"], "forced_new_tokens_per_30s_window": r["forced_new_tokens_per_window"],
-                                  "runs": r["runs"]}
+                                  "model": rr["model"], "audio_s": rr["audio_s"], "forced_new_tokens_per_30s_window": rr["forced_new_tokens_per_window"],
+                                  "runs": rr["runs"]}
             except Exception as e:  # noqa: BLE001
                 result["rtfx"] = {"error": repr(e)}
+        # ---- float16 as a first-class block: the reference's streaming default dtype (R:...streaming_pipeline.py:369-370) and the 16-bit
+        # context whose greedy ids are identical to the fp32 reference on every clip of the full-depth suite - the SAME timed schedule as
+        # the headline (overlap pipeline, K steps), its own roofline, the parity figures from the committed GPU-suite log next to both
+        result["parity_full_depth"] = {args.dtype: full_depth_parity(args.dtype)} if args.dtype in ("bf16", "f16", "f32") else {}
+        if world == 1 and not stub and not args.no_secondary and args.dtype == "bf16":
+            run.close()
+            run = None
+            torch.cuda.empty_cache()
+            try:
+                run16 = TimedRun(args, dims, "f16", rep, local, dev, stub, B, passes)
+                run16.set_share(share)
+                r16 = run16.timed()
+                rf16 = run16.roofline(r16, r16["dt_local"])
+                result["value_f16"] = round(r16["new_tok"] / r16["dt_local"], 2)
+                result["ms_per_step_f16"] = round(r16["dt_local"] / args.steps * 1e3, 3)
+                result["roofline_f16"] = {"bound": "hbm", "achieved": round(rf16["achieved"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": round(rf16["achieved"] / HBM_PEAK_GBS, 4), "avg_step_ms": round(rf16["avg_step_ms"], 4),
+                                          "algorithmic_bytes_per_step": int(rf16["alg_bytes"] / max(1, rf16["steps_per_call"])), "traffic": None}
+                result["stage_ms_per_step_f16"] = {k: round(v / args.steps, 3) for k, v in r16["stage"].items()}
+                result["parity_full_depth"]["f16"] = full_depth_parity("f16")
+                result["f16_note"] = ("the headline workload in a float16 context (TW_F16: the same kernels instantiated for _Float16, "
+                                      "v_mfma_f32_16x16x32_f16), same schedule, same step count; parity_full_depth.*.ids_identical_clips = clips (of 16) whose "
+                                      "160 free-running greedy ids equal the HF fp32 reference's to the end")
+                run16.close()
+            except Exception as e:  # noqa: BLE001
+                result["value_f16"] = None
+                result["f16_note"] = f"failed: {e!r}"
         if world == 1 and not stub and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(args.model, args.chunk_s, args.cpu_tokens, args.cpu_calls)
@@ -767,8 +942,8 @@ def main(argv=None):
                 result["cpu_baseline"] = {"value": None, "unit": "tok/s", "cores": os.cpu_count(), "kind": "reference",
                                           "sample": f"failed: {e!r}"}
         print(json.dumps(result), flush=True)
-    if overlap is not None:
-        overlap.close()
+    if run is not None:
+        run.close()
     rep.close()
 
 

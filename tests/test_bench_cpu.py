@@ -49,3 +49,18 @@ def test_algorithmic_bytes_follow_survey_8d():
     total, W = bench.algorithmic_decode_bytes(bench.DIMS["large-v3"], 16, 500, 3, 130)
     assert W == 1601044480 + 0 * 1 or abs(W - 1.601e9) < 1e6
     assert abs(total - 400.8e9) < 0.2e9      # the figure the round-1 review derived for the driver's call
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("gpus,share,passes,per_pass", [(2, 64, 1, 64), (1, 128, 2, 64)])
+def test_bench_strong_scaling_mode_shards_a_fixed_total(gpus, share, passes, per_pass):
+    """SURVEY.md section 8d row 4 ("fixed-128 for strong scaling"): --scaling strong --total-streams 128 gives every rank
+    128 / N streams, taken in passes of at most 64; the whole-job value counts all 128 streams whatever N."""
+    r = _run(["--gpus", str(gpus), "--scaling", "strong", "--total-streams", "128"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["scaling"] == "strong" and d["n_gpus"] == gpus
+    c = d["config"]
+    assert (c["total_streams"], c["streams_per_gpu"], c["passes_per_step"], c["streams_per_pass"]) == (128, share, passes, per_pass)
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 * d["steps"] - d["steps"] * 128 * 128) < 1.0     # 128 streams x 128 tokens per step
+    assert d["roofline"]["streams_per_launch"] == per_pass
