@@ -911,10 +911,11 @@ bool getenv_off_fuse() {
 // one token for every stream: embed -> Ld layers -> final LN + tied logits (fp32)
 // rs > 0: rows mode (tw_common.h: tw_row_of) - the B rows are rs streams x B / rs consecutive positions whose tokens are `ids`
 // (device, row order); no logits are produced (the tokens of those positions are known: prefill_core)
-int decode_core(tw_ctx* c, int B, hipStream_t st, int rs = 0, const int* ids = nullptr) {
+// embed = false: the input rows are already in place (the sampler's last launch of the previous step wrote them, SamplerArgs::x_next)
+int decode_core(tw_ctx* c, int B, hipStream_t st, int rs = 0, const int* ids = nullptr, bool embed = true) {
   const int d = c->d, H = c->H, F = c->ffn, T = c->T, P = c->P, dt = c->dtype;
   const size_t e = c->esz;
-  HIPCHK(c, launch_embed(dt, rs > 0 ? ids : c->cur_ids, c->stt, c->tok_emb, c->dec_pos, c->dx0, B, d, rs, st));
+  if (embed) HIPCHK(c, launch_embed(dt, rs > 0 ? ids : c->cur_ids, c->stt, c->tok_emb, c->dec_pos, c->dx0, B, d, rs, st));
   void* xin = c->dx0;
   void* xmid = c->dx1;
   const int Pp = (P + 63) / 64 * 64;
@@ -1123,11 +1124,18 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
   sa.no_ts_id = o->no_timestamps_id; sa.max_initial_ts = o->max_initial_timestamp_index;
   sa.begin_suppress = c->begin_suppress_dev; sa.n_begin_suppress = o->n_begin_suppress;
   sa.suppress_bits = c->suppress_bits; sa.partials = c->sampler_partials;
+  // the embedding of the token a step has chosen is written by the sampler's last launch (k_decode.hip: embed_row), so a step is
+  // layers + logits + sampler; only the FIRST step of the call needs its input row from a launch of its own (TW_FUSE_EMBED=0: A/B)
+  static const bool fuse_embed = []() { const char* e = getenv("TW_FUSE_EMBED"); return !(e && atoi(e) == 0); }();
+  if (fuse_embed) {
+    sa.tok_emb = c->tok_emb; sa.pos_emb = c->dec_pos; sa.x_next = c->dx0; sa.d = c->d; sa.dtype = c->dtype;
+    HIPCHK(c, launch_embed(c->dtype, c->cur_ids, c->stt, c->tok_emb, c->dec_pos, c->dx0, B, c->d, 0, st));
+  }
 
   // ---- graph replay: one captured step per self-attention length bucket, captured on first use ----
   char keybuf[256];
-  snprintf(keybuf, sizeof keybuf, "%d|%d|%d|%d|%d|%d|%d|%d|%d", B, o->eos_id, o->pad_id, o->min_new_tokens, o->timestamps,
-           o->no_timestamps_id, o->max_initial_timestamp_index, o->n_begin_suppress, o->n_suppress);
+  snprintf(keybuf, sizeof keybuf, "%d|%d|%d|%d|%d|%d|%d|%d|%d|%d", B, o->eos_id, o->pad_id, o->min_new_tokens, o->timestamps,
+           o->no_timestamps_id, o->max_initial_timestamp_index, o->n_begin_suppress, o->n_suppress, (int)fuse_embed);
   const bool use_graph = c->cfg.use_graph != 0;
   if (use_graph && c->step_graph_key != keybuf) {   // other options: the captured sampler arguments are stale
     for (auto& kv : c->step_graphs) (void)hipGraphExecDestroy(kv.second);
@@ -1146,7 +1154,7 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
     int r = TW_OK;
     hipError_t es = hipSuccess;
     for (int i = 0; i < n && r == TW_OK && es == hipSuccess; ++i) {
-      r = decode_core(c, B, st);
+      r = decode_core(c, B, st, 0, nullptr, !fuse_embed);
       if (r == TW_OK) es = launch_sampler(sa, st);
     }
     hipError_t ee = hipStreamEndCapture(st, &g);
@@ -1196,7 +1204,7 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
       HIPCHK(c, hipGraphLaunch(ex, st));
     } else {
       c->dec_key_bound = kb;
-      int r = decode_core(c, B, st);
+      int r = decode_core(c, B, st, 0, nullptr, !fuse_embed);
       if (r != TW_OK) return r;
       HIPCHK(c, launch_sampler(sa, st));
     }

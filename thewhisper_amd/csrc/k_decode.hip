@@ -27,6 +27,40 @@ __device__ unsigned long long* g_probe_ts;
 #define TW_TS(k) do { } while (0)
 #endif
 
+// Compile-time switches of the projection kernel (defaults = what ships; tools/dbg/probe_gemv.hip builds the other settings for A/B runs):
+//  TW_RED_STRIDE   row stride (floats) of the partial tiles in LDS.  A partial tile is written [weight row][stream] by the MFMA lanes and
+//                  read [stream][weight row] by the epilogue threads (16 consecutive rows of one stream per 16 threads, for the stores):
+//                  with 16 floats per row a 32-lane group of a ds_read_b32 hit 4 banks, 8 addresses each (8-way conflict on every read
+//                  of the reduction); 17 spreads it over all 32 banks, the writers stay at <= 2 addresses per bank (free for stores).
+//  TW_CG_ORDER     several groups of 16 streams per launch: the HBM weight requests leave FIRST and the (L2) activation requests follow in
+//                  consumption order (step-major); 0 = the order of the one-group kernel (activations first, group-major), which puts
+//                  20 KiB of L2 traffic per wavefront in front of the first HBM request.
+//  TW_CG_PREFETCH  ... and K longer than one round of fragments (fc2): the NEXT round's weight fragments are requested one round ahead
+//                  (second register set), so a round waits for its activation stream only.
+//  TW_CG_EPI_ALL   ... the epilogue of the groups is spread over all 512 threads (two halves of the workgroup take alternate groups).
+//  TW_CG_RING     several groups, 16-bit or f32 weights, one tile per workgroup: the template parameter SK_MAXS is then the wavefront's
+//                  WHOLE step count and the operands go through two register RINGS (weights: 5 steps deep, activations: 3 steps x
+//                  CG groups) refilled as soon as a step has been contracted - straight-line code, the compiler's vmcnt counts are
+//                  exact.  The point is registers: the one-round scheme holds CG x 5 activation fragments at once (80 registers at 64
+//                  streams, 134-158 in total: ONE 512-thread workgroup per CU, so the 320-workgroup launches ran as two rounds on
+//                  the decode loop's 160 CUs); the rings need 48 and two workgroups fit.
+#ifndef TW_RED_STRIDE
+#define TW_RED_STRIDE 17
+#endif
+#ifndef TW_CG_RING
+#define TW_CG_RING 1
+#endif
+#ifndef TW_CG_ORDER
+#define TW_CG_ORDER 1
+#endif
+#ifndef TW_CG_PREFETCH
+#define TW_CG_PREFETCH 1
+#endif
+#ifndef TW_CG_EPI_ALL
+#define TW_CG_EPI_ALL 1
+#endif
+constexpr int kRedTile = 16 * TW_RED_STRIDE;   // floats per partial tile in LDS
+
 __device__ __forceinline__ float wave_sum(float v) { return tw_wave_sum(v); }
 // erf-GELU (activation_function = "gelu").  Strict-f32 contexts use the library erff; bf16 contexts, whose outputs are
 // rounded to 8 mantissa bits anyway, use the Abramowitz-Stegun 7.1.26 rational form (|error| < 2e-7 on erf + one fast
@@ -265,8 +299,8 @@ template <> __device__ __forceinline__ void sk_stats<float>(const u32x4_t& v, fl
 // A weight lane needs the scales of ITS two 32-value blocks (16-byte half h of lane groups 2u, 2u+1, u = kq / 2); the scale array
 // holds block t = 2h + u in lane group t (where the scaled MFMA reads it), so the lane fetches groups u and 2 + u: two byte loads
 // per step instead of one, no exchange.  Several groups of 16 streams (CG > 1) are available in this mode only.
-template <typename T, int NW, int SK_MAXS, bool LN, int EPI, bool MULTI, bool W8, int CG, int TR, bool A16 = false>
-__global__ __launch_bounds__(NW * 64, (CG > 1 ? (NW >= 16 ? 4 : 2) : (NW >= 16 ? 4 : (W8 ? (SK_MAXS <= 2 ? 4 : 2) : (SK_MAXS <= 5 ? 4 : 2)))))
+template <typename T, int NW, int SK_MAXS, bool LN, int EPI, bool MULTI, bool W8, int CG, int TR, bool A16 = false, int MODE = 0>
+__global__ __launch_bounds__(NW * 64, (CG > 1 ? ((NW >= 16 || (TW_CG_RING && !MULTI && !W8 && MODE == 2)) ? 4 : 2) : (NW >= 16 ? 4 : (W8 ? (SK_MAXS <= 2 ? 4 : 2) : (SK_MAXS <= 5 ? 4 : 2)))))
 void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_arg, int n_arg, int rg_arg,
                         const unsigned char* wscale_arg, const void* bias_arg, const void* res_arg, const float* gw_arg, GemvArgs a) {
   // The first arguments repeat what the request addresses are formed from (operands, K, B, N, tiles per workgroup): gfx950
@@ -316,14 +350,29 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
   const int tile0 = blockIdx.x * RG;
   const int ej = (tid >> 4) & 15, ei = tid & 15;  // epilogue role of threads 0..255: stream ej, tile row ei (rows >= TR idle)
 
+  // several groups, long K: a second set of weight registers holds the NEXT round's fragments (TW_CG_PREFETCH)
+  // MODE (several groups of streams only; picked by the launcher): 0 = rounds of SK_MAXS fragments, 1 = the same with the next
+  // round's weights requested a round ahead (only for launches whose K takes several rounds - for the others the request would be
+  // waste), 2 = operand rings over the wavefront's whole K slice (TW_CG_RING above; SK_MAXS = the slice's step count)
+  constexpr bool PF = CG > 1 && TW_CG_PREFETCH && !MULTI && MODE == 1;
+  constexpr bool RING = CG > 1 && TW_CG_RING && !MULTI && !W8 && MODE == 2;
+  constexpr int DW = RING ? (SK_MAXS < 5 ? SK_MAXS : 5) : 1;   // ring depths (steps)
+  constexpr int DX = RING ? (SK_MAXS < 3 ? SK_MAXS : 3) : 1;
+  u32x4_t rw[DW], rx[DX][CG];
+  // several groups: the two 256-thread halves of the workgroup take alternate groups in the epilogue (TW_CG_EPI_ALL)
+  constexpr bool EALL = CG > 1 && TW_CG_EPI_ALL && NW >= 8;
+  constexpr int GPT = EALL ? CG / 2 : CG;     // groups per epilogue thread
   u32x4_t wq[SK_MAXS * WPS], xq[CG][SK_MAXS * XPS];
   int wsc[SK_MAXS];  // MXFP8: scale byte of the weight block this lane feeds to the scaled MFMA (A16: of its own first block)
   int wsc2[A16 ? SK_MAXS : 1];  // A16: scale byte of its own second block
-  float e_c = 0.f, e_gw = 0.f, e_res[CG];
+  u32x4_t wqn[PF ? SK_MAXS * WPS : 1];
+  int wscn[PF ? SK_MAXS : 1], wsc2n[(PF && A16) ? SK_MAXS : 1];
+  const int eh = EALL ? ((tid >> 8) & 1) : 0;   // which half of the workgroup this epilogue thread belongs to
+  float e_c = 0.f, e_gw = 0.f, e_res[GPT];
 #pragma unroll
-  for (int g = 0; g < CG; ++g) e_res[g] = 0.f;
+  for (int g = 0; g < GPT; ++g) e_res[g] = 0.f;
   // --- request helpers: all unconditional, addresses clamped into the matrix ---
-  auto load_epi = [&](int tile, float& c, float& gwv, float (&r)[CG]) {
+  auto load_epi = [&](int tile, float& c, float& gwv, float (&r)[GPT]) {
     const int n = min(tile * TR + min(ei, TR - 1), N - 1);
     const bool second = EPI == SK_RES && n >= nsplit;   // row of the composed half: its "residual" is u, it has no bias
     if (LN) {
@@ -339,10 +388,11 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
       const int usz = u_p ? N - nsplit : 0;
       const int nu = (u_p && second) ? n - nsplit : 0;
 #pragma unroll
-      for (int g = 0; g < CG; ++g) {
+      for (int gi = 0; gi < GPT; ++gi) {
+        const int g = EALL ? gi * 2 + eh : gi;
         const float rb = (float)res[(long long)g * 16 * nsplit + tw_xt_index<T>(ej, second ? 0 : n)];
         const float ru = up[(long long)min(g * 16 + ej, B - 1) * usz + nu];
-        r[g] = second ? ru : rb;
+        r[gi] = second ? ru : rb;
       }
     }
   };
@@ -350,7 +400,7 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
       const_cast<T*>(W), 0, TR == 16 ? 0 : (int)((long long)n_tiles * S * 4 * TR * 16 * (W8 ? 2 : 1)), 0x00020000);
   const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<unsigned char*>(wscale), 0, (W8 && TR != 16) ? (int)((long long)n_tiles * S * 4 * TR) : 0, 0x00020000);
-  auto load_w = [&](int tile, int s0) {  // fragment-major weights: 1 KiB contiguous per wavefront request
+  auto load_w_into = [&](auto& wq, auto& wsc, auto& wsc2, int tile, int s0) {  // fragment-major weights: 1 KiB contiguous per wavefront request
     const int tl = min(tile, n_tiles - 1);
     if (W8 && TR == 16) {
       const unsigned char* wt = reinterpret_cast<const unsigned char*>(W) + ((long long)tl * S * 128 + lane) * 16;
@@ -403,6 +453,7 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
             wr, lane_off + tile_off + (unsigned)(min(s0 + i, S - 1) * (4 * TR * 16)), 0, 2 /* nt */));
     }
   };
+  auto load_w = [&](int tile, int s0) { load_w_into(wq, wsc, wsc2, tile, s0); };
   // fragment-major activations: lane (stream fr, k-group kq) of each 32-k step.  Requested through a buffer descriptor so
   // that the lanes of streams >= B are out of range: they return zeros WITHOUT a memory request, i.e. a launch for one
   // stream moves 1/16 of the activation bytes of a launch for 16 (the block is re-read by every workgroup: at B = 1 that
@@ -413,21 +464,73 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
   for (int g = 0; g < CG; ++g)
     xoff[g] = (g * 16 + fr < B) ? (unsigned)((g * 16 * K + lane * E) * (int)sizeof(T)) : 0x80000000u;
   auto load_x = [&](int s0) {
-#pragma unroll
-    for (int g = 0; g < CG; ++g)
+    if constexpr (CG > 1 && TW_CG_ORDER) {   // step-major: the order mfma_round consumes them in
 #pragma unroll
       for (int i = 0; i < SK_MAXS; ++i)
 #pragma unroll
-        for (int m = 0; m < XPS; ++m) {
-          const unsigned step_bytes = (unsigned)((min(s0 + i, S - 1) * XPS + m) * (64 * E) * (int)sizeof(T));
-          xq[g][i * XPS + m] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(xr, xoff[g] + step_bytes, 0, 0));
-        }
+        for (int g = 0; g < CG; ++g)
+#pragma unroll
+          for (int m = 0; m < XPS; ++m) {
+            const unsigned step_bytes = (unsigned)((min(s0 + i, S - 1) * XPS + m) * (64 * E) * (int)sizeof(T));
+            xq[g][i * XPS + m] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(xr, xoff[g] + step_bytes, 0, 0));
+          }
+    } else {
+#pragma unroll
+      for (int g = 0; g < CG; ++g)
+#pragma unroll
+        for (int i = 0; i < SK_MAXS; ++i)
+#pragma unroll
+          for (int m = 0; m < XPS; ++m) {
+            const unsigned step_bytes = (unsigned)((min(s0 + i, S - 1) * XPS + m) * (64 * E) * (int)sizeof(T));
+            xq[g][i * XPS + m] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(xr, xoff[g] + step_bytes, 0, 0));
+          }
+    }
   };
 
-  load_x(s_lo);
-  __builtin_amdgcn_sched_barrier(0);  // request order = consumption order: hipcc must not reorder the groups
-  load_w(tile0, s_lo);
-  __builtin_amdgcn_sched_barrier(0);
+  auto ring_w = [&](int step) -> u32x4_t {   // one weight fragment of this workgroup's tile (RING: every step is inside the matrix)
+    const int tl = min(tile0, n_tiles - 1);
+    if constexpr (TR == 16) {
+      return sk_load_w<T>(W + ((long long)tl * S * 64 + lane) * E + (long long)step * (64 * E));
+    } else {
+      const unsigned lane_off = (fr < TR) ? (unsigned)((kq * TR + fr) * 16) : 0x80000000u;
+      return __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(
+          wr, lane_off + (unsigned)tl * (unsigned)(S * 4 * TR * 16) + (unsigned)(step * (4 * TR * 16)), 0, 2 /* nt */));
+    }
+  };
+  auto ring_x = [&](int g, int step) -> u32x4_t {
+    return __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(xr, xoff[g] + (unsigned)(step * (64 * E) * (int)sizeof(T)), 0, 0));
+  };
+  if constexpr (RING) {
+    // HBM first, then the first DX steps of activations in consumption order; everything else is requested as registers free up
+#pragma unroll
+    for (int i = 0; i < DW; ++i) rw[i] = ring_w(s_lo + i);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < DX; ++i)
+#pragma unroll
+      for (int g = 0; g < CG; ++g) rx[i][g] = ring_x(g, s_lo + i);
+    __builtin_amdgcn_sched_barrier(0);
+  } else if constexpr (CG > 1 && TW_CG_ORDER) {
+    // several groups of streams: a wavefront asks for up to 20 KiB of activations per round.  The HBM requests go first (their
+    // latency is the long one; vmcnt retires in order, so by the time an activation fragment has arrived its weights have too)
+    load_w(tile0, s_lo);
+    __builtin_amdgcn_sched_barrier(0);
+    load_x(s_lo);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PF) {
+      load_w_into(wqn, wscn, wsc2n, tile0, s_lo + SK_MAXS);   // (clamped to the matrix; unused when K fits one round)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    load_x(s_lo);
+    __builtin_amdgcn_sched_barrier(0);  // request order = consumption order: hipcc must not reorder the groups
+    load_w(tile0, s_lo);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PF) {
+      load_w_into(wqn, wscn, wsc2n, tile0, s_lo + SK_MAXS);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
   // (2) everything else (epilogue operands, outputs, cache geometry): ONE batch of scalar loads from the argument block, waited for
   // here, behind the operand requests that are already on their way
   asm volatile("" ::"s"(bias), "s"(res), "s"(gw_p), "s"(cb_p), "s"(a.gelu), "s"(ldy), "s"(d_model), "s"(cache_bstride), "s"(y),
@@ -441,9 +544,9 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
   __builtin_amdgcn_sched_barrier(0);  // ... nor hoist arithmetic between the requests
   TW_TS(1);
 
-  float mean[CG], rstd[CG];
+  float mean[GPT], rstd[GPT];
 #pragma unroll
-  for (int g = 0; g < CG; ++g) { mean[g] = 0.f; rstd[g] = 1.f; }
+  for (int g = 0; g < GPT; ++g) { mean[g] = 0.f; rstd[g] = 1.f; }
   const int n_grp = MULTI ? RG : 1;
   for (int grp = 0; grp < n_grp; ++grp) {
     const int tile = tile0 + grp;
@@ -495,17 +598,55 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
         }
       }
     };
+    if constexpr (RING) {
+#pragma unroll
+      for (int i = 0; i < SK_MAXS; ++i) {
+#pragma unroll
+        for (int g = 0; g < CG; ++g) {
+          const u32x4_t xv = rx[i % DX][g];
+          if (LN) sk_stats<T>(xv, ps[g], pss[g]);
+          acc[g] = sk_mfma<T>(rw[i % DW], xv, acc[g]);
+        }
+        if (i + DX < SK_MAXS) {
+#pragma unroll
+          for (int g = 0; g < CG; ++g) rx[i % DX][g] = ring_x(g, s_lo + i + DX);
+        }
+        if (i + DW < SK_MAXS) rw[i % DW] = ring_w(s_lo + i + DW);
+        __builtin_amdgcn_sched_barrier(0);   // keep the software pipeline in this order
+      }
+    } else {
     mfma_round(s_lo);  // operands already in flight
     for (int s0 = s_lo + SK_MAXS; s0 < s_hi; s0 += SK_MAXS) {  // K longer than one round of fragments
-      load_x(s0);
-      load_w(tile, s0);
+      if constexpr (PF) {
+        // this round's weights were requested a round ago (wqn): ask for the activations, take the weights over, ask for the
+        // round after - a round waits for its activation stream, not for HBM
+        load_x(s0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < SK_MAXS * WPS; ++i) wq[i] = wqn[i];
+        if constexpr (W8) {
+#pragma unroll
+          for (int i = 0; i < SK_MAXS; ++i) { wsc[i] = wscn[i]; if constexpr (A16) wsc2[i] = wsc2n[i]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_w_into(wqn, wscn, wsc2n, tile, s0 + SK_MAXS);
+        __builtin_amdgcn_sched_barrier(0);
+      } else if constexpr (CG > 1 && TW_CG_ORDER) {
+        load_w(tile, s0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_x(s0);
+      } else {
+        load_x(s0);
+        load_w(tile, s0);
+      }
       mfma_round(s0);
+    }
     }
     // operands of the tile after this one are requested now, behind the reduction and the epilogue of the current one
     // (MULTI is only launched with a single round of fragments per tile, so the activation fragments stay in registers)
-    float n_c = 0.f, n_gw = 0.f, n_res[CG];
+    float n_c = 0.f, n_gw = 0.f, n_res[GPT];
 #pragma unroll
-    for (int g = 0; g < CG; ++g) n_res[g] = 0.f;
+    for (int g = 0; g < GPT; ++g) n_res[g] = 0.f;
     if (MULTI) {
       const int nt = min(tile + 1, n_tiles - 1);
       load_w(nt, s_lo);
@@ -517,7 +658,7 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
 #pragma unroll
     for (int g = 0; g < CG; ++g)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[(wave * CG + g) * 256 + (kq * 4 + r) * 16 + fr] = acc[g][r];
+      for (int r = 0; r < 4; ++r) red[(wave * CG + g) * kRedTile + (kq * 4 + r) * TW_RED_STRIDE + fr] = acc[g][r];
     if (LN && (!MULTI || grp == 0)) {
 #pragma unroll
       for (int g = 0; g < CG; ++g) {
@@ -527,15 +668,16 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
     }
     __syncthreads();
     TW_TS(3);
-    if (tid < 256) {
+    if (tid < (EALL ? 512 : 256)) {
       const int j = ej, i = ei;  // stream (within its group), row: 16 consecutive rows of one stream per 16 threads
       const int n = tile * TR + i;
 #pragma unroll
-      for (int g = 0; g < CG; ++g) {
+      for (int gi = 0; gi < GPT; ++gi) {
+        const int g = EALL ? gi * 2 + eh : gi;
         const int jg = g * 16 + j;  // stream
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) v += red[(w * CG + g) * 256 + i * 16 + j];
+        for (int w = 0; w < NW; ++w) v += red[(w * CG + g) * kRedTile + i * TW_RED_STRIDE + j];
         const float vraw = v;
         if (LN) {
           if (!MULTI || grp == 0) {
@@ -543,15 +685,15 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
 #pragma unroll
             for (int w = 0; w < NW; ++w) { sx += pstat[w][jg][0]; sxx += pstat[w][jg][1]; }
             const float inv_k = __builtin_amdgcn_rcpf((float)K);
-            mean[g] = sx * inv_k;
-            rstd[g] = __frsqrt_rn(fmaxf(sxx * inv_k - mean[g] * mean[g], 0.f) + 1e-5f);
+            mean[gi] = sx * inv_k;
+            rstd[gi] = __frsqrt_rn(fmaxf(sxx * inv_k - mean[gi] * mean[gi], 0.f) + 1e-5f);
           }
-          v = rstd[g] * (v - mean[g] * e_gw) + e_c;
+          v = rstd[gi] * (v - mean[gi] * e_gw) + e_c;
         } else {
           v += e_c;
         }
         if (EPI == SK_GELU) v = gelu_exact<T>(v);
-        if (EPI == SK_RES) v += e_res[g];
+        if (EPI == SK_RES) v += e_res[gi];
         if (EPI == SK_RES && u_p) {   // (kernel-uniform) LayerNorm statistics of the residual rows of this tile, as stored
           const float xs = (tile < n_tiles && n < nsplit && jg < B && i < TR) ? (float)tw_cast<T>(v) : 0.f;
           const float s1 = tw_row16_sum(xs), s2 = tw_row16_sum(xs * xs);   // the 16 threads of one stream are one DPP row
@@ -591,7 +733,7 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
     if (MULTI) {
       e_c = n_c; e_gw = n_gw;
 #pragma unroll
-      for (int g = 0; g < CG; ++g) e_res[g] = n_res[g];
+      for (int g = 0; g < GPT; ++g) e_res[g] = n_res[g];
     }
     TW_TS(4);
   }
@@ -1290,9 +1432,30 @@ __global__ __launch_bounds__(256) void sampler_part_kernel(SamplerArgs a) {
 }
 
 // wavefront b <- stream b; thread 0 advances the position once every wavefront has used it
+// the next step's input row of stream b (A6: HF:models/whisper/modeling_whisper.py:733-771), by one wavefront: 16-byte vectors of the
+// token row and the positional row, added in float32, rounded once, stored where tw_xt_index puts elements 8v .. 8v+7 (E per vector)
+template <typename T>
+__device__ __forceinline__ void embed_row(const SamplerArgs& a, int b, int id, int p, int lane) {
+  constexpr int E = ElemTraits<T>::kPer16B;
+  const T* tok = reinterpret_cast<const T*>(a.tok_emb) + (long long)id * a.d;
+  const T* pos = reinterpret_cast<const T*>(a.pos_emb) + (long long)p * a.d;
+  T* x = reinterpret_cast<T*>(a.x_next) + (long long)(b >> 4) * 16 * a.d;
+  for (int v = lane; v * E < a.d; v += 64) {
+    const u32x4_t tv = *reinterpret_cast<const u32x4_t*>(tok + v * E), pv = *reinterpret_cast<const u32x4_t*>(pos + v * E);
+    T o[E];
+    const T* tp = reinterpret_cast<const T*>(&tv);
+    const T* pp = reinterpret_cast<const T*>(&pv);
+#pragma unroll
+    for (int e = 0; e < E; ++e) o[e] = (T)((float)tp[e] + (float)pp[e]);
+    *reinterpret_cast<u32x4_t*>(x + tw_xt_index<T>(b & 15, v * E)) = *reinterpret_cast<const u32x4_t*>(o);
+  }
+}
+
 __global__ __launch_bounds__(1024) void sampler_finish_kernel(SamplerArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
+  const int pos_now = a.stt->pos;              // (thread 0 advances it behind the barrier at the end)
   for (int b = tid >> 6; b < a.B; b += 16) {  // wavefront w <- streams w, w+16, ...
+    int next_id = 0;
     const SamplerMask k = sampler_mask(a, b);
     SamplerPartial p = a.partials[b * SAMPLER_NS_MAX + min(lane, a.n_slices - 1)];
     const bool on = lane < a.n_slices;
@@ -1308,10 +1471,12 @@ __global__ __launch_bounds__(1024) void sampler_finish_kernel(SamplerArgs a) {
       const int cur_len = a.stt->pos + 1;
       int* seq = a.seq + (long long)b * a.seq_ld;
       if (k.in_prompt) {
-        a.cur_ids[b] = seq[cur_len];
+        next_id = seq[cur_len];
+        a.cur_ids[b] = next_id;
       } else if (k.fin) {
         seq[cur_len] = a.pad;
         a.cur_ids[b] = a.pad;
+        next_id = a.pad;
       } else {
         int choice;
         if (force_ts) choice = bs.i;
@@ -1319,9 +1484,16 @@ __global__ __launch_bounds__(1024) void sampler_finish_kernel(SamplerArgs a) {
         if (choice == 0x7fffffff) choice = 0;  // everything masked: torch.argmax of all -inf is 0
         seq[cur_len] = choice;
         a.cur_ids[b] = choice;
+        next_id = choice;
         if (a.timestamps && choice >= k.ts_begin) a.last_ts[b] = choice;
         if (choice == a.eos) a.finished[b] = 1;
       }
+    }
+    if (a.x_next) {   // (kernel-uniform) the token just appended is the next step's input at position pos + 1
+      const int id = __builtin_amdgcn_readfirstlane(next_id);   // lane 0's
+      if (a.dtype == 1) embed_row<bf16_t>(a, b, id, pos_now + 1, lane);
+      else if (a.dtype == 2) embed_row<f16_t>(a, b, id, pos_now + 1, lane);
+      else embed_row<float>(a, b, id, pos_now + 1, lane);
     }
   }
   __syncthreads();
@@ -1339,11 +1511,18 @@ static int env_int(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-template <typename T, int NW, int SK_MAXS, bool MULTI, bool W8, int CG, int TR, bool A16 = false>
+// how launches for more than 16 streams move their operands (skinny_mfma_kernel's MODE): 2 = operand rings where the shape allows
+// (default), 1 = rounds with the next round's weights a round ahead, 0 = plain rounds (rounds 3-4); TW_SK_CG_MODE for A/B runs
+static int cg_mode() {
+  static const int m = env_int("TW_SK_CG_MODE", 2);
+  return m;
+}
+
+template <typename T, int NW, int SK_MAXS, bool MULTI, bool W8, int CG, int TR, bool A16 = false, int MODE = 0>
 static hipError_t skinny_launch_cg(const GemvArgs& a, dim3 grid, size_t lds1, hipStream_t st) {
   const bool ln = a.ln_gw != nullptr;
   const size_t lds = lds1 * CG;
-#define SK_GO(LNV, EPIV) hipLaunchKernelGGL((skinny_mfma_kernel<T, NW, SK_MAXS, LNV, EPIV, MULTI, W8, CG, TR, A16>), grid, dim3(NW * 64), lds, st, \
+#define SK_GO(LNV, EPIV) hipLaunchKernelGGL((skinny_mfma_kernel<T, NW, SK_MAXS, LNV, EPIV, MULTI, W8, CG, TR, A16, MODE>), grid, dim3(NW * 64), lds, st, \
                                             a.x, a.W, a.K, a.B, a.N, a.rg, a.wscale, a.bias, a.res, a.ln_gw, a)
   if constexpr (TR != 16) {  // narrow tiles: plain / residual / GELU projections, one tile per workgroup
     if (a.y_f32 || a.kcache) return hipErrorInvalidValue;
@@ -1394,8 +1573,11 @@ static hipError_t skinny_launch_v(const GemvArgs& a, dim3 grid, size_t lds1, hip
       if constexpr (NW != 8 || SK_MAXS != 2) {
         return hipErrorInvalidValue;
       } else {
-        if (a.B <= 32) return skinny_launch_cg<T, NW, SK_MAXS, MULTI, true, 2, TR, true>(a, grid, lds1, st);
-        return skinny_launch_cg<T, NW, SK_MAXS, MULTI, true, 4, TR, true>(a, grid, lds1, st);
+        const bool rounds = !MULTI && cg_mode() >= 1 && (a.K / 128 + NW - 1) / NW > SK_MAXS;   // K takes several rounds of fragments: weights a round ahead
+        if (a.B <= 32) return rounds ? skinny_launch_cg<T, NW, SK_MAXS, MULTI, true, 2, TR, true, MULTI ? 0 : 1>(a, grid, lds1, st)
+                                     : skinny_launch_cg<T, NW, SK_MAXS, MULTI, true, 2, TR, true>(a, grid, lds1, st);
+        return rounds ? skinny_launch_cg<T, NW, SK_MAXS, MULTI, true, 4, TR, true, MULTI ? 0 : 1>(a, grid, lds1, st)
+                      : skinny_launch_cg<T, NW, SK_MAXS, MULTI, true, 4, TR, true>(a, grid, lds1, st);
       }
     }
     if (a.B > 16) return hipErrorInvalidValue;
@@ -1407,8 +1589,11 @@ static hipError_t skinny_launch_v(const GemvArgs& a, dim3 grid, size_t lds1, hip
   if constexpr (W8 || NW != 8 || SK_MAXS != 5) {
     return hipErrorInvalidValue;
   } else {
-    if (a.B <= 32) return skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 2, TR>(a, grid, lds1, st);
-    return skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 4, TR>(a, grid, lds1, st);
+    const bool rounds = !MULTI && cg_mode() >= 1 && (a.K / (4 * ElemTraits<T>::kPer16B) + NW - 1) / NW > SK_MAXS;   // several rounds: weights a round ahead
+    if (a.B <= 32) return rounds ? skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 2, TR, false, MULTI ? 0 : 1>(a, grid, lds1, st)
+                                 : skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 2, TR>(a, grid, lds1, st);
+    return rounds ? skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 4, TR, false, MULTI ? 0 : 1>(a, grid, lds1, st)
+                  : skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 4, TR>(a, grid, lds1, st);
   }
 }
 
@@ -1417,7 +1602,7 @@ static hipError_t skinny_launch_nw(const GemvArgs& a0, hipStream_t st) {
   constexpr int E = ElemTraits<T>::kPer16B;
   GemvArgs a = a0;
   if (a.K % (4 * E) != 0 || a.B > 64) return hipErrorInvalidValue;
-  const size_t lds = (size_t)NW * 256 * 4;
+  const size_t lds = (size_t)NW * kRedTile * 4;
   const int tiles = (a.N + TR - 1) / TR;
   // at most `max_blocks` workgroups: tall matrices (the tied logits projection) walk several tiles per workgroup
   static const int max_blocks = env_int("TW_SK_MAX_BLOCKS", 512);
@@ -1426,6 +1611,23 @@ static hipError_t skinny_launch_nw(const GemvArgs& a0, hipStream_t st) {
   a.rg = (tiles + max_blocks - 1) / max_blocks;
   if (a.rg < 1 || steps_per_wave > (groups ? 5 : 10)) a.rg = 1;  // several tiles per workgroup only with one round per tile
   dim3 grid((tiles + a.rg - 1) / a.rg);
+  if constexpr (NW == 8) {
+    // more than 16 streams, one tile per workgroup, K an exact multiple of the wavefronts' step: operand rings (skinny_mfma_kernel MODE 2)
+    const int steps = a.K / E / 4;
+    if (groups && a.rg == 1 && cg_mode() >= 2 && steps % NW == 0 && !a.y_f32) {
+      const int spw = steps / NW;
+#define SK_RING(SPW) (a.B <= 32 ? skinny_launch_cg<T, NW, SPW, false, false, 2, TR, false, 2>(a, grid, lds, st) \
+                                : skinny_launch_cg<T, NW, SPW, false, false, 4, TR, false, 2>(a, grid, lds, st))
+      if constexpr (E == 8) {          // 16-bit contexts: K = 1280 / 5120
+        if (spw == 5) return SK_RING(5);
+        if (spw == 20) return SK_RING(20);
+      } else {                         // strict-f32 contexts
+        if (spw == 10) return SK_RING(10);
+        if (spw == 40) return SK_RING(40);
+      }
+#undef SK_RING
+    }
+  }
   if constexpr (TR != 16) {
     if (a.rg > 1) return hipErrorInvalidValue;
     if (steps_per_wave <= 5 || groups) return skinny_launch_v<T, NW, 5, false, false, TR>(a, grid, lds, st);
@@ -1445,7 +1647,7 @@ template <int NW, int TR>
 static hipError_t skinny_launch_w8(const GemvArgs& a0, hipStream_t st) {
   GemvArgs a = a0;
   if (a.K % 128 != 0 || a.B > 64) return hipErrorInvalidValue;
-  const size_t lds = (size_t)NW * 256 * 4;
+  const size_t lds = (size_t)NW * kRedTile * 4;
   const int tiles = (a.N + TR - 1) / TR;
   static const int max_blocks = env_int("TW_SK_MAX_BLOCKS", 512);
   const int steps_per_wave = (a.K / 128 + NW - 1) / NW;

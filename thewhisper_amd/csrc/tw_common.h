@@ -315,6 +315,10 @@ struct SamplerArgs {   // A10 + argmax + bookkeeping
   const unsigned* suppress_bits;  // static suppress list as a V-bit map (launch_suppress_bitmap)
   SamplerPartial* partials;       // [B][32] workspace between the two sampler launches
   int n_slices;                   // vocabulary slices per stream (set by launch_sampler)
+  // A6 fused into the sampler's last launch (round 5): x_next non-null = the wavefront that has just chosen stream b's token also
+  // writes the NEXT step's input row, tok_emb[token] + pos_emb[pos + 1], in the fragment-major activation layout (what launch_embed
+  // would write at the start of that step: one launch per step less).  dtype = the context's element type code (0 f32, 1 bf16, 2 f16).
+  const void* tok_emb; const void* pos_emb; void* x_next; int d; int dtype;
 };
 hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st);   // sampler + pos advance
 hipError_t launch_suppress_bitmap(const int* list, int n, unsigned* bits, int V, hipStream_t st);  // zero + set bits

@@ -11,9 +11,9 @@ int main(int argc, char** argv) {
   const size_t pool_bytes = 768ull << 20;
   char* pool; CK(hipMalloc(&pool, pool_bytes)); CK(hipMemset(pool, 0x11, pool_bytes));
   bf16_t *x, *y, *res, *bias, *g, *b; float* logits; float *gw, *cb;
-  CK(hipMalloc(&x, 16 * 5120 * 2)); CK(hipMalloc(&y, 16 * 5120 * 2)); CK(hipMalloc(&res, 16 * 5120 * 2));
+  CK(hipMalloc(&x, 64 * 5120 * 2)); CK(hipMalloc(&y, 64 * 5120 * 2)); CK(hipMalloc(&res, 64 * 5120 * 2));
   CK(hipMalloc(&bias, 52000 * 2)); CK(hipMalloc(&g, 1280 * 2)); CK(hipMalloc(&b, 1280 * 2)); CK(hipMalloc(&logits, 16 * 52000 * 4)); CK(hipMalloc(&gw, 52000 * 4)); CK(hipMalloc(&cb, 52000 * 4)); CK(hipMemset(gw, 0, 52000 * 4)); CK(hipMemset(cb, 0, 52000 * 4));
-  CK(hipMemset(x, 0, 16 * 5120 * 2)); CK(hipMemset(res, 0, 16 * 5120 * 2)); CK(hipMemset(bias, 0, 52000 * 2));
+  CK(hipMemset(x, 0, 64 * 5120 * 2)); CK(hipMemset(y, 0, 64 * 5120 * 2)); CK(hipMemset(res, 0, 64 * 5120 * 2)); CK(hipMemset(bias, 0, 52000 * 2));
   CK(hipMemset(g, 0, 2560)); CK(hipMemset(b, 0, 2560));
   const int NL = 128;
   DecState* stt; CK(hipMalloc(&stt, NL * sizeof(DecState)));
@@ -23,16 +23,32 @@ int main(int argc, char** argv) {
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_ts), &ts, sizeof(ts)));
 #endif
   CK(init_decode_kernels());
-  hipStream_t st; CK(hipStreamCreate(&st));
-  struct Shape { const char* name; int N, K; bool ln, resid, gelu; };
+  hipStream_t st;
+  // PROBE_CUS=160: the launches run on a stream confined to that many compute units (what the decode loop gets in production,
+  // thewhisper_amd/engine.py: THEWHISPER_DECODE_CUS = 160); default: the whole chip
+  const int cus = getenv("PROBE_CUS") ? atoi(getenv("PROBE_CUS")) : 0;
+  if (cus > 0) {
+    unsigned mask[8] = {0};
+    for (int i = 0; i < cus; ++i) mask[i / 32] |= 1u << (i % 32);
+    CK(hipExtStreamCreateWithCUMask(&st, 8, mask));
+  } else {
+    CK(hipStreamCreate(&st));
+  }
+  // the decoder layer's projection launches as production lays them out (api.hip: retile): rows, K, rows per weight tile
+  struct Shape { const char* name; int N, K; bool ln, resid, gelu; int tr; };
   const Shape shapes[] = {
-      {"o-proj  1280x1280      ", 1280, 1280, false, true, false},
-      {"q_c     1280x1280 LN   ", 1280, 1280, true, false, false},
-      {"qkv     3840x1280 LN   ", 3840, 1280, true, false, false},
-      {"fc1     5120x1280 LN G ", 5120, 1280, true, false, true},
-      {"fc2     1280x5120      ", 1280, 5120, false, true, false},
+      {"qkv+cq  5120x1280 LN    tr16", 5120, 1280, true, false, false, 16},
+      {"o+comp  2560x1280 res   tr16", 2560, 1280, false, true, false, 16},
+      {"o_cross 1280x1280 res   tr8 ", 1280, 1280, false, true, false, 8},
+      {"fc1     5120x1280 LN G  tr16", 5120, 1280, true, false, true, 16},
+      {"fc2     1280x5120 res   tr8 ", 1280, 5120, false, true, false, 8},
   };
-  for (int B : {1, 4, 16}) {
+  std::vector<int> Bs = {16, 32, 64};
+  if (getenv("PROBE_B")) { Bs.clear(); Bs.push_back(atoi(getenv("PROBE_B"))); }
+  printf("# probe_gemv: CUs=%s TW_SK_CG_MODE=%s RED_STRIDE=%d CG_ORDER=%d CG_EPI_ALL=%d\n", cus ? getenv("PROBE_CUS") : "all",
+         getenv("TW_SK_CG_MODE") ? getenv("TW_SK_CG_MODE") : "(2)", TW_RED_STRIDE, TW_CG_ORDER, TW_CG_EPI_ALL);
+  for (int B : Bs) {
+    double total_us = 0;
     for (const Shape& s : shapes) {
       const size_t wbytes = (size_t)s.N * s.K * 2;
       hipGraph_t gr; hipGraphExec_t ge;
@@ -40,7 +56,7 @@ int main(int argc, char** argv) {
       for (int i = 0; i < NL; ++i) {
         GemvArgs a{};
         a.x = (i & 1) ? y : x; a.ldx = s.K; a.W = pool + ((size_t)i * wbytes) % (pool_bytes - wbytes); a.bias = bias;
-        a.N = s.N; a.K = s.K; a.B = B; a.gelu = s.gelu; a.y = (i & 1) ? x : y; a.ldy = s.N;
+        a.N = s.N; a.K = s.K; a.B = B; a.gelu = s.gelu; a.y = (i & 1) ? x : y; a.ldy = s.N; a.tr = s.tr;
         if (s.ln) { a.ln_gw = gw; a.ln_cb = cb; }
         if (s.resid) { a.res = res; a.ldres = s.N; }
         a.stt = stt + i;
@@ -59,6 +75,7 @@ int main(int argc, char** argv) {
       CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       const double us = ms * 1e3 / (R * NL);
+      total_us += us;
       printf("B=%2d %s: %6.2f us/launch  (%.2f TB/s of weights)\n", B, s.name, us, wbytes / us * 1e-6);
 #ifdef TW_PROBE_TS
       {
@@ -86,6 +103,7 @@ int main(int argc, char** argv) {
 #endif
       hipGraphExecDestroy(ge); hipGraphDestroy(gr);
     }
+    printf("B=%2d sum of the five projection launches of a layer: %.2f us\n", B, total_us);
   }
   return 0;
 }
