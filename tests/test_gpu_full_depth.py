@@ -327,8 +327,16 @@ F16 = dict(logit_tol=5e-3, enc_tol=4e-3, top_abs=0.02, ts_bounds=dict(surface_re
 #   bf16     0.016           0.068-0.076   0.104-0.115                0.003-0.005     0.80 / 0.53   (HF-bf16 itself: 0.94 / 0.53)
 #   fp8a16   0.063-0.066     0.20-0.21     0.145-0.163                0.009-0.014     0.66 / 0.43
 #   fp8a8    0.082-0.085     0.28-0.34     0.37-0.41                  0.024-0.127     0.57 / 0.39
-FP8A8 = dict(logit_tol=0.13, enc_tol=3e-2, top_abs=0.5, margin_mult=2.0, ts_bounds=dict(surface_rel=0.6, excess_frac=0.3, within_1_frame=0.2))
-FP8A16 = dict(logit_tol=0.10, enc_tol=3e-2, top_abs=0.32, margin_mult=2.0, ts_bounds=dict(surface_rel=0.25, excess_frac=0.0625, within_1_frame=0.3))
+# Round 5: bounds = 1.25 x the worst value measured in round 4 (the previous 1.5-2 x left room for a regression of half the effect):
+#   fp8a16 worst: logits 0.0662, top-8 0.2142, surface 0.1585, excess 0.0137, within one frame 0.50
+#   fp8a8  worst: logits 0.0861, top-8 0.3950 (random-token pass), surface 0.3991, excess 0.1566, within one frame 0.385
+# W8A8's top-1 rule ("arg-max identical wherever the golden margin exceeds 2 x top_abs" = 1.0) binds on 0-0.5 % of the steps of these
+# goldens, i.e. it asserts nothing (round-3 and round-4 reviews): it is SWITCHED OFF for that flavour (margin_mult = inf: every
+# arg-max change is reported as a sub-margin flip, none is an error) rather than kept as a rule that cannot fail; what W8A8 is held
+# to are the logits / top-8 / surface / excess bounds.  W8A16 - the flavour that ships as dtype="fp8" - keeps the rule, which binds on
+# a third of all steps at top_abs = 0.27 (asserted >= 0.30 below).
+FP8A8 = dict(logit_tol=0.108, enc_tol=3e-2, top_abs=0.5, margin_mult=float("inf"), ts_bounds=dict(surface_rel=0.5, excess_frac=0.2, within_1_frame=0.3))
+FP8A16 = dict(logit_tol=0.083, enc_tol=3e-2, top_abs=0.27, margin_mult=2.0, ts_bounds=dict(surface_rel=0.2, excess_frac=0.0175, within_1_frame=0.4))
 
 
 # ordered so that consecutive cases share the (6 GB, ~20 s to generate) seeded state dict

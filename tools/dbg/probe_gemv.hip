@@ -43,10 +43,11 @@ int main(int argc, char** argv) {
       {"fc1     5120x1280 LN G  tr16", 5120, 1280, true, false, true, 16},
       {"fc2     1280x5120 res   tr8 ", 1280, 5120, false, true, false, 8},
   };
+  const int tr_narrow = getenv("PROBE_TR_NARROW") ? atoi(getenv("PROBE_TR_NARROW")) : 8;   // rows per tile of the N = 1280 launches
   std::vector<int> Bs = {16, 32, 64};
   if (getenv("PROBE_B")) { Bs.clear(); Bs.push_back(atoi(getenv("PROBE_B"))); }
-  printf("# probe_gemv: CUs=%s TW_SK_CG_MODE=%s RED_STRIDE=%d CG_ORDER=%d CG_EPI_ALL=%d\n", cus ? getenv("PROBE_CUS") : "all",
-         getenv("TW_SK_CG_MODE") ? getenv("TW_SK_CG_MODE") : "(2)", TW_RED_STRIDE, TW_CG_ORDER, TW_CG_EPI_ALL);
+  printf("# probe_gemv: CUs=%s TW_SK_CG_MODE=%s RED_STRIDE=%d CG_ORDER=%d CG_EPI_ALL=%d tr_narrow=%d\n", cus ? getenv("PROBE_CUS") : "all",
+         getenv("TW_SK_CG_MODE") ? getenv("TW_SK_CG_MODE") : "(default)", TW_RED_STRIDE, TW_CG_ORDER, TW_CG_EPI_ALL, tr_narrow);
   for (int B : Bs) {
     double total_us = 0;
     for (const Shape& s : shapes) {
@@ -56,7 +57,7 @@ int main(int argc, char** argv) {
       for (int i = 0; i < NL; ++i) {
         GemvArgs a{};
         a.x = (i & 1) ? y : x; a.ldx = s.K; a.W = pool + ((size_t)i * wbytes) % (pool_bytes - wbytes); a.bias = bias;
-        a.N = s.N; a.K = s.K; a.B = B; a.gelu = s.gelu; a.y = (i & 1) ? x : y; a.ldy = s.N; a.tr = s.tr;
+        a.N = s.N; a.K = s.K; a.B = B; a.gelu = s.gelu; a.y = (i & 1) ? x : y; a.ldy = s.N; a.tr = s.tr == 8 ? tr_narrow : s.tr;
         if (s.ln) { a.ln_gw = gw; a.ln_cb = cb; }
         if (s.resid) { a.res = res; a.ldres = s.N; }
         a.stt = stt + i;
