@@ -104,6 +104,10 @@ DEC_CASES = [
     ("micro", 750, 2, "f32", 2, 2e-5), ("micro", 750, 3, "bf16", 2, 3e-2),   # 15 s chunks: two key chunks, second one partial
     ("micro", 100, 17, "f32", 2, 2e-5), ("micro", 100, 40, "bf16", 2, 3e-2), ("micro", 100, 64, "f32", 1, 2e-5),  # > 16 streams: groups of 16
     ("large-v3", 500, 32, "bf16", 1, 3e-2),
+    # round 5: the operand-ring projection kernels (more than 16 streams at the real width: K = 1280 / 5120 - the micro presets never
+    # reach them) against the oracle: two and four groups of 16 streams, every element type (the strict-f32 rings to 2e-5)
+    ("large-v3", 100, 64, "f32", 1, 2e-5), ("large-v3", 100, 24, "f32", 1, 2e-5), ("large-v3", 100, 64, "bf16", 1, 3e-2),
+    ("large-v3", 100, 40, "f16", 1, 4e-3),
     ("micro", 50, 2, "f32", 2, 2e-5), ("micro", 1250, 2, "f32", 2, 2e-5), ("micro", 1450, 3, "bf16", 2, 3e-2),   # ragged last key tile
     # float16 contexts
     ("micro", 100, 16, "f16", 2, 4e-3), ("large-v3", 500, 2, "f16", 1, 4e-3), ("large-v3", 500, 16, "f16", 1, 4e-3),

@@ -37,8 +37,6 @@ __device__ unsigned long long* g_probe_ts;
 //  TW_CG_ORDER     several groups of 16 streams per launch: the HBM weight requests leave FIRST and the (L2) activation requests follow in
 //                  consumption order (step-major); 0 = the order of the one-group kernel (activations first, group-major), which puts
 //                  20 KiB of L2 traffic per wavefront in front of the first HBM request.
-//  TW_CG_PREFETCH  ... and K longer than one round of fragments (fc2): the NEXT round's weight fragments are requested one round ahead
-//                  (second register set), so a round waits for its activation stream only.
 //  TW_CG_EPI_ALL   ... the epilogue of the groups is spread over all 512 threads (two halves of the workgroup take alternate groups).
 //  TW_CG_RING     several groups, 16-bit or f32 weights, one tile per workgroup: the template parameter SK_MAXS is then the wavefront's
 //                  WHOLE step count and the operands go through two register RINGS (weights: 5 steps deep, activations: 3 steps x
@@ -54,9 +52,6 @@ __device__ unsigned long long* g_probe_ts;
 #endif
 #ifndef TW_CG_ORDER
 #define TW_CG_ORDER 1
-#endif
-#ifndef TW_CG_PREFETCH
-#define TW_CG_PREFETCH 1
 #endif
 #ifndef TW_CG_EPI_ALL
 #define TW_CG_EPI_ALL 1
@@ -355,27 +350,19 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
   const int tile0 = blockIdx.x * RG;
   const int ej = (tid >> 4) & 15, ei = tid & 15;  // epilogue role of threads 0..255: stream ej, tile row ei (rows >= TR idle)
 
-  // several groups, long K: a second set of weight registers holds the NEXT round's fragments (TW_CG_PREFETCH)
-  // MODE (several groups of streams only; picked by the launcher): 0 = rounds of SK_MAXS fragments, 1 = the same with the next
-  // round's weights requested a round ahead (only for launches whose K takes several rounds - for the others the request would be
-  // waste), 2 = operand rings over the wavefront's whole K slice (TW_CG_RING above; SK_MAXS = the slice's step count)
-  constexpr bool PF = CG > 1 && TW_CG_PREFETCH && !MULTI && MODE == 1;
-  constexpr bool RING = CG > 1 && TW_CG_RING && !W8 && MODE == 2;
-  // RING with MULTI = DUAL: the workgroup contracts TWO weight tiles (tile0, tile0 + 1; the launcher sets RG = 2) against ONE sweep of
-  // the activation rings - half the activation (L2) traffic of two workgroups, 160 instead of 320 workgroups for the 5120-row launches
-  constexpr bool DUAL = RING && MULTI;
+  // MODE (several groups of streams only; picked by the launcher): 0 = rounds of SK_MAXS fragments, 2 = operand rings over the
+  // wavefront's whole K slice (TW_CG_RING above; SK_MAXS = the slice's step count).  (1 - rounds with the next round's weights
+  // requested a round ahead - was measured in round 5 and dropped: fc2 at 64 streams 12.1 -> 12.6 us, profiles/r05_projection_probe.txt)
+  constexpr bool RING = CG > 1 && TW_CG_RING && !MULTI && !W8 && MODE == 2;
   constexpr int DW = RING ? (SK_MAXS < 5 ? SK_MAXS : 5) : 1;   // ring depths (steps)
   constexpr int DX = RING ? (SK_MAXS < 3 ? SK_MAXS : 3) : 1;
   u32x4_t rw[DW], rx[DX][CG];
-  u32x4_t rw2[DUAL ? DW : 1];
   // several groups: the two 256-thread halves of the workgroup take alternate groups in the epilogue (TW_CG_EPI_ALL)
   constexpr bool EALL = CG > 1 && TW_CG_EPI_ALL && NW >= 8;
   constexpr int GPT = EALL ? CG / 2 : CG;     // groups per epilogue thread
   u32x4_t wq[SK_MAXS * WPS], xq[CG][SK_MAXS * XPS];
   int wsc[SK_MAXS];  // MXFP8: scale byte of the weight block this lane feeds to the scaled MFMA (A16: of its own first block)
   int wsc2[A16 ? SK_MAXS : 1];  // A16: scale byte of its own second block
-  u32x4_t wqn[PF ? SK_MAXS * WPS : 1];
-  int wscn[PF ? SK_MAXS : 1], wsc2n[(PF && A16) ? SK_MAXS : 1];
   const int eh = EALL ? ((tid >> 8) & 1) : 0;   // which half of the workgroup this epilogue thread belongs to
   float e_c = 0.f, e_gw = 0.f, e_res[GPT];
 #pragma unroll
@@ -496,8 +483,8 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
     }
   };
 
-  auto ring_w = [&](int step, int tile_ofs = 0) -> u32x4_t {   // one weight fragment of this workgroup's tile (RING: every step is inside the matrix)
-    const int tl = min(tile0 + tile_ofs, n_tiles - 1);
+  auto ring_w = [&](int step) -> u32x4_t {   // one weight fragment of this workgroup's tile (RING: every step is inside the matrix)
+    const int tl = min(tile0, n_tiles - 1);
     if constexpr (TR == 16) {
       return sk_load_w<T>(W + ((long long)tl * S * 64 + lane) * E + (long long)step * (64 * E));
     } else {
@@ -512,10 +499,7 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
   if constexpr (RING) {
     // HBM first, then the first DX steps of activations in consumption order; everything else is requested as registers free up
 #pragma unroll
-    for (int i = 0; i < DW; ++i) {
-      rw[i] = ring_w(s_lo + i);
-      if constexpr (DUAL) rw2[i] = ring_w(s_lo + i, 1);
-    }
+    for (int i = 0; i < DW; ++i) rw[i] = ring_w(s_lo + i);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < DX; ++i)
@@ -529,19 +513,11 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
     __builtin_amdgcn_sched_barrier(0);
     load_x(s_lo);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (PF) {
-      load_w_into(wqn, wscn, wsc2n, tile0, s_lo + SK_MAXS);   // (clamped to the matrix; unused when K fits one round)
-      __builtin_amdgcn_sched_barrier(0);
-    }
   } else {
     load_x(s_lo);
     __builtin_amdgcn_sched_barrier(0);  // request order = consumption order: hipcc must not reorder the groups
     load_w(tile0, s_lo);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (PF) {
-      load_w_into(wqn, wscn, wsc2n, tile0, s_lo + SK_MAXS);
-      __builtin_amdgcn_sched_barrier(0);
-    }
   }
   // (2) everything else (epilogue operands, outputs, cache geometry): ONE batch of scalar loads from the argument block, waited for
   // here, behind the operand requests that are already on their way
@@ -560,7 +536,6 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
 #pragma unroll
   for (int g = 0; g < GPT; ++g) { mean[g] = 0.f; rstd[g] = 1.f; }
   const int n_grp = MULTI ? RG : 1;
-  f32x4_t acc2[(CG > 1) ? CG : 1];   // DUAL: the second tile's accumulators, filled together with the first tile's
   for (int grp = 0; grp < n_grp; ++grp) {
     const int tile = tile0 + grp;
     f32x4_t acc[CG];
@@ -612,50 +587,25 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
       }
     };
     if constexpr (RING) {
-      if (!DUAL || grp == 0) {
 #pragma unroll
-        for (int g = 0; g < CG; ++g) acc2[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < SK_MAXS; ++i) {
 #pragma unroll
-        for (int i = 0; i < SK_MAXS; ++i) {
-#pragma unroll
-          for (int g = 0; g < CG; ++g) {
-            const u32x4_t xv = rx[i % DX][g];
-            if (LN) sk_stats<T>(xv, ps[g], pss[g]);
-            acc[g] = sk_mfma<T>(rw[i % DW], xv, acc[g]);
-            if constexpr (DUAL) acc2[g] = sk_mfma<T>(rw2[i % DW], xv, acc2[g]);
-          }
-          if (i + DX < SK_MAXS) {
-#pragma unroll
-            for (int g = 0; g < CG; ++g) rx[i % DX][g] = ring_x(g, s_lo + i + DX);
-          }
-          if (i + DW < SK_MAXS) {
-            rw[i % DW] = ring_w(s_lo + i + DW);
-            if constexpr (DUAL) rw2[i % DW] = ring_w(s_lo + i + DW, 1);
-          }
-          __builtin_amdgcn_sched_barrier(0);   // keep the software pipeline in this order
+        for (int g = 0; g < CG; ++g) {
+          const u32x4_t xv = rx[i % DX][g];
+          if (LN) sk_stats<T>(xv, ps[g], pss[g]);
+          acc[g] = sk_mfma<T>(rw[i % DW], xv, acc[g]);
         }
-      } else {   // DUAL, second tile: contracted together with the first
+        if (i + DX < SK_MAXS) {
 #pragma unroll
-        for (int g = 0; g < CG; ++g) acc[g] = acc2[g];
+          for (int g = 0; g < CG; ++g) rx[i % DX][g] = ring_x(g, s_lo + i + DX);
+        }
+        if (i + DW < SK_MAXS) rw[i % DW] = ring_w(s_lo + i + DW);
+        __builtin_amdgcn_sched_barrier(0);   // keep the software pipeline in this order
       }
     } else {
     mfma_round(s_lo);  // operands already in flight
     for (int s0 = s_lo + SK_MAXS; s0 < s_hi; s0 += SK_MAXS) {  // K longer than one round of fragments
-      if constexpr (PF) {
-        // this round's weights were requested a round ago (wqn): ask for the activations, take the weights over, ask for the
-        // round after - a round waits for its activation stream, not for HBM
-        load_x(s0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < SK_MAXS * WPS; ++i) wq[i] = wqn[i];
-        if constexpr (W8) {
-#pragma unroll
-          for (int i = 0; i < SK_MAXS; ++i) { wsc[i] = wscn[i]; if constexpr (A16) wsc2[i] = wsc2n[i]; }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        load_w_into(wqn, wscn, wsc2n, tile, s0 + SK_MAXS);
-        __builtin_amdgcn_sched_barrier(0);
-      } else if constexpr (CG > 1 && TW_CG_ORDER) {
+      if constexpr (CG > 1 && TW_CG_ORDER) {
         load_w(tile, s0);
         __builtin_amdgcn_sched_barrier(0);
         load_x(s0);
@@ -673,7 +623,7 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
     for (int g = 0; g < GPT; ++g) n_res[g] = 0.f;
     if (MULTI) {
       const int nt = min(tile + 1, n_tiles - 1);
-      if constexpr (!RING) load_w(nt, s_lo);
+      load_w(nt, s_lo);
       load_epi(nt, n_c, n_gw, n_res);
     }
     TW_TS(2);
@@ -1536,9 +1486,9 @@ static int env_int(const char* name, int dflt) {
 }
 
 // how launches for more than 16 streams move their operands (skinny_mfma_kernel's MODE): 2 = operand rings where the shape allows
-// (default), 1 = rounds with the next round's weights a round ahead, 0 = plain rounds (rounds 3-4); TW_SK_CG_MODE for A/B runs
-static int cg_mode() {   // 3 = 2 + two tiles per workgroup (DUAL) for the launches with more tiles than TW_SK_RING_BLOCKS
-  static const int m = env_int("TW_SK_CG_MODE", 3);
+// (default), 0 = plain rounds (rounds 3-4); TW_SK_CG_MODE for A/B runs
+static int cg_mode() {
+  static const int m = env_int("TW_SK_CG_MODE", 2);
   return m;
 }
 
@@ -1597,11 +1547,8 @@ static hipError_t skinny_launch_v(const GemvArgs& a, dim3 grid, size_t lds1, hip
       if constexpr (NW != 8 || SK_MAXS != 2) {
         return hipErrorInvalidValue;
       } else {
-        const bool rounds = !MULTI && cg_mode() >= 1 && (a.K / 128 + NW - 1) / NW > SK_MAXS;   // K takes several rounds of fragments: weights a round ahead
-        if (a.B <= 32) return rounds ? skinny_launch_cg<T, NW, SK_MAXS, MULTI, true, 2, TR, true, MULTI ? 0 : 1>(a, grid, lds1, st)
-                                     : skinny_launch_cg<T, NW, SK_MAXS, MULTI, true, 2, TR, true>(a, grid, lds1, st);
-        return rounds ? skinny_launch_cg<T, NW, SK_MAXS, MULTI, true, 4, TR, true, MULTI ? 0 : 1>(a, grid, lds1, st)
-                      : skinny_launch_cg<T, NW, SK_MAXS, MULTI, true, 4, TR, true>(a, grid, lds1, st);
+        if (a.B <= 32) return skinny_launch_cg<T, NW, SK_MAXS, MULTI, true, 2, TR, true>(a, grid, lds1, st);
+        return skinny_launch_cg<T, NW, SK_MAXS, MULTI, true, 4, TR, true>(a, grid, lds1, st);
       }
     }
     if (a.B > 16) return hipErrorInvalidValue;
@@ -1613,11 +1560,8 @@ static hipError_t skinny_launch_v(const GemvArgs& a, dim3 grid, size_t lds1, hip
   if constexpr (W8 || NW != 8 || SK_MAXS != 5) {
     return hipErrorInvalidValue;
   } else {
-    const bool rounds = !MULTI && cg_mode() >= 1 && (a.K / (4 * ElemTraits<T>::kPer16B) + NW - 1) / NW > SK_MAXS;   // several rounds: weights a round ahead
-    if (a.B <= 32) return rounds ? skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 2, TR, false, MULTI ? 0 : 1>(a, grid, lds1, st)
-                                 : skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 2, TR>(a, grid, lds1, st);
-    return rounds ? skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 4, TR, false, MULTI ? 0 : 1>(a, grid, lds1, st)
-                  : skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 4, TR>(a, grid, lds1, st);
+    if (a.B <= 32) return skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 2, TR>(a, grid, lds1, st);
+    return skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 4, TR>(a, grid, lds1, st);
   }
 }
 
@@ -1636,26 +1580,18 @@ static hipError_t skinny_launch_nw(const GemvArgs& a0, hipStream_t st) {
   if (a.rg < 1 || steps_per_wave > (groups ? 5 : 10)) a.rg = 1;  // several tiles per workgroup only with one round per tile
   dim3 grid((tiles + a.rg - 1) / a.rg);
   if constexpr (NW == 8) {
-    // more than 16 streams, K an exact multiple of the wavefronts' step: operand rings (skinny_mfma_kernel MODE 2), one tile per
-    // workgroup - or, for the launches with more 16-row tiles than the decode loop has compute units (QKV, fc1: 320 on 160 CUs),
-    // TWO tiles per workgroup contracted against one sweep of the activation rings (DUAL: half the activation traffic)
+    // more than 16 streams, one tile per workgroup, K an exact multiple of the wavefronts' step: operand rings (skinny_mfma_kernel MODE 2)
     const int steps = a.K / E / 4;
-    static const int ring_blocks = env_int("TW_SK_RING_BLOCKS", 160);
-    if (groups && cg_mode() >= 2 && steps % NW == 0 && !a.y_f32 && a.rg == 1) {
+    if (groups && a.rg == 1 && cg_mode() >= 2 && steps % NW == 0 && !a.y_f32) {
       const int spw = steps / NW;
-      bool dual = false;
-      if constexpr (TR == 16) dual = cg_mode() >= 3 && ring_blocks > 0 && tiles > ring_blocks && tiles <= 2 * ring_blocks && tiles % 2 == 0 && spw <= 10;
-      if (dual) { a.rg = 2; grid = dim3(tiles / 2); }
-#define SK_RING(SPW, MU) (a.B <= 32 ? skinny_launch_cg<T, NW, SPW, MU, false, 2, TR, false, 2>(a, grid, lds, st) \
-                                    : skinny_launch_cg<T, NW, SPW, MU, false, 4, TR, false, 2>(a, grid, lds, st))
+#define SK_RING(SPW) (a.B <= 32 ? skinny_launch_cg<T, NW, SPW, false, false, 2, TR, false, 2>(a, grid, lds, st) \
+                                : skinny_launch_cg<T, NW, SPW, false, false, 4, TR, false, 2>(a, grid, lds, st))
       if constexpr (E == 8) {          // 16-bit contexts: K = 1280 / 5120
-        if constexpr (TR == 16) { if (dual && spw == 5) return SK_RING(5, true); }
-        if (spw == 5) return SK_RING(5, false);
-        if (spw == 20) return SK_RING(20, false);
+        if (spw == 5) return SK_RING(5);
+        if (spw == 20) return SK_RING(20);
       } else {                         // strict-f32 contexts
-        if constexpr (TR == 16) { if (dual && spw == 10) return SK_RING(10, true); }
-        if (spw == 10) return SK_RING(10, false);
-        if (spw == 40) return SK_RING(40, false);
+        if (spw == 10) return SK_RING(10);
+        if (spw == 40) return SK_RING(40);
       }
 #undef SK_RING
     }

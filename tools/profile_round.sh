@@ -21,6 +21,12 @@ f=$(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1)
 t=$(find /tmp/prof_stats -name "*kernel_trace.csv" | head -1)
 cp $f $OUT/${R}_large-v3_b16_kernel_stats.csv
 (cd $ROOT && python tools/summarize_rocprof.py $f > $OUT/${R}_kernel_table.md; python tools/trace_by_shape.py $t 30 > $OUT/${R}_large-v3_b16_by_shape.txt)
+# the same WITHOUT the encoder overlap (one context, stages back to back): the per-step kernel sum of THIS trace is what the HIP-event
+# step time of a decode-only run is compared with (under the overlap the encoder's launches on the other CUs stretch the decode kernels)
+rm -rf /tmp/prof_dec
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_dec -o p -- python $ROOT/bench.py --steps 2 --warmup 1 --encoder-cus 0 --no-cpu-baseline --no-pipeline-leg --no-secondary --latency-iters 0 > $OUT/${R}_bench_profiled_run_decode_only.json 2>/dev/null
+t=$(find /tmp/prof_dec -name "*kernel_trace.csv" | head -1)
+(cd $ROOT && python tools/trace_by_shape.py $t 30 > $OUT/${R}_large-v3_b16_by_shape_decode_only.txt)
 PMCARGS="--steps 1 --warmup 0 --no-graph --encoder-cus 0 --no-cpu-baseline --no-pipeline-leg --no-secondary --latency-iters 0"
 for C in FETCH_SIZE WRITE_SIZE; do
   d=/tmp/prof_$C; rm -rf $d
