@@ -13,11 +13,23 @@ N ranks (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master
 RCCL for the barrier / max / sum); launched by the driver through torch.distributed.run it reads RANK / LOCAL_RANK /
 WORLD_SIZE from the environment.  Rank 0 prints ONE JSON line.
 
+`--scaling strong --total-streams 128` (round 5): the streams are a FIXED total sharded over the ranks
+(stream i on rank i % N), each rank takes its share in passes of at most 64 streams; the default is weak scaling (--streams per GPU).
+
 Besides the engine-level headline the line carries (rank 0, N = 1 only):
-  * `pipeline`: the same workload THROUGH the drop-in API - tokens/s of 16 session threads behind the BatchingHub
-    (thewhisper_amd/serving.py) and the p50 wall time of `AMDWhisperBackend.transcribe` on a 10 s host buffer
-    (the metric as SURVEY.md section 8d defines it, R:thestage_speechkit/streaming/streaming_pipeline.py:388-435);
-  * `cpu_baseline`: the reference's PyTorch-CPU path on this box's host cores (bounded sample);
+  * the CONTRACT's definitions first: `value_contract` (tokens over wall-clock from transcribe() entry to return,
+    host buffers in, words out, 16 free-running sessions behind the BatchingHub), `p50_chunk_latency_contract_ms` (one
+    `AMDWhisperBackend.transcribe` call on a 10 s host buffer, R:thestage_speechkit/streaming/streaming_pipeline.py:388-435),
+    `hub_request_p50_ms` / `_p90_ms`; the engine-level figures stay beside them (`value`, `p50_chunk_latency_ms`);
+  * `config3`: BASELINE config 3's call pattern - the 117 backend calls the REFERENCE'S OWN scheduler + stepper make for one 60 s stream
+    (tests/golden/config3_trace.json, generated and re-derived from the reference: oracle/config3_trace.py) - replayed through the
+    backend at large-v3 dimensions: p50 / p90 per call, calls per audio second, with and without `reuse_committed_prefix`;
+  * `value_f16`, `roofline_f16`, `parity_full_depth`: the float16 context (the reference's streaming default dtype; the 16-bit context whose
+    greedy ids equal the fp32 reference's on every clip) on the same schedule, and the id-identity figures of both dtypes from the
+    committed GPU-suite log;
+  * `pipeline`: everything measured through the drop-in API (hub legs, two cohorts, short passes, lock-step);
+  * `cpu_baseline`: the reference's own `nvidia.ASRPipeline` on this box's host cores (bounded sample; `kind: "reference"` wherever the
+    reference package is importable - /root/reference, or the oracle/_ref bundle on the GPU box);
   * `roofline`: decode step, algorithmic bytes (W = 2*(Ld*14*d^2 + V*d)) over HIP-event time.
 """
 from __future__ import annotations
