@@ -931,15 +931,10 @@ static hipError_t gemm_dispatch(const void* A, RowMap amap, const void* W, int M
   // launch is bound by the aggregate operand traffic of its small tiles (210 MB for fc1 at M = 500 = 6 TB/s), not by latency
   // (profiles/r04_gemm_deep_ring_ab.txt).  TW_GEMM_SMALL_64=0 restores the round-3 choice.
   static const int small64 = gemm_env("TW_GEMM_SMALL_64", 1);
-  // Round 5: the deep rings ONLY for the narrow projections of a single stream (N <= 2048: out-projection, fc2 - 80 / 240 workgroups
-  // walking 20 / 80 K tiles, latency-bound: round 4 measured 15.5 -> 12.5 and 39.5 -> 30 us at M = 500), which is where they won; the
-  // wide ones keep two workgroups per CU.  Same tiles, same accumulation order: results do not change.  Bit 0: 64 x 64 tiles on 8
-  // stages (M <= 1000), bit 1: 128 x 64 tiles on 6 stages (larger single-stream M); TW_GEMM_DEEP_NARROW=0 restores round 4.
-  static const int deep_narrow = gemm_env("TW_GEMM_DEEP_NARROW", 3);
   if (forced >= 0) cfg = forced;
   else if (N % 256 == 0 && b128 >= wreg_min) cfg = (N <= 2048) ? narrow : 5;
-  else if (small64 && M <= 1000) cfg = (N <= 2048 && (deep_narrow & 1)) ? 13 : 12;
-  else if (M > 64) cfg = (N <= 2048 && (deep_narrow & 2)) ? 14 : 1;
+  else if (small64 && M <= 1000) cfg = 12;
+  else if (M > 64) cfg = 1;
   else cfg = 0;
   if (cfg == 5) {
     // Tile HEIGHT of kernel 2 by how the grid divides over the chip.  Two workgroups share a CU's matrix pipe, so a CU's time is
@@ -974,8 +969,6 @@ static hipError_t gemm_dispatch(const void* A, RowMap amap, const void* W, int M
     case 4: return gemm_go<T, 128, 128, 2, 2, 2>(A, amap, W, M, N, K, ep, st);
     case 1: return gemm_go<T, 128, 64, 2, 2, 3>(A, amap, W, M, N, K, ep, st);
     case 12: return gemm_go<T, 64, 64, 2, 2, 4>(A, amap, W, M, N, K, ep, st);     // 64 KB: two workgroups per CU
-    case 13: return gemm_go<T, 64, 64, 2, 2, 8>(A, amap, W, M, N, K, ep, st);     // 128 KB ring: one workgroup per CU, 7 K tiles ahead
-    case 14: return gemm_go<T, 128, 64, 2, 2, 6>(A, amap, W, M, N, K, ep, st);    // 144 KB ring
     default: return gemm_go<T, 64, 64, 2, 2, 2>(A, amap, W, M, N, K, ep, st);
   }
 }
