@@ -212,3 +212,29 @@ def test_call_wider_than_the_engine_and_a_decoder_that_never_advances():
 
     with pytest.raises(RuntimeError, match="seek passes"):
         shortform.generate_shortform(Stuck(), plan, feats.input_features[:2], feats.attention_mask[:2])
+
+
+def test_kept_columns_rule_of_the_host_mirror_equals_the_pinned_restatement():
+    """`shortform.hf_kept_columns` (product) and `oracle.whisper_oracle.hf_kept_columns` (pinned to HF's own `_extract_token_timestamps`
+    for every flavour of `num_frames`, tests/test_oracle_vs_hf.py) are two statements of the same rule; the engine bound derived from it
+    (`columns_as_num_frames`: one Python-slice crop per row, include/thewhisper.h) keeps exactly those columns."""
+    import torch
+
+    from oracle import whisper_oracle as wo
+    from thewhisper_amd import shortform as sf
+
+    rng = np.random.default_rng(0)
+    cases = [None, 3000, 1067, -1721, 0, -1, 1, [3000] * 3, [-1721], [-400, -400], [-2999, -2999], [-3000] * 2, [-5000], [1067, 2900], [-1721, 900, 40],
+             np.array([-1000, -1000]), torch.tensor([-400, 700]), torch.tensor([-1721])]
+    cases += [rng.integers(-3200, 3200, size=int(rng.integers(1, 5))).tolist() for _ in range(200)]
+    cases += [[int(rng.integers(-3200, 3200))] * int(rng.integers(1, 4)) for _ in range(200)]
+    for T in (1500, 500, 100, 7):
+        for nf in cases:
+            B = 3 if nf is None or isinstance(nf, int) else len(nf)
+            want = wo.hf_kept_columns(nf, B, T)
+            got = sf.hf_kept_columns(nf, B, T)
+            assert got == want, (T, nf, got, want)
+            # the C ABI's per-row rule applied to the derived bound keeps exactly those columns
+            for c, n in zip(got, sf.columns_as_num_frames(got)):
+                k = n // 2
+                assert (min(T, k) if k >= 0 else max(0, T + k)) == c
