@@ -64,3 +64,21 @@ def test_bench_strong_scaling_mode_shards_a_fixed_total(gpus, share, passes, per
     assert (c["total_streams"], c["streams_per_gpu"], c["passes_per_step"], c["streams_per_pass"]) == (128, share, passes, per_pass)
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 * d["steps"] - d["steps"] * 128 * 128) < 1.0     # 128 streams x 128 tokens per step
     assert d["roofline"]["streams_per_launch"] == per_pass
+
+
+def test_parity_block_reads_the_committed_full_depth_log():
+    """bench.py's `parity_full_depth` block: the id-identity figures of a dtype come from the newest committed GPU-suite log."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    f16, bf16 = bench.full_depth_parity("f16"), bench.full_depth_parity("bf16")
+    assert f16 and bf16 and f16["clips"] == 16
+    assert f16["ids_identical_clips"] == 16                       # the float16 context carries the id-identity claim
+    assert 0 < bf16["ids_identical_clips"] <= 16 and bf16["logits_rel_l2"] > f16["logits_rel_l2"]
+    assert "gpu_tests_full_depth.log" in f16["source"]
+    assert bench.full_depth_parity("int3") is None
+
+
+def test_config3_trace_is_where_the_bench_expects_it():
+    tr = json.load(open(os.path.join(ROOT, "tests", "golden", "config3_trace.json")))
+    assert tr["chunk_length_s"] == 10 and len(tr["calls"]) == 117 and all(set(c) == {"offset", "n", "t0"} for c in tr["calls"])
