@@ -722,6 +722,8 @@ def main(argv=None):
                     help="skip the hub measurement with twice as many sessions as rows per pass (hub_2x_*)")
     ap.add_argument("--hub-prefetch-cus", type=int, default=96,
                     help="compute units of the side stream that encodes arrivals while a hub pass decodes (0 = off; serving.py)")
+    ap.add_argument("--no-streams-sweep", dest="streams_sweep", action="store_false",
+                    help="skip the compact 32 / 64 / 2 x 64 streams-per-GPU legs (the single-GPU points of the strong-scaling curve)")
     ap.add_argument("--hub-short-tokens", type=int, default=24,
                     help="max_new_tokens of the second hub measurement (the <= 2 passes per buffer regime; 0 = skip)")
     args = ap.parse_args(argv)
@@ -947,6 +949,40 @@ def main(argv=None):
             except Exception as e:  # noqa: BLE001
                 result["value_f16"] = None
                 result["f16_note"] = f"failed: {e!r}"
+        # ---- streams per GPU: what ONE MI355X delivers with 32 and 64 streams per weight pass, and with BASELINE configs[3]'s whole 128
+        # streams as two passes of 64 = the N = 1 point of the strong-scaling curve.  Replicas share nothing, so
+        # the other points of that curve are these per-GPU rates times N (128 / N streams per GPU): N = 2 -> 2 x the 64-stream rate,
+        # N = 4 -> 4 x the 32-stream rate, N = 8 -> 8 x the headline; a node run with `--scaling strong` measures them directly.
+        if world == 1 and not stub and not args.no_secondary and args.streams_sweep and args.scaling == "weak" and args.streams == 16:
+            if run is not None:
+                run.close()
+                run = None
+                torch.cuda.empty_cache()
+            sweep = []
+            sargs = argparse.Namespace(**{**vars(args), "steps": 3, "warmup": 1})
+            for label, sh in (("32 streams per GPU", 32), ("64 streams per GPU", 64), ("128 streams on this GPU, two passes of 64 (strong scaling, N = 1)", 128)):
+                try:
+                    ps = (sh + 63) // 64
+                    r_s = TimedRun(sargs, dims, args.dtype, rep, local, dev, stub, (sh + ps - 1) // ps, ps)
+                    r_s.set_share(sh)
+                    t_s = r_s.timed()
+                    f_s = r_s.roofline(t_s, t_s["dt_local"])
+                    sweep.append({"workload": label, "streams": sh, "passes_per_step": ps, "tok_per_s": round(t_s["new_tok"] / t_s["dt_local"], 1),
+                                  "ms_per_step": round(t_s["dt_local"] / sargs.steps * 1e3, 2), "decode_step_ms": round(f_s["avg_step_ms"], 4),
+                                  "roofline_frac": round(f_s["achieved"] / HBM_PEAK_GBS, 4), "steps": sargs.steps})
+                    r_s.close()
+                    torch.cuda.empty_cache()
+                except Exception as e:  # noqa: BLE001
+                    sweep.append({"workload": label, "error": repr(e)})
+            result["streams_sweep"] = sweep
+            ok = {x["streams"]: x["tok_per_s"] for x in sweep if "tok_per_s" in x}
+            if {32, 64, 128} <= set(ok):
+                result["strong_scaling_128_streams"] = {
+                    "n_gpus_1_measured": ok[128],
+                    "projected_from_per_gpu_rates": {"2": round(2 * ok[64], 1), "4": round(4 * ok[32], 1), "8": round(8 * result["value"], 1)},
+                    "note": "128 concurrent streams (BASELINE configs[3]) on N GPUs; N = 1 is measured here (two passes of 64), N = 2 / 4 / 8 are N x the "
+                            "measured single-GPU rate at 64 / 32 / 16 streams per GPU (replicas, no data-path collective: DESIGN.md section 5) - a "
+                            "projection, NOT a measurement; `python bench.py --gpus N --scaling strong --total-streams 128` measures it on a node"}
         if world == 1 and not stub and not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline(args.model, args.chunk_s, args.cpu_tokens, args.cpu_calls)
