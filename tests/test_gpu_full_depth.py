@@ -369,3 +369,46 @@ def test_full_depth(name, dtype):
     if dtype == "f32" and rep["min_golden_margin"] > 4 * F32["top_abs"]:
         # strict mode: every decision margin on these clips is above the bound, so the ids must be identical outright
         assert all(d is None for d in rep["first_divergence(pos, golden_margin)"]), rep
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_full_depth_64_streams_follow_the_16_clip_golden(dtype):
+    """The kernels for MORE than 16 streams (operand-ring projections: four groups of 16 streams per weight pass, k_decode.hip) at full
+    depth against the reference: the 16 clips of the headline-shaped golden (HF fp32, 32 + 32 layers, 160 free-running greedy tokens
+    with the timestamp grammar) decoded FOUR TIMES side by side in one 64-stream context.  Strict f32: every one of the 64 rows
+    reproduces its clip's reference ids to the end and the teacher-forced logits to 2e-4; float16: ids identical too (as the 16-stream
+    context does, test_full_depth), logits to 5e-3.  Rows of different groups that carry the same clip are bit-identical."""
+    name = "full_large-v3_c10_b16"
+    if not os.path.exists(os.path.join(GOLD, f"{name}.npz")):
+        pytest.skip(f"{name}.npz not generated (oracle/make_golden_full.py)")
+    z, dims, w, pcm, heads = load_case(name)
+    T, B0 = 50 * int(z["chunk_s"]), pcm.shape[0]
+    R = 64 // B0
+    B = R * B0
+    stride = int(z["logit_stride"]) if "logit_stride" in z.files else STRIDE
+    eng = make_engine(dims, w, T=T, max_batch=B, dtype=dtype, heads=heads, use_graph=True)
+    try:
+        mel = eng.logmel(torch.from_numpy(np.tile(pcm, (R, 1))).cuda(), out_dtype=torch.float32)
+        eng.encode(mel)
+        eng.cross_kv(B)
+        seq = np.tile(z["sequences"].astype(np.int64), (R, 1))
+        # teacher-forced along the reference's greedy path: a strided sample of every logits row against the golden sample
+        eng.decoder_reset(B)
+        worst = 0.0
+        for s in range(min(24, seq.shape[1] - 1)):
+            lg = eng.decode_step(seq[:, s].tolist()).cpu().numpy()
+            ref = np.tile(z["logits_sample"][:, s], (R, 1))
+            worst = max(worst, rel_l2(lg[:, ::stride], ref))
+            for r in range(1, R):    # the same clip in another group of 16 streams
+                assert np.array_equal(lg[:B0], lg[r * B0 : (r + 1) * B0]), (s, r)
+        assert worst < (2e-4 if dtype == "f32" else 5e-3), worst
+        # free-running greedy ids: all 64 rows on their clip's reference path
+        prompt = np.tile(np.array(PROMPT, dtype=np.int32), (B, 1))
+        got = eng.generate_greedy(prompt, max_new_tokens=int(z["max_new"]), timestamps=True, want_alignment=True)["sequences"]
+        L = min(got.shape[1], seq.shape[1])
+        same = [b for b in range(B) if got.shape[1] == seq.shape[1] and np.array_equal(got[b, :L], seq[b, :L])]
+        print(f"\nFULLDEPTH64 {name} {dtype}: 64 streams = 16 golden clips x 4, teacher-forced logits rel-L2 {worst:.3e}, "
+              f"streams_with_identical_ids={len(same)} of {B}")
+        assert len(same) == B, sorted(set(range(B)) - set(same))
+    finally:
+        eng.close()
