@@ -932,7 +932,7 @@ int decode_core(tw_ctx* c, int B, hipStream_t st, int rs = 0, const int* ids = n
     {  // LN + fused QKV; k,v rows go straight into the cache at position pos
       GemvArgs a{};
       a.x = xin; a.ldx = d; a.ln_gw = L.qkv_gw; a.ln_cb = L.qkv_cb; a.W = L.wqkv; a.wscale = L.s_qkv; a.a16 = c->a16; a.N = (fq_on ? 4 : 3) * d; a.K = d; a.B = B;
-      a.y = c->dq; a.ldy = d; a.kcache = sk; a.vcache = sv; a.cache_bstride = (long long)Pp * d; a.d_model = d; a.stt = c->stt;
+      a.y = c->dq; a.ldy = d; a.kcache = sk; a.vcache = sv; a.cache_bstride = (long long)Pp * d; a.cache_hstride = (long long)Pp * 64; a.d_model = d; a.stt = c->stt;
       a.u = fq_on ? c->du : nullptr;
       a.rows_streams = rs;
       HIPCHK(c, launch_gemv(dt, a, st));

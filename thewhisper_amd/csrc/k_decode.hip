@@ -322,7 +322,7 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
   const float* gw_p = gw_arg;
   const float* cb_p = a.ln_cb;
   const int K = k_arg, N = n_arg, B = b_arg, ldy = a.ldy, RG = rg_arg, d_model = a.d_model;
-  const long long cache_bstride = a.cache_bstride;
+  const long long cache_bstride = a.cache_bstride, cache_hstride = a.cache_hstride;
   T* y = reinterpret_cast<T*>(a.y);
   float* y_f32 = a.y_f32;
   T* kcache = reinterpret_cast<T*>(a.kcache);
@@ -521,7 +521,7 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
   }
   // (2) everything else (epilogue operands, outputs, cache geometry): ONE batch of scalar loads from the argument block, waited for
   // here, behind the operand requests that are already on their way
-  asm volatile("" ::"s"(bias), "s"(res), "s"(gw_p), "s"(cb_p), "s"(a.gelu), "s"(ldy), "s"(d_model), "s"(cache_bstride), "s"(y),
+  asm volatile("" ::"s"(bias), "s"(res), "s"(gw_p), "s"(cb_p), "s"(a.gelu), "s"(ldy), "s"(d_model), "s"(cache_bstride), "s"(cache_hstride), "s"(y),
                "s"(y_f32), "s"(kcache), "s"(vcache), "s"(stt), "s"(u_p), "s"(nsplit), "s"(stats_p), "s"(rows_streams));
 #ifdef TW_PROBE_TS
   cur_pos = stt->pos;
@@ -681,14 +681,16 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
           if (EPI == SK_F32) {
             y_f32[(long long)jg * N + n] = v;
           } else if (EPI == SK_KV) {
-            const int seg = n / d_model;  // 0: query -> y, 1: key -> K cache, 2: value -> V^T cache   (one predicated store)
+            // 0: query -> y, 1: key -> K cache, 2: value -> V^T cache, 3: cross query ahead   (one predicated store; compares and a
+            // host-side per-head stride instead of the 32- and 64-bit divisions by run-time values this epilogue used to carry: ~0.3 us)
+            const int seg = (n >= d_model) + (n >= 2 * d_model) + (n >= 3 * d_model);
             const int nn = n - seg * d_model, hh = nn >> 6, cc = nn & 63;
             if (seg == 3) {   // cross query ahead: x . W'^T + c0 WITHOUT this LayerNorm (its own is applied by the consumer)
               u_p[(long long)jg * d_model + nn] = vraw + e_c;
             } else {
               int srow, prow;   // rows mode (prefill): row jg is stream jg % rs at position cur_pos + jg / rs
               tw_row_of(jg, rows_streams, cur_pos, srow, prow);
-              const long long hb = (long long)srow * cache_bstride + (long long)hh * (cache_bstride / (d_model >> 6));  // (stream, head)
+              const long long hb = (long long)srow * cache_bstride + (long long)hh * cache_hstride;  // (stream, head)
               T* dst = seg == 0 ? y + (long long)jg * ldy + n
                                 : (seg == 1 ? kcache + hb + tw_kf_index<T>(prow, cc) : vcache + hb + tw_vtf_index<T>(prow, cc));
               *dst = tw_cast<T>(v);
@@ -1179,14 +1181,16 @@ __global__ __launch_bounds__(NW * 64) void dec_self_attn_kernel(const T* __restr
 
 template <typename T, bool SINGLE, bool FQ>
 __global__ __launch_bounds__(512) void dec_cross_attn_kernel(const T* __restrict__ ck, const T* __restrict__ cv, int H, int Tp,
-                                                              int Tlen, const T* __restrict__ q, T* __restrict__ out,
+                                                              int Tlen, int rows_streams, const T* __restrict__ q, T* __restrict__ out,
                                                               const int* __restrict__ align_slot, float* __restrict__ align,
-                                                              int Ha, int P, const DecState* __restrict__ stt, FusedQ fq, int rows_streams) {
+                                                              int Ha, int P, const DecState* __restrict__ stt, FusedQ fq) {
+  // (rows_streams sits among the LEADING arguments since round 5: the K / V^T request addresses depend on it - which stream's arena -
+  //  and an argument behind the FusedQ block is not delivered with the wave: the requests waited for a scalar load)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* sc = reinterpret_cast<float*>(smem);  // [Tp] scores -> unnormalised probabilities
   __shared__ float red[2 * 8 + 8 * 64];
   __shared__ __attribute__((aligned(16))) T qst[FQ ? 8 * 64 : 8];
-  asm volatile("" ::"s"(ck), "s"(cv), "s"(H), "s"(Tp), "s"(Tlen));
+  asm volatile("" ::"s"(ck), "s"(cv), "s"(H), "s"(Tp), "s"(Tlen), "s"(rows_streams));
   const int h = blockIdx.x, b = blockIdx.y;
   const int srow = rows_streams > 0 ? b % rows_streams : b;   // rows mode (prefill): the stream whose encoder K / V this row attends to
   const long long base = ((long long)srow * H + h) * Tp * 64;
@@ -1205,15 +1209,15 @@ template <int G, bool FQ>
 __global__ __launch_bounds__(512) void dec_cross_attn_kv8_kernel(const unsigned char* __restrict__ ck, const unsigned char* __restrict__ cv,
                                                                   const unsigned char* __restrict__ ksc,
                                                                   const unsigned char* __restrict__ vsc, int H, int Tp, int Tlen,
-                                                                  const bf16_t* __restrict__ q, bf16_t* __restrict__ out,
+                                                                  int rows_streams, const bf16_t* __restrict__ q, bf16_t* __restrict__ out,
                                                                   const int* __restrict__ align_slot, float* __restrict__ align,
-                                                                  int Ha, int P, const DecState* __restrict__ stt, FusedQ fq, int rows_streams) {
+                                                                  int Ha, int P, const DecState* __restrict__ stt, FusedQ fq) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* sc = reinterpret_cast<float*>(smem);  // [Tp] scores -> unnormalised probabilities
   float* scv = sc + Tp;                        // [Tp] probabilities x V scale
   __shared__ float red[2 * 8 + 8 * 64];
   __shared__ __attribute__((aligned(16))) bf16_t qst[FQ ? 8 * 64 : 8];
-  asm volatile("" ::"s"(ck), "s"(cv), "s"(ksc), "s"(vsc), "s"(H), "s"(Tp), "s"(Tlen));
+  asm volatile("" ::"s"(ck), "s"(cv), "s"(ksc), "s"(vsc), "s"(H), "s"(Tp), "s"(Tlen), "s"(rows_streams));
   const int h = blockIdx.x, b = blockIdx.y;
   const int srow = rows_streams > 0 ? b % rows_streams : b;   // rows mode (prefill), as in dec_cross_attn_kernel
   const long long hb = ((long long)srow * H + h) * Tp;
@@ -1711,8 +1715,8 @@ hipError_t launch_dec_cross_attn(int dtype, const void* q, const FusedQ& fq, con
     if (!ksc || !vsc || dtype != 1) return hipErrorInvalidValue;
     const size_t lds8 = (size_t)Tp * sizeof(float) * 2;
 #define CA8_GO(GV, FV) hipLaunchKernelGGL((dec_cross_attn_kv8_kernel<GV, FV>), dim3(H, B), dim3(512), lds8, st,                        \
-                                          (const unsigned char*)ck, (const unsigned char*)cv, ksc, vsc, H, Tp, T, (const bf16_t*)q,  \
-                                          (bf16_t*)out, align_slot_for_head, align, Ha, P, stt, fq, rows_streams)
+                                          (const unsigned char*)ck, (const unsigned char*)cv, ksc, vsc, H, Tp, T, rows_streams, (const bf16_t*)q,  \
+                                          (bf16_t*)out, align_slot_for_head, align, Ha, P, stt, fq)
 #define CA8_PICK(FV) do { if (Tp <= 512) CA8_GO(1, FV); else if (Tp <= 1024) CA8_GO(2, FV); else if (Tp <= 1536) CA8_GO(3, FV);      \
                           else return hipErrorInvalidValue; } while (0)
     if (f) CA8_PICK(true); else CA8_PICK(false);
@@ -1722,7 +1726,7 @@ hipError_t launch_dec_cross_attn(int dtype, const void* q, const FusedQ& fq, con
   }
   const size_t lds = (size_t)Tp * sizeof(float);
 #define CA_GO(TT, SV, FV) hipLaunchKernelGGL((dec_cross_attn_kernel<TT, SV, FV>), dim3(H, B), dim3(512), lds, st, (const TT*)ck,      \
-                                             (const TT*)cv, H, Tp, T, (const TT*)q, (TT*)out, align_slot_for_head, align, Ha, P, stt, fq, rows_streams)
+                                             (const TT*)cv, H, Tp, T, rows_streams, (const TT*)q, (TT*)out, align_slot_for_head, align, Ha, P, stt, fq)
 #define CA_PICK(TT) do { if (single) { if (f) CA_GO(TT, true, true); else CA_GO(TT, true, false); }                                  \
                          else { if (f) CA_GO(TT, false, true); else CA_GO(TT, false, false); } } while (0)
   if (dtype == 1) CA_PICK(bf16_t); else if (dtype == 2) CA_PICK(f16_t); else CA_PICK(float);

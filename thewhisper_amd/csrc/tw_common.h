@@ -256,8 +256,9 @@ struct GemvArgs {
   void* y; int ldy;              // output (T): fragment-major [16, N] with res or gelu, else row-major [B, ldy]; or
   float* y_f32;                  // float32 output [B, N] (logits) when non-null
   // optional KV-cache scatter for the fused self-attention QKV projection: rows [d,2d) -> kcache, [2d,3d) -> vcache
-  // (fragment-major per (stream, head): tw_kf_index / tw_vtf_index; cache_bstride = elements per stream = H * rows * 64)
-  void* kcache; void* vcache; long long cache_bstride; int d_model; const DecState* stt;
+  // (fragment-major per (stream, head): tw_kf_index / tw_vtf_index; cache_bstride = elements per stream = H * rows * 64,
+  //  cache_hstride = elements per (stream, head) = rows * 64 - handed over so that the epilogue has no 64-bit division to do)
+  void* kcache; void* vcache; long long cache_bstride; long long cache_hstride; int d_model; const DecState* stt;
   int rg;  // skinny path: 16-row tiles walked per workgroup (set by the launcher)
   int tr;  // weight rows per workgroup tile the weights were laid out for by launch_tile_weights (0 / 16, 8 or 4)
   // "cross query ahead" (api.hip: decode_core): float32 [B][d_model] pre-activation of the NEXT LayerNorm'd projection.
