@@ -24,9 +24,9 @@ Besides the engine-level headline the line carries (rank 0, N = 1 only):
   * `config3`: BASELINE config 3's call pattern - the 117 backend calls the REFERENCE'S OWN scheduler + stepper make for one 60 s stream
     (tests/golden/config3_trace.json, generated and re-derived from the reference: oracle/config3_trace.py) - replayed through the
     backend at large-v3 dimensions: p50 / p90 per call, calls per audio second, with and without `reuse_committed_prefix`;
-  * `value_f16`, `roofline_f16`, `parity_full_depth`: the float16 context (the reference's streaming default dtype; the 16-bit context whose
-    greedy ids equal the fp32 reference's on every clip) on the same schedule, and the id-identity figures of both dtypes from the
-    committed GPU-suite log;
+  * `dtype` = f16 since round 6 (the reference's streaming default dtype and the 16-bit context whose greedy ids equal the fp32
+    reference's on every full-depth clip); `value_bf16`, `roofline_bf16`: the bfloat16 context on the same schedule; `parity_full_depth`:
+    the id-identity figures of both from the committed GPU-suite log (refused when that log belongs to other kernel sources);
   * `pipeline`: everything measured through the drop-in API (hub legs, two cohorts, short passes, lock-step);
   * `cpu_baseline`: the reference's own `nvidia.ASRPipeline` on this box's host cores (bounded sample; `kind: "reference"` wherever the
     reference package is importable - /root/reference, or the oracle/_ref bundle on the GPU box);
@@ -205,10 +205,11 @@ def pipeline_leg(eng, dims, args, device_index, heads, latency_calls, hub_rounds
     from thewhisper_amd.serving import BatchingHub
 
     B = args.streams
-    model = synthetic.skeleton_model(dims, device=f"cuda:{device_index}", dtype=torch.bfloat16, alignment_heads=heads)
+    tdt = {"f16": torch.float16, "f32": torch.float32}.get(args.dtype, torch.bfloat16)   # (the engine holds the arithmetic; this is the HF shell's dtype)
+    model = synthetic.skeleton_model(dims, device=f"cuda:{device_index}", dtype=tdt, alignment_heads=heads)
     pipe = ASRPipeline(model, feature_extractor=WhisperFeatureExtractor(feature_size=dims["n_mels"], chunk_length=args.chunk_s),
                        tokenizer=synthetic.build_tokenizer(dims["vocab"]), chunk_length_s=args.chunk_s, device=f"cuda:{device_index}",
-                       torch_dtype=torch.bfloat16, batch_size=B, engine=eng)
+                       torch_dtype=tdt, batch_size=B, engine=eng)
     backend = AMDWhisperBackend(None, chunk_length_s=args.chunk_s, asr_pipeline=pipe)
     counted = {"tok": 0}
     inner = eng.generate_greedy
@@ -306,6 +307,33 @@ def pipeline_leg(eng, dims, args, device_index, heads, latency_calls, hub_rounds
             if config3 is not None:
                 config3["with_reuse_committed_prefix"] = {"p50_ms": reuse_out["reuse_scheduler_pattern_p50_ms"], "p90_ms": reuse_out["reuse_scheduler_pattern_p90_ms"],
                                                           "calls_with_forced_prefix": st["reused"], "token_identity_mean": reuse_out["reuse_token_identity_mean"]}
+        # ... and the EXACT form (round 6): `draft_previous_tick` - the previous tick's tokens as a draft the engine verifies
+        # (tw_greedy_opts::n_draft); ids must equal the plain backend's on every call
+        if latency_calls > 0 and rag:
+            db = AMDWhisperBackend(None, chunk_length_s=args.chunk_s, asr_pipeline=pipe, draft_previous_tick=True)
+            dl, draft_ids = run_pattern(db)
+            dls = sorted(dl)
+            ident = []
+            for a, b in zip(plain_ids, draft_ids):
+                n = max(len(a), len(b))
+                if n:
+                    m = min(len(a), len(b))
+                    ident.append(float((a[:m] == b[:m]).sum()) / n)
+            st = db.reuse_stats
+            draft_out = {
+                "p50_ms": round(dls[len(dls) // 2], 2), "p90_ms": round(dls[(len(dls) * 9) // 10], 2), "sum_ms": round(sum(dl), 1),
+                "calls_with_draft": st["reused"], "draft_tokens": st["draft_tokens"], "confirmed_tokens": st["confirmed_tokens"],
+                "acceptance": round(st["confirmed_tokens"] / max(1, st["draft_tokens"]), 3), "verify_launches": st["verify_launches"],
+                "token_identity_mean": round(float(np.mean(ident)), 4) if ident else None,
+                "calls_identical": int(sum(1 for a, b in zip(plain_ids, draft_ids) if len(a) == len(b) and (a == b).all())), "calls": len(dl),
+                "note": "AMDWhisperBackend(draft_previous_tick=True): the previous tick's tokens are offered as a draft and VERIFIED (logits + "
+                        "processors of every position in batched launches, tw_greedy_opts::n_draft): ids identical to the plain backend by "
+                        "construction; acceptance on random weights is a lower bound (the transcript of a random-weight model changes with "
+                        "every 0.5 s of new audio)",
+            }
+            reuse_out["draft_previous_tick"] = draft_out
+            if config3 is not None:
+                config3["with_draft_previous_tick"] = draft_out
         eng.generate_greedy = counting
         # (a) lock-step rounds (continuity with rounds 1-2: all sessions ask at once and wait for the slowest), classic whole-call
         #     batches: what the hub did until round 3
@@ -669,10 +697,21 @@ class TimedRun:
 def full_depth_parity(dtype):
     """`streams_with_identical_ids` and friends of the headline-shaped parity case (16 clips x 163 positions at full depth, fp32
     reference goldens) from the newest committed log of the GPU suite: what the id-identity claim of a dtype rests on."""
+    from thewhisper_amd.build import source_digest
+
     logs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gpu_tests_full_depth.log")))
     for path in reversed(logs):
         for line in open(path, errors="replace"):
             if line.startswith(f"FULLDEPTH full_large-v3_c10_b16 {dtype}:"):
+                k = line.find("kernel_source_sha256=")
+                sha = line[k + 21 :].split(",")[0].strip() if k >= 0 else None
+                if sha != source_digest():
+                    # figures of OTHER kernels are not this build's parity: never reported (tests/test_bench_cpu.py fails the CPU suite
+                    # while the committed log is stale, so this branch is not reached by a tree whose tests are green)
+                    msg = (f"profiles/{os.path.basename(path)} was taken with kernel sources {str(sha)[:12]}..., this build is "
+                           f"{source_digest()[:12]}...: re-run tests/test_gpu_full_depth.py on the MI355X and commit its log")
+                    print(f"[bench] STALE parity_full_depth ({dtype}): {msg}", file=sys.stderr, flush=True)
+                    return {"stale": True, "error": msg}
                 out = {"source": f"profiles/{os.path.basename(path)} (tests/test_gpu_full_depth.py, case full_large-v3_c10_b16: 16 clips, 160 free-running "
                                  f"greedy tokens each, HF fp32 reference)", "clips": 16}
                 for key, name in (("streams_with_identical_ids", "ids_identical_clips"), ("greedy_path_logits_rel_l2", "logits_rel_l2"),
@@ -702,8 +741,11 @@ def main(argv=None):
                          "(SURVEY.md section 8d row 4, 'fixed-128'): every GPU takes total / N of them, in passes of at most 64")
     ap.add_argument("--total-streams", type=int, default=128, help="with --scaling strong: streams of the whole job (BASELINE configs[3]: 128)")
     ap.add_argument("--new-tokens", type=int, default=128)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32", "fp8", "fp8a8", "fp8a16"],
-                    help="fp8 = bf16 activations/encoder + MXFP8 decoder projection weights (BASELINE config 5)")
+    ap.add_argument("--dtype", default="f16", choices=["bf16", "f16", "f32", "fp8", "fp8a8", "fp8a16"],
+                    help="context element type.  f16 (default since round 6): the reference's streaming default "
+                         "(R:thestage_speechkit/streaming/streaming_pipeline.py:369-370, torch.float16) and the 16-bit type whose greedy ids equal "
+                         "the fp32 reference's on every full-depth clip (parity_full_depth); bf16 is reported beside it (value_bf16).  "
+                         "fp8 = bf16 activations/encoder + MXFP8 decoder projection weights (BASELINE config 5)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tokens", type=int, default=32, help="forced tokens per CPU-baseline call (BASELINE.md section 3: >= 3 calls x 32)")
@@ -922,33 +964,40 @@ def main(argv=None):
                                   "runs": rr["runs"]}
             except Exception as e:  # noqa: BLE001
                 result["rtfx"] = {"error": repr(e)}
-        # ---- float16 as a first-class block: the reference's streaming default dtype (R:...streaming_pipeline.py:369-370) and the 16-bit
-        # context whose greedy ids are identical to the fp32 reference on every clip of the full-depth suite - the SAME timed schedule as
-        # the headline (overlap pipeline, K steps), its own roofline, the parity figures from the committed GPU-suite log next to both
+        # ---- the OTHER 16-bit context as a first-class block.  Headline = float16 (round 6): the reference's streaming default dtype
+        # (R:...streaming_pipeline.py:369-370) and the 16-bit context whose greedy ids are identical to the fp32 reference on every clip of
+        # the full-depth suite; bfloat16 (the nvidia pipeline's alternative, R:thestage_speechkit/nvidia/asr_pipeline.py:47-60) runs the SAME
+        # timed schedule (overlap pipeline, K steps) with its own roofline; the parity figures of both from the committed GPU-suite log
         result["parity_full_depth"] = {args.dtype: full_depth_parity(args.dtype)} if args.dtype in ("bf16", "f16", "f32") else {}
-        if world == 1 and not stub and not args.no_secondary and args.dtype == "bf16":
+        if args.dtype == "f16":
+            result["dtype_note"] = ("float16 is the headline dtype since round 6: it is the reference's streaming default (torch.float16, "
+                                    "streaming_pipeline.py:369-370), costs what bf16 costs (value_bf16 beside it) and carries the north star's "
+                                    "'greedy token IDs identical' claim at full depth (parity_full_depth.f16.ids_identical_clips); HF's own bf16 "
+                                    "arithmetic flips sub-margin decisions too (tests/test_golden_ctrl.py)")
+        other = {"f16": "bf16", "bf16": "f16"}.get(args.dtype)
+        if world == 1 and not stub and not args.no_secondary and other is not None:
             run.close()
             run = None
             torch.cuda.empty_cache()
             try:
-                run16 = TimedRun(args, dims, "f16", rep, local, dev, stub, B, passes)
+                run16 = TimedRun(args, dims, other, rep, local, dev, stub, B, passes)
                 run16.set_share(share)
                 r16 = run16.timed()
                 rf16 = run16.roofline(r16, r16["dt_local"])
-                result["value_f16"] = round(r16["new_tok"] / r16["dt_local"], 2)
-                result["ms_per_step_f16"] = round(r16["dt_local"] / args.steps * 1e3, 3)
-                result["roofline_f16"] = {"bound": "hbm", "achieved": round(rf16["achieved"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                          "frac": round(rf16["achieved"] / HBM_PEAK_GBS, 4), "avg_step_ms": round(rf16["avg_step_ms"], 4),
-                                          "algorithmic_bytes_per_step": int(rf16["alg_bytes"] / max(1, rf16["steps_per_call"])), "traffic": None}
-                result["stage_ms_per_step_f16"] = {k: round(v / args.steps, 3) for k, v in r16["stage"].items()}
-                result["parity_full_depth"]["f16"] = full_depth_parity("f16")
-                result["f16_note"] = ("the headline workload in a float16 context (TW_F16: the same kernels instantiated for _Float16, "
-                                      "v_mfma_f32_16x16x32_f16), same schedule, same step count; parity_full_depth.*.ids_identical_clips = clips (of 16) whose "
-                                      "160 free-running greedy ids equal the HF fp32 reference's to the end")
+                result[f"value_{other}"] = round(r16["new_tok"] / r16["dt_local"], 2)
+                result[f"ms_per_step_{other}"] = round(r16["dt_local"] / args.steps * 1e3, 3)
+                result[f"roofline_{other}"] = {"bound": "hbm", "achieved": round(rf16["achieved"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                               "frac": round(rf16["achieved"] / HBM_PEAK_GBS, 4), "avg_step_ms": round(rf16["avg_step_ms"], 4),
+                                               "algorithmic_bytes_per_step": int(rf16["alg_bytes"] / max(1, rf16["steps_per_call"])), "traffic": None}
+                result[f"stage_ms_per_step_{other}"] = {k: round(v / args.steps, 3) for k, v in r16["stage"].items()}
+                result["parity_full_depth"][other] = full_depth_parity(other)
+                result[f"{other}_note"] = (f"the headline workload in a {other} context (the same kernels instantiated for the other 16-bit type: "
+                                           "v_mfma_f32_16x16x32_bf16 / _f16), same schedule, same step count; parity_full_depth.*.ids_identical_clips = "
+                                           "clips (of 16) whose 160 free-running greedy ids equal the HF fp32 reference's to the end")
                 run16.close()
             except Exception as e:  # noqa: BLE001
-                result["value_f16"] = None
-                result["f16_note"] = f"failed: {e!r}"
+                result[f"value_{other}"] = None
+                result[f"{other}_note"] = f"failed: {e!r}"
         # ---- streams per GPU: what ONE MI355X delivers with 32 and 64 streams per weight pass, and with BASELINE configs[3]'s whole 128
         # streams as two passes of 64 = the N = 1 point of the strong-scaling curve.  Replicas share nothing, so
         # the other points of that curve are these per-GPU rates times N (128 / N streams per GPU): N = 2 -> 2 x the 64-stream rate,

@@ -106,6 +106,18 @@ typedef struct tw_greedy_opts {
                                     SURVEY.md section 8f-3 - a streaming backend re-decodes every 0.5 s a buffer most of whose text
                                     it emitted a moment ago (R:thestage_speechkit/streaming/streaming_pipeline.py:770-796) and may
                                     force that text and decode only the tail (thewhisper_amd/streaming.py, opt-in).  0 = off. */
+  int32_t n_draft;               /* the last n_draft tokens of every prompt row are a DRAFT of the output (exact form):
+                                    GUESSES, e.g. what the previous 0.5 s tick of the same stream produced
+                                    (R:thestage_speechkit/streaming/streaming_pipeline.py:388-435 decodes the rolling buffer from scratch
+                                    every tick, :770-796).  The call returns exactly what it returns with the same prompt WITHOUT
+                                    them - same ids, same alignment rows - however good the guesses are: prompt and draft are run
+                                    through the decoder in launches of up to 64 rows (streams x consecutive positions) WITH the logits
+                                    and the logits processors of every row; the draft is accepted up to the first position where
+                                    some stream's arg-max differs from its guess, that arg-max becomes the token there, the rest of
+                                    the draft is offered again behind it, and the one-token-per-step loop takes over where nothing
+                                    more is confirmed.  Sound because a row's result does not depend on the other rows of its launch
+                                    (one reduction order for every launch width, k_decode.hip).  Begin index = n_prompt - n_draft.
+                                    Not together with n_forced.  0 = off.  tw_last_draft reports what was accepted. */
 } tw_greedy_opts;
 
 const char* tw_version(void);
@@ -186,6 +198,10 @@ int tw_decode_step(tw_ctx* ctx, int32_t B, const int32_t* ids_host, float* logit
  * Requires tw_encode + tw_cross_kv for the same B. */
 int tw_generate_greedy(tw_ctx* ctx, int32_t B, const int32_t* prompt_host, int32_t n_prompt,
                        const tw_greedy_opts* opts, int32_t* out_ids_host, int32_t* out_len_host, void* stream);
+
+/* Of the most recent tw_generate_greedy with n_draft > 0 (all streams together): draft tokens offered, draft tokens confirmed, rows-mode
+ * launches and verify rounds it took.  Any pointer may be NULL.  No reference counterpart (see tw_greedy_opts::n_draft). */
+int tw_last_draft(tw_ctx* ctx, int32_t* offered, int32_t* accepted, int32_t* launches, int32_t* rounds);
 
 /* A11.  Replaces: _extract_token_timestamps + _median_filter + _dynamic_time_warping
  * (HF:models/whisper/generation_whisper.py:241-381, :43-61, :64-115) on the alignment rows recorded by the

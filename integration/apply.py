@@ -43,6 +43,10 @@ def apply(reference: str, out: str | None = None) -> str:
             if os.path.isdir(src):
                 shutil.copytree(src, os.path.join(out, sub), dirs_exist_ok=True,
                                 ignore=shutil.ignore_patterns("__pycache__", "*.pyc"))
+        for dp, dns, fns in os.walk(out):            # a copy of a read-only checkout keeps its modes: make the copy writable
+            for n in dns + fns:
+                q = os.path.join(dp, n)
+                os.chmod(q, os.stat(q).st_mode | 0o200)
         root = out
     pkg = os.path.join(root, "thestage_speechkit")
     if not os.path.isdir(pkg):
@@ -55,6 +59,7 @@ def apply(reference: str, out: str | None = None) -> str:
         if text.count(ANCHOR) != 1:
             raise SystemExit("the platform switch of LocalWhisperBackend.__init__ was not found (reference layout changed)")
         text = text.replace(ANCHOR, BRANCH + ANCHOR)
+        os.chmod(sp, os.stat(sp).st_mode | 0o200)     # (a copy of a read-only checkout keeps its modes)
         open(sp, "w").write(text)
     return root
 

@@ -87,7 +87,7 @@ class OracleEngine:
 
     def generate_greedy(self, prompt, max_new_tokens=128, min_new_tokens=0, max_length=448, eos_id=50257, pad_id=50257,
                         timestamps=False, no_timestamps_id=50364, max_initial_timestamp_index=50, begin_suppress=(220, 50257),
-                        suppress=(), want_alignment=False, n_forced=0):
+                        suppress=(), want_alignment=False, n_forced=0, n_draft=0):
         self.calls["generate"] += 1
         opt = wo.GreedyOptions(eos=eos_id, pad=pad_id, max_new_tokens=max_new_tokens, min_new_tokens=min_new_tokens,
                                max_length=max_length, begin_suppress=tuple(begin_suppress), suppress=tuple(suppress),
@@ -95,10 +95,21 @@ class OracleEngine:
                                max_initial_timestamp_index=max_initial_timestamp_index,
                                alignment_heads=self.alignment_heads if want_alignment else None)
         B = prompt.shape[0]
-        res = wo.greedy_generate(self.model, self._enc[:B], np.asarray(prompt), opt,
+        prompt = np.asarray(prompt)
+        draft = None
+        if n_draft:     # tw_greedy_opts::n_draft, by its definition: the result is the call's result WITHOUT the guesses
+            assert not n_forced
+            draft, prompt = prompt[:, prompt.shape[1] - int(n_draft):], prompt[:, : prompt.shape[1] - int(n_draft)]
+        res = wo.greedy_generate(self.model, self._enc[:B], prompt, opt,
                                  begin_index=(prompt.shape[1] - int(n_forced)) if n_forced else None)
         self._cross = res["cross"]
-        return {"sequences": res["sequences"], "length": int(res["sequences"].shape[1])}
+        out = {"sequences": res["sequences"], "length": int(res["sequences"].shape[1])}
+        if draft is not None:   # confirmed = the common prefix of guess and result, the shortest over the streams (lock-step), per stream
+            gen = res["sequences"][:, prompt.shape[1]:]
+            n = min(gen.shape[1], draft.shape[1])
+            first = [int(np.argmax(np.append(gen[b, :n] != draft[b, :n], True))) for b in range(B)]
+            out["draft"] = {"offered": int(n_draft) * B, "accepted": min(first) * B, "launches": 0, "rounds": 0}
+        return out
 
     def token_timestamps(self, B, n_prompt, seq_len, num_frames=None, time_precision=0.02):
         self.calls["dtw"] += 1

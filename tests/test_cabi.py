@@ -36,8 +36,8 @@ def test_struct_layouts_match_header():
     from thewhisper_amd import _cabi
 
     assert ctypes.sizeof(_cabi.tw_config) == 4 * (12 + 64 + 2)
-    # tw_greedy_opts: 9 int32, pad to 8, ptr, int32 (+pad), ptr, int32 (+pad)
-    assert ctypes.sizeof(_cabi.tw_greedy_opts) == 40 + 8 + 8 + 8 + 8
+    # tw_greedy_opts: 9 int32, pad to 8, ptr, int32 (+pad), ptr, 3 int32 (+pad)
+    assert ctypes.sizeof(_cabi.tw_greedy_opts) == 40 + 8 + 8 + 8 + 16
 
 
 def test_no_cpu_fallback(built_library):

@@ -1,0 +1,214 @@
+"""Round 6 (`-m gpu`, through the C ABI):
+
+* a stream's results do not depend on the other rows of its launch - 1, 16, 17 and 64 rows, an ordinary step or the rows mode of
+  the batched prefill - BIT FOR BIT, in every context dtype, at the REAL width (d = 1280, ffn = 5120: the long-K projection takes
+  16 wavefronts per tile with one group of streams and 8 with several; k_decode.hip gives both the same sixteen K slices and the
+  same order of additions);
+* tw_greedy_opts::n_draft (draft-and-verify): whatever is offered as a draft - the true continuation, a corrupted
+  one, rubbish - the call returns what it returns without it: ids against the oracle's `greedy_generate` (strict f32) and ids,
+  alignment rows and token timestamps against the engine's own plain call (every dtype), with the expected number of confirmed tokens;
+* `AMDWhisperBackend(draft_previous_tick=True)` on the reference scheduler's call sequence: every call's words identical to the
+  plain backend's."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import whisper_oracle as wo
+from tests.util import PROMPT, clips, dims_variant, make_engine
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+
+
+REAL = dict(enc_layers=1, dec_layers=2)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16", "f32", "fp8a16"])
+def test_rows_of_a_launch_do_not_matter(dtype):
+    """The same clip (slot 0) teacher-forced through 7 positions alone, among 16, 17 and 64 rows, and again from another slot of
+    the 64-row launch: identical logits, bit for bit.  Then the rows mode: a forced-prefix call (positions in launches of up to 64
+    rows) must leave exactly the alignment rows and produce exactly the ids of the step-by-step call."""
+    dims = dims_variant("large-v3", **REAL)
+    w = wo.make_weights(dims, 2)
+    heads = [(1, 0), (1, 3)]
+    T, Bmax = 100, 64
+    eng = make_engine(dims, w, T=T, max_batch=Bmax, dtype=dtype, heads=heads, use_graph=False)
+    try:
+        pcm = clips(T * 320, Bmax)
+        pcm[40] = pcm[0]                                      # the same audio in another group of 16 rows
+        mel = eng.logmel(torch.from_numpy(pcm).cuda())
+        ids = np.concatenate([np.tile(np.array(PROMPT), (Bmax, 1)), np.random.default_rng(3).integers(0, 50000, size=(Bmax, 4))], axis=1)
+        ids[40] = ids[0]
+
+        def run(B):
+            eng.encode(mel[:B]); eng.cross_kv(B); eng.decoder_reset(B)
+            return np.stack([eng.decode_step(ids[:B, s].tolist()).cpu().numpy() for s in range(ids.shape[1])], axis=1)
+
+        one = run(1)
+        for B in (16, 17, 64, 33):
+            got = run(B)
+            assert np.array_equal(got[0], one[0]), f"{dtype}: row 0 of a {B}-row launch differs from the one-row launch"
+            if B == 64:
+                assert np.array_equal(got[40], one[0]), f"{dtype}: slot 40 differs from slot 0 on the same audio"
+        # rows mode (prefill launches of 16-64 rows) against the one-position steps: free-running ids, alignment rows, timestamps
+        for B in (1, 3):
+            eng.encode(mel[:B]); eng.cross_kv(B)
+            prompt = np.tile(np.array(PROMPT, dtype=np.int32), (B, 1))
+            kw = dict(max_new_tokens=40, min_new_tokens=40, timestamps=True, want_alignment=True)
+            full = eng.generate_greedy(prompt, **kw)
+            L = full["length"]
+            al_full = eng.get_alignment(B, L - 1)
+            forced = full["sequences"][:, : 3 + 30].astype(np.int32)
+            out = eng.generate_greedy(forced, n_forced=30, **kw)
+            assert np.array_equal(out["sequences"], full["sequences"]), dtype
+            assert np.array_equal(eng.get_alignment(B, L - 1), al_full), dtype
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("dtype,T", [("bf16", 500), ("f16", 1000), ("bf16", 1500), ("f32", 500)])
+def test_streams_of_a_pass_do_not_matter_encoder_included(dtype, T):
+    """The encoder side of the same statement: a clip's encoder states - and with them its logits - are bit for bit the same whether it
+    is encoded alone (M = T rows: 64 x 64 tiles, plain epilogue), with two others, or among 16 / 40 clips (M >= 8000 rows: the
+    large-M kernel with its LDS-staged epilogue, 128-query attention workgroups).  Until round 6 the two epilogues summed the
+    LayerNorm statistics they leave for the next GEMM in different orders (18 % of the 16-bit encoder states differed between a
+    one-clip and a 16-clip pass); tw_common.h: tw_stat4."""
+    dims = dims_variant("large-v3", enc_layers=2, dec_layers=1)
+    w = wo.make_weights(dims, 2)
+    eng = make_engine(dims, w, T=T, max_batch=40, dtype=dtype, heads=[(0, 0)], use_graph=False)
+    try:
+        mel = eng.logmel(torch.from_numpy(clips(T * 320, 40)).cuda())
+        ids = np.array(PROMPT + [1234, 777])
+        ref = None
+        for B in (1, 3, 16, 40):
+            enc = eng.encode(mel[:B], return_hidden=True)[0].float().cpu().numpy()
+            eng.cross_kv(B); eng.decoder_reset(B)
+            lg = np.stack([eng.decode_step([int(t)] * B).cpu().numpy()[0] for t in ids])
+            if ref is None:
+                ref = (enc, lg)
+                continue
+            assert np.array_equal(enc, ref[0]), f"{dtype} T={T}: encoder states of clip 0 among {B} clips differ from the one-clip pass"
+            assert np.array_equal(lg, ref[1]), f"{dtype} T={T}: logits of clip 0 among {B} clips differ from the one-clip pass"
+    finally:
+        eng.close()
+
+
+def _corrupt(seq, n0, where, rng, V=50000):
+    d = seq[:, n0:].copy()
+    for b in range(d.shape[0]):
+        for j in where:
+            if j < d.shape[1]:
+                d[b, j] = (int(d[b, j]) + 1 + int(rng.integers(0, V - 2))) % V
+    return d
+
+
+DRAFT_CASES = [
+    # preset, layers, T, B, max_new, forced length?, dtype, graph
+    ("micro", None, 100, 1, 60, True, "f32", True), ("micro", None, 100, 1, 60, False, "f32", False), ("micro", None, 500, 3, 40, True, "f32", True),
+    ("micro", None, 100, 16, 30, True, "f32", True), ("micro", None, 100, 1, 120, True, "bf16", True), ("micro", None, 750, 2, 40, True, "fp8a16", True),
+    ("micro", None, 100, 5, 90, True, "f16", False), ("micro", None, 100, 2, 40, True, "fp8a8", True),
+    ("large-v3", REAL, 100, 1, 100, True, "bf16", True), ("large-v3", REAL, 100, 1, 100, False, "f16", True), ("large-v3", REAL, 100, 2, 48, True, "f32", True),
+    ("large-v3", REAL, 100, 4, 48, True, "fp8a16", True), ("large-v3", REAL, 100, 20, 24, True, "bf16", True),
+]
+
+
+@pytest.mark.parametrize("preset,layers,T,B,max_new,fixed_len,dtype,graph", DRAFT_CASES)
+def test_draft_and_verify_returns_the_plain_result(preset, layers, T, B, max_new, fixed_len, dtype, graph):
+    dims = dims_variant(preset, **layers) if layers else wo.PRESETS[preset]
+    w = wo.make_weights(dims, 0 if layers is None else 2)
+    heads = [(dims.dec_layers - 1, 0), (dims.dec_layers - 1, 1)]
+    eng = make_engine(dims, w, T=T, max_batch=B, dtype=dtype, heads=heads, use_graph=graph)
+    try:
+        pcm = clips(T * 320, B)
+        mel = eng.logmel(torch.from_numpy(pcm).cuda(), out_dtype=torch.float32)
+        eng.encode(mel); eng.cross_kv(B)
+        prompt = np.tile(np.array(PROMPT, dtype=np.int32), (B, 1))
+        kw = dict(max_new_tokens=max_new, min_new_tokens=max_new if fixed_len else 0, timestamps=True, want_alignment=True)
+        full = eng.generate_greedy(prompt, **kw)
+        L = full["length"]
+        seq = full["sequences"]
+        al_full = eng.get_alignment(B, L - 1)
+        nf = [2 * T] * B
+        ts_full = eng.token_timestamps(B, 3, L, nf)
+        if dtype == "f32" and preset == "micro":
+            om = wo.OracleWhisper(dims, w, T=T)
+            opt = wo.GreedyOptions(max_new_tokens=max_new, min_new_tokens=max_new if fixed_len else 0, timestamps=True, alignment_heads=heads)
+            ref = wo.greedy_generate(om, om.encode(wo.log_mel(pcm, dims.n_mels)), prompt, opt)
+            assert np.array_equal(seq, ref["sequences"])
+        # what may be offered: generated tokens before any <eos> / padding of any row
+        gen = seq[:, 3:]
+        n_ok = int(min([np.nonzero(r == 50257)[0][0] if (r == 50257).any() else len(r) for r in gen]))
+        n_ok = min(n_ok, max_new - 2)
+        assert n_ok >= 4, "the case needs a few tokens to offer"
+        rng = np.random.default_rng(5)
+        variants = {
+            "true continuation": (gen[:, :n_ok].copy(), n_ok),
+            "half of it": (gen[:, : n_ok // 2].copy(), n_ok // 2),
+            "one token": (gen[:, :1].copy(), 1),
+            "wrong from the start": (_corrupt(seq[:, : 3 + n_ok], 3, range(n_ok), rng), None),
+            "one wrong token": (_corrupt(seq[:, : 3 + n_ok], 3, [n_ok // 3], rng), None),
+            "three wrong tokens": (_corrupt(seq[:, : 3 + n_ok], 3, [2, n_ok // 2, n_ok - 1], rng), None),
+        }
+        if B > 1:       # only ONE stream's draft is wrong: the round ends there for everybody, the others' drafts are offered again
+            d = gen[:, :n_ok].copy()
+            d[B - 1, n_ok // 2] = (int(d[B - 1, n_ok // 2]) + 7) % 50000
+            variants["one stream wrong"] = (d, None)
+        for name, (draft, want_acc) in variants.items():
+            draft = np.where(draft == 50257, 0, draft).astype(np.int32)
+            out = eng.generate_greedy(np.concatenate([prompt, draft], axis=1), n_draft=draft.shape[1], **kw)
+            what = f"{preset} {dtype} B={B}: draft = {name}"
+            assert out["length"] == L and np.array_equal(out["sequences"], seq), what
+            assert np.array_equal(eng.get_alignment(B, L - 1), al_full), what
+            assert np.array_equal(eng.token_timestamps(B, 3, L, nf), ts_full), what
+            dr = out["draft"]
+            assert dr["offered"] == draft.shape[1] * B and dr["launches"] >= 1 and dr["rounds"] >= 1
+            n_same = int(np.min([np.argmax(np.append(draft[b] != gen[b, : draft.shape[1]], True)) for b in range(B)]))
+            assert dr["accepted"] >= n_same * B, (what, dr, n_same)          # round 1 confirms the common prefix, later rounds may add
+            if want_acc is not None:
+                assert dr["accepted"] == want_acc * B and dr["rounds"] == 1, (what, dr)
+            if name == "one wrong token" and B <= 4:       # the rest of the draft is confirmed by the rounds that follow
+                assert dr["accepted"] == (n_ok - 1) * B and dr["rounds"] >= 2, (what, dr)
+        # misuse
+        with pytest.raises(RuntimeError, match="n_draft"):
+            eng.generate_greedy(np.concatenate([prompt, gen[:, :4].astype(np.int32)], axis=1), n_draft=4, n_forced=2, **kw)
+        with pytest.raises(RuntimeError, match="n_draft"):
+            eng.generate_greedy(prompt, n_draft=3, **kw)
+        bad = np.concatenate([prompt, gen[:, :4].astype(np.int32)], axis=1); bad[0, -1] = 50257
+        with pytest.raises(RuntimeError, match="draft token"):
+            eng.generate_greedy(bad, n_draft=4, **kw)
+        # and the context is as usable as before
+        again = eng.generate_greedy(prompt, **kw)
+        assert np.array_equal(again["sequences"], seq)
+    finally:
+        eng.close()
+
+
+def test_backend_with_drafts_reproduces_the_plain_backend_on_the_scheduler_sequence():
+    """`AMDWhisperBackend(draft_previous_tick=True)` on the golden stream's call sequence (ragged rolling buffers as the reference
+    scheduler sends them): every call returns the plain backend's words - text, start, end - exactly."""
+    import json
+    import os
+
+    from tests.test_pipeline_glue import build_amd_pipeline, normalise
+    from thewhisper_amd import AMDWhisperBackend
+
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "pipeline_golden.json")))["streaming_micro_c10"]
+    audio = wo.synth_audio(16000 * gold["seconds"], gold["seed"], gold["kind"])
+    plain = AMDWhisperBackend(None, chunk_length_s=10, asr_pipeline=build_amd_pipeline("micro", 10, 1, device="cuda", engine_factory=None))
+    draft = AMDWhisperBackend(None, chunk_length_s=10, asr_pipeline=build_amd_pipeline("micro", 10, 1, device="cuda", engine_factory=None),
+                              draft_previous_tick=True)
+    for c in gold["calls"]:
+        buf = audio[c["offset"] : c["offset"] + c["n"]]
+        a = plain.transcribe(buf.copy(), c["t0"], 16000)
+        b = draft.transcribe(buf.copy(), c["t0"], 16000)
+        assert normalise(a) == normalise(b), c
+        assert [(w["start"], w["end"]) for w in a] == [(w["start"], w["end"]) for w in b], c
+    st = draft.reuse_stats
+    print(f"\nDRAFT (MI355X, micro model, golden stream): {st['reused']} of {st['calls']} calls offered a draft, {st['draft_tokens']} tokens offered, "
+          f"{st['confirmed_tokens']} confirmed, {st['verify_launches']} verify launches")
+    assert st["reused"] >= 1 and st["draft_tokens"] > 0

@@ -122,3 +122,48 @@ def test_reuse_on_the_mi355x():
     print(f"\nREUSE (MI355X, micro model): {st['reused']} of {st['calls']} calls reused a prefix, {st['forced_tokens']} tokens forced / "
           f"{st['decoded_tokens']} decoded; words identical to the plain backend: mean {np.mean(fracs):.3f}, min {np.min(fracs):.3f}")
     assert st["reused"] >= 1 and np.mean(fracs) > 0.5
+
+
+# ---- round 6: the exact form (tw_greedy_opts::n_draft) ---------------------------------------------------------------------------
+def draft_backends(device="cpu", engine_factory="oracle"):
+    from tests.oracle_engine import oracle_engine_factory
+    from thewhisper_amd import AMDWhisperBackend
+
+    ef = oracle_engine_factory if engine_factory == "oracle" else None
+    plain = AMDWhisperBackend(None, chunk_length_s=10, asr_pipeline=build_amd_pipeline("micro", 10, 1, device=device, engine_factory=ef))
+    draft = AMDWhisperBackend(None, chunk_length_s=10, asr_pipeline=build_amd_pipeline("micro", 10, 1, device=device, engine_factory=ef),
+                              draft_previous_tick=True)
+    return plain, draft
+
+
+def test_draft_previous_tick_host_logic_cpu():
+    """Host side of `draft_previous_tick` on the stand-in engine (whose `n_draft` is the definition: the call's result without the
+    guesses): every call of the reference scheduler's sequence returns the plain backend's words; a draft is offered exactly on the
+    calls that extend their predecessor, it is everything the predecessor produced, and the two options exclude each other."""
+    from thewhisper_amd import AMDWhisperBackend
+
+    plain, draft = draft_backends()
+    with open(GOLD) as f:
+        g = json.load(f)["streaming_micro_c10"]
+    audio = wo.synth_audio(16000 * g["seconds"], g["seed"], g["kind"])
+    prev, n_ext = None, 0
+    for c in g["calls"]:
+        buf = audio[c["offset"] : c["offset"] + c["n"]]
+        a = plain.transcribe(buf.copy(), c["t0"], 16000)
+        r0, d0 = draft.reuse_stats["reused"], draft.reuse_stats["draft_tokens"]
+        last_ids = None if draft._last is None else draft._last["ids"]
+        b = draft.transcribe(buf.copy(), c["t0"], 16000)
+        assert a == b, c
+        engaged = draft.reuse_stats["reused"] > r0
+        extends = prev is not None and abs(prev["t0"] - c["t0"]) < 1e-6 and c["n"] >= prev["n"] and c["offset"] == prev["offset"]
+        assert not engaged or extends, (c, prev)
+        if engaged:
+            assert draft.reuse_stats["draft_tokens"] - d0 == min(len(last_ids), 126)
+        n_ext += int(extends)
+        prev = c
+    st = draft.reuse_stats
+    print(f"\nDRAFT (cpu stand-in): {st['reused']} of {st['calls']} calls offered a draft ({n_ext} extend their predecessor), "
+          f"{st['draft_tokens']} tokens offered, {st['confirmed_tokens']} confirmed")
+    assert st["reused"] >= 1 and 0 < st["confirmed_tokens"] <= st["draft_tokens"] and st["forced_tokens"] == 0
+    with pytest.raises(ValueError, match="alternatives"):
+        AMDWhisperBackend(None, chunk_length_s=10, asr_pipeline=plain.asr_pipeline, reuse_committed_prefix=True, draft_previous_tick=True)

@@ -34,7 +34,7 @@ class tw_greedy_opts(C.Structure):
         ("max_length", C.c_int32), ("timestamps", C.c_int32), ("no_timestamps_id", C.c_int32),
         ("max_initial_timestamp_index", C.c_int32), ("n_begin_suppress", C.c_int32),
         ("begin_suppress", C.POINTER(C.c_int32)), ("n_suppress", C.c_int32), ("suppress", C.POINTER(C.c_int32)),
-        ("want_alignment", C.c_int32), ("n_forced", C.c_int32),
+        ("want_alignment", C.c_int32), ("n_forced", C.c_int32), ("n_draft", C.c_int32),
     ]
 
 
@@ -58,6 +58,7 @@ SYMBOLS = [
     ("tw_decode_step", C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), _P, _P]),
     ("tw_generate_greedy", C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(tw_greedy_opts),
                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P]),
+    ("tw_last_draft", C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("tw_token_timestamps", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_double,
                                       C.POINTER(C.c_float), _P]),
     ("tw_get_alignment", C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_float), _P]),

@@ -93,7 +93,13 @@ struct tw_ctx {
   unsigned* suppress_bits = nullptr;  // [(V+31)/32] static suppress list as a bitmap, rebuilt per generate call
   int* h_pinned = nullptr;  // pinned host scratch: finished ring [8][64] | n_valid [64] | DecState upload [16]
   int* row_ids = nullptr;   // device token table of a prefill (position-major), row_ids_cap ints
-  int* h_rows = nullptr;    // its pinned host staging
+  int* h_rows = nullptr;    // its pinned host staging: [2][row_ids_cap] (token table | last-timestamp table of a verify round)
+  // draft-and-verify (tw_greedy_opts::n_draft): per-row sampler state and results (SamplerArgs, tw_common.h)
+  int* row_lastts = nullptr;     // [row_ids_cap] position-major like row_ids
+  int* row_choice = nullptr;     // [row_ids_cap]
+  int* verify_state = nullptr;   // [2 + 64] device
+  int* h_verify = nullptr;       // pinned: [2 + 64] read back | [1] reset value
+  int last_draft[4] = {0, 0, 0, 0};   // of the last greedy call: tokens offered, accepted, verify launches, verify rounds
   size_t row_ids_cap = 0;
   int row_cap = 0;          // rows the per-token activation buffers hold (>= max_batch; 64 for the prefill launches)
   int* h_stage = nullptr;   // pinned staging of tw_generate_greedy: token table [Bmax][P] (up and down) | 3 x [Bmax] | suppress lists | DecState
@@ -235,6 +241,7 @@ int tw_destroy(tw_ctx* c) {
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->h_rows) (void)hipHostFree(c->h_rows);
+  if (c->h_verify) (void)hipHostFree(c->h_verify);
   for (int i = 0; i < 5; ++i) {
     if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]);
     if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]);
@@ -443,8 +450,12 @@ static int create_ctx(const tw_config* cfg, const tw_ctx* share, tw_ctx** out) {
   CALLOC(c->dstats, R * (d / 4) * 2 * 4, true);
   c->row_ids_cap = (size_t)B * P;
   CALLOC(c->row_ids, c->row_ids_cap * 4, true);
-  CHIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_rows), sizeof(int) * c->row_ids_cap, hipHostMallocDefault));
-  CALLOC(c->logits, B * V * 4, true);
+  CHIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_rows), sizeof(int) * 2 * c->row_ids_cap, hipHostMallocDefault));
+  CALLOC(c->row_lastts, c->row_ids_cap * 4, true);
+  CALLOC(c->row_choice, c->row_ids_cap * 4, true);
+  CALLOC(c->verify_state, (2 + 64) * 4, true);
+  CHIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_verify), sizeof(int) * (2 + 64 + 2), hipHostMallocDefault));
+  CALLOC(c->logits, R * V * 4, true);   // (the rows of a verify launch - up to 64 - whatever max_batch is: 13 MB)
   const size_t Ha = c->Ha > 0 ? c->Ha : 1;
   CALLOC(c->align, B * Ha * P * T * 4, true);
   CALLOC(c->align_slot, Ld * H * 4, false);
@@ -912,7 +923,9 @@ bool getenv_off_fuse() {
 // rs > 0: rows mode (tw_common.h: tw_row_of) - the B rows are rs streams x B / rs consecutive positions whose tokens are `ids`
 // (device, row order); no logits are produced (the tokens of those positions are known: prefill_core)
 // embed = false: the input rows are already in place (the sampler's last launch of the previous step wrote them, SamplerArgs::x_next)
-int decode_core(tw_ctx* c, int B, hipStream_t st, int rs = 0, const int* ids = nullptr, bool embed = true) {
+// rows_logits: rows mode WITH the tied-logits projection of every row (draft-and-verify: verify_round) - the same launch the step uses,
+// so a row's logits are bit for bit what the one-position step would have produced (k_decode.hip: one reduction order for every B)
+int decode_core(tw_ctx* c, int B, hipStream_t st, int rs = 0, const int* ids = nullptr, bool embed = true, bool rows_logits = false) {
   const int d = c->d, H = c->H, F = c->ffn, T = c->T, P = c->P, dt = c->dtype;
   const size_t e = c->esz;
   if (embed) HIPCHK(c, launch_embed(dt, rs > 0 ? ids : c->cur_ids, c->stt, c->tok_emb, c->dec_pos, c->dx0, B, d, rs, st));
@@ -978,7 +991,7 @@ int decode_core(tw_ctx* c, int B, hipStream_t st, int rs = 0, const int* ids = n
     }
     void* t = xin; xin = xmid; xmid = t;
   }
-  if (rs == 0) {
+  if (rs == 0 || rows_logits) {
     GemvArgs a{};
     a.x = xin; a.ldx = d; a.ln_gw = c->logit_gw; a.ln_cb = c->logit_cb; a.W = c->logit_w; a.wscale = c->logit_ws; a.a16 = c->a16; a.N = c->V; a.K = d; a.B = B;
     a.y_f32 = c->logits;
@@ -1010,6 +1023,68 @@ int prefill_core(tw_ctx* c, int B, const int* tok, int ld, int n_pos, hipStream_
     HIPCHK(c, launch_advance(c->stt, l, st));
   }
   return TW_OK;
+}
+
+// One ROUND of draft-and-verify (tw_greedy_opts::n_draft).  tok[b * ld + p] holds, for every stream, the true tokens at
+// positions <= p_start and GUESSES behind them; the device position is p_start.  Positions [p_start, p_end] are run in rows mode
+// (launches of up to rows_cap rows = B streams x consecutive positions, each with the logits of every row and the sampler's choice for
+// every row - the processors see the given tokens as history), and the round ends at the first position p_acc where some stream's
+// choice differs from the token the next row was given (or at p_end): the choices at p_acc become the tokens at p_acc + 1 - exactly
+// what the one-position loop would have produced there, because a row's logits do not depend on which other rows share its launch
+// (k_decode.hip) and every earlier given token was confirmed - and the device state (history, last timestamp, finished flags,
+// position) is the loop's state after that token.  The host synchronises once per launch (it needs the decision to go on).
+// On return *p_next = p_acc + 1 and tok[.. + *p_next] holds those tokens.
+// *next_given = 1 when the tokens the round PRODUCED at *p_next are (for every stream) the guesses that stood there (p_next <= p_given).
+int verify_round(tw_ctx* c, int B, int* tok, int ld, int n_begin, int ts_begin, int p_start, int p_end, int rows_cap, const SamplerArgs& sa0,
+                 hipStream_t st, int* p_next, int* n_launches, int p_given, int* next_given) {
+  const int n_pos = p_end - p_start + 1;
+  if (n_pos < 1 || B > rows_cap) return fail(c, TW_EINVAL, "verify: bad round [%d, %d] for %d streams", p_start, p_end, B);
+  if ((size_t)n_pos * B > c->row_ids_cap) return fail(c, TW_EINVAL, "verify: %d positions x %d streams exceed the row table", n_pos, B);
+  const int L = std::max(1, rows_cap / B);
+  int* h = c->h_rows;
+  int* hl = c->h_rows + c->row_ids_cap;
+  for (int b = 0; b < B; ++b) {
+    int lt = -1;
+    for (int p = n_begin; p < p_start; ++p) if (tok[(size_t)b * ld + p] >= ts_begin) lt = tok[(size_t)b * ld + p];
+    for (int p = p_start; p <= p_end; ++p) {
+      const int t = tok[(size_t)b * ld + p];
+      if (p >= n_begin && t >= ts_begin) lt = t;
+      h[(size_t)(p - p_start) * B + b] = t;
+      hl[(size_t)(p - p_start) * B + b] = lt;
+    }
+  }
+  int* hv = c->h_verify;
+  hv[66] = 0x7fffffff; hv[67] = 0;
+  HIPCHK(c, hipMemcpyAsync(c->row_ids, h, sizeof(int) * (size_t)n_pos * B, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->row_lastts, hl, sizeof(int) * (size_t)n_pos * B, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(c->verify_state, hv + 66, sizeof(int) * 2, hipMemcpyHostToDevice, st));
+  for (int p0 = p_start; p0 <= p_end; p0 += L) {
+    const int l = std::min(L, p_end - p0 + 1);
+    const size_t off = (size_t)(p0 - p_start) * B;
+    c->dec_key_bound = std::min(((p0 + l + 63) / 64) * 64, ((c->P + 63) / 64) * 64);
+    int r = decode_core(c, l * B, st, B, c->row_ids + off, true, true);
+    if (r != TW_OK) return r;
+    SamplerArgs sa = sa0;
+    sa.B = l * B; sa.rows_streams = B; sa.row_pos0 = p0; sa.row_lastts = c->row_lastts + off; sa.row_choice = c->row_choice + off;
+    sa.row_last_pos = p_end; sa.row_is_last = (p0 + l > p_end) ? 1 : 0; sa.verify_state = c->verify_state;
+    HIPCHK(c, launch_sampler_rows(sa, st));
+    HIPCHK(c, hipMemcpyAsync(hv, c->verify_state, sizeof(int) * (2 + B), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    ++*n_launches;
+    if (hv[1] != 0) {
+      const int pn = hv[1];
+      if (pn < p0 + 1 || pn > p0 + l) return fail(c, TW_EHIP, "verify: decided position %d outside the launch [%d, %d)", pn - 1, p0, p0 + l);
+      bool same = pn <= p_given;
+      for (int b = 0; b < B; ++b) {
+        same = same && tok[(size_t)b * ld + pn] == hv[2 + b];
+        tok[(size_t)b * ld + pn] = hv[2 + b];
+      }
+      *next_given = same ? 1 : 0;
+      *p_next = pn;
+      return TW_OK;
+    }
+  }
+  return fail(c, TW_EHIP, "verify: the round ended without a decision");
 }
 
 int reset_state(tw_ctx* c, int n_prompt, hipStream_t st) {
@@ -1060,7 +1135,13 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
   // forced output tokens (tw_greedy_opts::n_forced): the begin index of the generation is n_begin, the tokens behind it are given
   const int n_forced = o->n_forced;
   if (n_forced < 0 || n_forced >= n_prompt) return fail(c, TW_EINVAL, "bad n_forced %d (n_prompt %d)", n_forced, n_prompt);
-  const int n_begin = n_prompt - n_forced;
+  // draft tokens (tw_greedy_opts::n_draft): guesses of the output, verified - the result is the plain call's, token for token
+  const int n_draft = o->n_draft;
+  if (n_draft < 0 || n_draft >= n_prompt || (n_draft > 0 && n_forced > 0))
+    return fail(c, TW_EINVAL, "bad n_draft %d (n_prompt %d, n_forced %d: one of the two)", n_draft, n_prompt, n_forced);
+  if (o->pad_id < 0 || o->pad_id >= c->V || o->eos_id < 0 || o->eos_id >= c->V)
+    return fail(c, TW_EINVAL, "pad_id %d / eos_id %d outside the vocabulary", o->pad_id, o->eos_id);   // (the sampler embeds pad_id for finished rows)
+  const int n_begin = n_prompt - n_forced - n_draft;
   int max_len = n_begin + o->max_new_tokens;
   if (o->max_length > 0 && o->max_length < max_len) max_len = o->max_length;
   if (max_len > c->P) max_len = c->P;
@@ -1092,8 +1173,8 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
     neg[b] = -1;
     for (int i = n_begin; i < n_prompt; ++i) {   // state the sampler would have after producing the forced tokens itself
       const int t = prompt[(size_t)b * n_prompt + i];
-      if (t == o->eos_id) return fail(c, TW_EINVAL, "a forced token is <eos>");
-      if (o->timestamps && t > o->no_timestamps_id) neg[b] = t;
+      if (t == o->eos_id) return fail(c, TW_EINVAL, n_draft > 0 ? "a draft token is <eos>" : "a forced token is <eos>");
+      if (n_forced > 0 && o->timestamps && t > o->no_timestamps_id) neg[b] = t;
     }
   }
   HIPCHK(c, hipMemcpyAsync(c->seq, hseq, sizeof(int) * (size_t)B * P, hipMemcpyHostToDevice, st));
@@ -1111,7 +1192,7 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
   HIPCHK(c, launch_suppress_bitmap(c->suppress_dev, o->n_suppress, c->suppress_bits, c->V, st));
   *s0p = DecState{0, n_begin, max_len - 1, B};
   HIPCHK(c, hipMemcpyAsync(c->stt, s0p, sizeof(DecState), hipMemcpyHostToDevice, st));
-  const int s_start = n_forced > 0 ? n_prompt - 1 : 0;
+  int s_start = n_forced > 0 ? n_prompt - 1 : 0;
   if (n_forced > 0) {   // positions 0 .. n_prompt-2 in batched launches (self-attention caches + alignment rows); device pos -> s_start
     int r = prefill_core(c, B, prompt, n_prompt, s_start, st);
     if (r != TW_OK) return r;
@@ -1127,6 +1208,43 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
   // the embedding of the token a step has chosen is written by the sampler's last launch (k_decode.hip: embed_row), so a step is
   // layers + logits + sampler; only the FIRST step of the call needs its input row from a launch of its own (TW_FUSE_EMBED=0: A/B)
   static const bool fuse_embed = []() { const char* e = getenv("TW_FUSE_EMBED"); return !(e && atoi(e) == 0); }();
+  c->last_draft[0] = n_draft * B; c->last_draft[1] = c->last_draft[2] = c->last_draft[3] = 0;
+  bool draft_all_done = false;
+  if (n_draft > 0) {
+    // ---- draft-and-verify: rounds of rows-mode launches over the given tokens (verify_round), then the ordinary loop from where the
+    //      last round stopped.  Round 1 takes everything that was offered (prompt included: its positions have to be processed anyway);
+    //      after a rejection the REST of the draft is offered again at the same positions (a changed timestamp or word usually leaves
+    //      the text behind it as it was), in launches of one group of rows - such a launch costs about what one step costs and
+    //      yields at least the one token a step yields - until a round confirms nothing or the draft is used up. ----
+    static const int retry_rows = []() { const char* e = getenv("TW_DRAFT_RETRY_ROWS"); const int v = e ? atoi(e) : 16; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
+    static const int max_rounds = []() { const char* e = getenv("TW_DRAFT_MAX_ROUNDS"); const int v = e ? atoi(e) : 16; return v < 1 ? 1 : v; }();
+    static const int first_rows = []() { const char* e = getenv("TW_DRAFT_FIRST_ROWS"); const int v = e ? atoi(e) : 64; return v < 1 ? 1 : (v > 64 ? 64 : v); }();
+    const int cap = std::min((c->w8 && !c->a16) ? 16 : 64, c->row_cap);   // W8A8 quantises activations per group of 16 rows: one group per launch
+    if (B > cap) return fail(c, TW_EINVAL, "n_draft: %d streams exceed the %d rows of a launch", B, cap);
+    const int ts_begin = o->timestamps ? o->no_timestamps_id + 1 : c->V;
+    const int p_end = n_prompt - 1;
+    tic(c, 3, st);
+    int pos = 0, rounds = 0;
+    while (true) {
+      // (several streams: at least four positions per retry launch, or a round could not confirm anything)
+      const int rows = rounds == 0 ? std::min(cap, std::max(first_rows, B)) : std::min(cap, std::max(retry_rows, 4 * B));
+      const int pe = rounds == 0 ? p_end : std::min(p_end, pos + std::max(1, rows / B) - 1);
+      int pn = 0, next_given = 0;
+      int r = verify_round(c, B, hseq, P, n_begin, ts_begin, pos, pe, rows, sa, st, &pn, &c->last_draft[2], p_end, &next_given);
+      if (r != TW_OK) return r;
+      ++rounds;
+      // guesses this round confirmed: the given tokens at positions <= p_acc that were compared, and the token the round produced
+      // itself at p_acc + 1 where it is the guess that stood there (a round that ends without a mismatch before the draft does)
+      const int confirmed = pn - 1 - std::max(pos, n_begin - 1) + ((next_given && pn >= n_begin) ? 1 : 0);
+      c->last_draft[1] += std::max(0, confirmed) * B;
+      pos = pn;
+      draft_all_done = true;
+      for (int b = 0; b < B; ++b) draft_all_done &= pos >= n_begin && hseq[(size_t)b * P + pos] == o->eos_id;
+      if (draft_all_done || pos > p_end - 1 || pos >= max_len - 1 || rounds >= max_rounds || (rounds > 1 && confirmed <= 0)) break;
+    }
+    c->last_draft[3] = rounds;
+    s_start = pos;
+  }
   if (fuse_embed) {
     sa.tok_emb = c->tok_emb; sa.pos_emb = c->dec_pos; sa.x_next = c->dx0; sa.d = c->d; sa.dtype = c->dtype;
     HIPCHK(c, launch_embed(c->dtype, c->cur_ids, c->stt, c->tok_emb, c->dec_pos, c->dx0, B, c->d, 0, st));
@@ -1177,7 +1295,7 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
   const auto ht0 = std::chrono::steady_clock::now();
   auto ht_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ht0).count(); };
   double ht_first = 0, ht_loop = 0;
-  tic(c, 3, st);
+  if (n_draft == 0) tic(c, 3, st);
   // two steps per graph launch: measured +2 % at one turbo stream, +0.3 % at 16 large-v3 streams (4 per launch: +3 % / +0.8 %, but
   // up to 7 steps past the last <eos> instead of 5); the finished flags are read LAG launches behind so the host never waits
   static const int group = []() { const char* e = getenv("TW_GRAPH_STEPS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
@@ -1187,7 +1305,7 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
   static const int group_forced = []() { const char* e = getenv("TW_GRAPH_STEPS_FORCED"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
   const int LAG = std::max(1, 4 / group);
   int steps = 0, launches = 0;
-  bool all_done = false;
+  bool all_done = draft_all_done;
   for (int s = s_start; s < max_len - 1 && !all_done;) {
     // step s produces the token at position s + 1, which can be <eos> only once s + 1 - n_prompt >= min_new_tokens
     // (not for the first launch of a call: submitting a graph costs host time in proportion to its nodes, and the GPU is idle until
@@ -1237,10 +1355,13 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
 
   // common sequence length exactly as HF's loop would have stopped: when the last row hit eos, or at max_len
   const int produced = s_start + steps + 1;  // positions 0 .. s_start + steps are filled
-  int L = n_prompt + 1;
+  // first position a SAMPLED token sits at (forced / confirmed draft tokens before it are never <eos>; unconfirmed draft tokens
+  // behind `produced` are stale and never looked at)
+  const int scan_from = n_draft > 0 ? std::max(s_start, n_begin) : n_prompt;
+  int L = scan_from + 1;
   for (int b = 0; b < B; ++b) {
     int lb = produced;
-    for (int i = n_prompt; i < produced; ++i)
+    for (int i = scan_from; i < produced; ++i)
       if (hseq[(size_t)b * P + i] == o->eos_id) { lb = i + 1; break; }
     if (lb > L) L = lb;
   }
@@ -1251,7 +1372,7 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
       if (i < L) {
         v = hseq[(size_t)b * P + i];
         if (ended) v = o->pad_id;
-        if (i >= n_prompt && v == o->eos_id) ended = true;
+        if (i >= scan_from && v == o->eos_id) ended = true;
       }
       out_ids[(size_t)b * out_ld + i] = v;
     }
@@ -1259,6 +1380,27 @@ int tw_generate_greedy(tw_ctx* c, int32_t B, const int32_t* prompt, int32_t n_pr
   *out_len = L;
   c->last_seq_len = L;
   c->last_n_prompt = n_prompt;
+  return TW_OK;
+}
+
+// Diagnostics only (NOT part of include/thewhisper.h): copy an internal decoder buffer to the host - tools/dbg/rows_vs_steps.py.
+int tw_dbg_copy(tw_ctx* c, const char* what, void* host, size_t bytes) {
+  if (!c || !what || !host) return TW_EINVAL;
+  TW_ON_DEVICE(c);
+  const std::string w(what);
+  const void* src = w == "dq" ? c->dq : w == "du" ? (void*)c->du : w == "dstats" ? (void*)c->dstats : w == "datt" ? c->datt : w == "dx0" ? c->dx0 :
+                    w == "dx1" ? c->dx1 : w == "dh" ? c->dh : w == "self_k" ? c->self_k : w == "self_v" ? c->self_v : w == "logits" ? (void*)c->logits : nullptr;
+  if (!src) return TW_EINVAL;
+  (void)hipDeviceSynchronize();
+  return hipMemcpy(host, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? TW_OK : TW_EHIP;
+}
+
+int tw_last_draft(tw_ctx* c, int32_t* offered, int32_t* accepted, int32_t* launches, int32_t* rounds) {
+  if (!c) return TW_EINVAL;
+  if (offered) *offered = c->last_draft[0];
+  if (accepted) *accepted = c->last_draft[1];
+  if (launches) *launches = c->last_draft[2];
+  if (rounds) *rounds = c->last_draft[3];
   return TW_OK;
 }
 

@@ -309,7 +309,8 @@ hipError_t launch_enc_attention(int dtype, const void* q, const void* k, const v
   if (B <= 0 || T <= 0 || Tp % 64 != 0 || Tp < T) return hipErrorInvalidValue;
   // 128 queries per workgroup when that still yields >= 2 workgroups per CU, else 64.
   const long long blocks128 = (long long)B * H * ((T + 127) / 128);
-  const bool big = blocks128 >= 512;
+  static const int qb_env = []() { const char* e = getenv("TW_ATTN_QB"); return e ? atoi(e) : 0; }();   // diagnostics: 1 / 2 forces 64 / 128 queries
+  const bool big = qb_env ? qb_env == 2 : blocks128 >= 512;
   // TW_ATTN_XCD: 1 (default) = heads pinned to XCDs when there are at least 64 of them (with the 20 heads of one stream 4 XCDs
   // would get three heads and 4 two: 5.68 -> 5.88 ms for one 30 s chunk), 0 = never, 2 = always
   static const int xcd_env = []() { const char* e = getenv("TW_ATTN_XCD"); return e ? atoi(e) : 1; }();

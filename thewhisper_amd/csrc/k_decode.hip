@@ -72,7 +72,7 @@ __device__ __forceinline__ float gelu_exact(float x) {
   p = fmaf(t, p, 1.421413741f);
   p = fmaf(t, p, -0.284496736f);
   p = fmaf(t, p, 0.254829592f);
-  const float e = 1.0f - p * t * __expf(-az * az);
+  const float e = fmaf(-(p * t), __expf(-az * az), 1.0f);   // (spelled out: one rounding sequence in every instantiation)
   return 0.5f * x * (1.0f + copysignf(e, z));
 }
 
@@ -296,7 +296,18 @@ template <> __device__ __forceinline__ void sk_stats<float>(const u32x4_t& v, fl
 // A weight lane needs the scales of ITS two 32-value blocks (16-byte half h of lane groups 2u, 2u+1, u = kq / 2); the scale array
 // holds block t = 2h + u in lane group t (where the scaled MFMA reads it), so the lane fetches groups u and 2 + u: two byte loads
 // per step instead of one, no exchange.  Several groups of 16 streams (CG > 1) are available in this mode only.
-template <typename T, int NW, int SK_MAXS, bool LN, int EPI, bool MULTI, bool W8, int CG, int TR, bool A16 = false, int MODE = 0>
+//
+// ONE reduction order for every number of rows (round 6).  A stream's result must not depend on who else is in the launch - the
+// serving hub mixes sessions freely, and the draft-and-verify prefill (api.hip: verify_core) is only exact if a position computed in a
+// 64-row launch has the bits the one-row step would have produced.  Every kernel flavour contracts a given k step with the same
+// instruction and walks a wavefront's K slice in ascending order, so results can only differ through HOW K IS SPLIT over wavefronts.
+// All projections use 8 slices [w S / 8, (w + 1) S / 8) summed in ascending order - except the long-K residual projection (fc2,
+// K >= 4096), which takes 16 wavefronts when the launch has one group of streams (half the steps per wavefront on the critical
+// path) and 8 with several groups (registers).  Its canonical order is therefore defined over SIXTEEN slices v = 0..15,
+// P_v = sum over steps [v S / 16, (v + 1) S / 16), result = sum_{w = 0..7} (P_2w + P_2w+1): the 16-wavefront kernel adds its LDS tiles
+// in pairs, the 8-wavefront kernel (SPLIT2) keeps two accumulators per group - the two halves of its slice - and adds them in
+// registers before the tile goes to LDS.  Bit-identical by construction; tests/test_gpu_parity.py::test_rows_of_a_launch_do_not_matter.
+template <typename T, int NW, int SK_MAXS, bool LN, int EPI, bool MULTI, bool W8, int CG, int TR, bool A16 = false, int MODE = 0, bool SPLIT2 = false>
 __global__ __launch_bounds__(NW * 64, (CG > 1 ? ((NW >= 16 || (TW_CG_RING && !MULTI && !W8 && MODE == 2)) ? 4 : 2) : (NW >= 16 ? 4 : (W8 ? (SK_MAXS <= 2 ? 4 : 2) : (SK_MAXS <= 5 ? 4 : 2)))))
 void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_arg, int n_arg, int rg_arg,
                         const unsigned char* wscale_arg, const void* bias_arg, const void* res_arg, const float* gw_arg, GemvArgs a) {
@@ -309,6 +320,7 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
   static_assert(!W8 || TR == 16 || TR == 8, "MXFP8 weights: 16- or 8-row tiles");
   static_assert(!A16 || W8, "A16 is a flavour of the MXFP8-weight kernel");
   static_assert(!W8 || CG == 1 || A16, "several stream groups with MXFP8 weights: W8A16 only");
+  static_assert(!SPLIT2 || (NW == 8 && !LN && !MULTI && CG > 1), "SPLIT2: the 8-wavefront flavour of the long-K residual projection");
   constexpr int E = ElemTraits<T>::kPer16B;
   constexpr int XPS = W8 ? 4 : 1;  // 32-wide activation fragments per MFMA step
   constexpr int WPS = W8 ? 2 : 1;  // 16-B weight requests per MFMA step
@@ -538,20 +550,30 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
   const int n_grp = MULTI ? RG : 1;
   for (int grp = 0; grp < n_grp; ++grp) {
     const int tile = tile0 + grp;
-    f32x4_t acc[CG];
+    f32x4_t acc[CG], acc2[SPLIT2 ? CG : 1];   // acc2: the second half of the wavefront's K slice (SPLIT2, see the kernel's header)
     float ps[CG], pss[CG];
 #pragma unroll
     for (int g = 0; g < CG; ++g) { acc[g] = f32x4_t{0.f, 0.f, 0.f, 0.f}; ps[g] = 0.f; pss[g] = 0.f; }
+#pragma unroll
+    for (int g = 0; g < (SPLIT2 ? CG : 1); ++g) acc2[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int s_mid = SPLIT2 ? (int)((long long)(2 * wave + 1) * S / (2 * NW)) : 0x7fffffff;   // first step of slice 2 wave + 1 of 16
     auto mfma_round = [&](int s0) {
 #pragma unroll
       for (int i = 0; i < SK_MAXS; ++i) {
         const bool on = s0 + i < s_hi;  // wave-uniform: steps past this wavefront's K slice contribute zero
+        const bool second = SPLIT2 && s0 + i >= s_mid;   // wave-uniform: which of the two accumulator sets this step belongs to
         const u32x4_t zero = u32x4_t{0u, 0u, 0u, 0u};
         if constexpr (A16) {
           // fragments m = 0, 1 live in the first 16 bytes (block h = 0), m = 2, 3 in the second (h = 1)
           u32x4_t wf[4];
           sk_widen8(on ? wq[2 * i] : zero, __builtin_bit_cast(float, (unsigned)(wsc[i] & 0xff) << 23), wf[0], wf[1]);
           sk_widen8(on ? wq[2 * i + 1] : zero, __builtin_bit_cast(float, (unsigned)(wsc2[i] & 0xff) << 23), wf[2], wf[3]);
+          if (SPLIT2 && second) {   // (a branch around matrix instructions only: no load inside)
+#pragma unroll
+            for (int g = 0; g < (SPLIT2 ? CG : 1); ++g)
+#pragma unroll
+              for (int m = 0; m < 4; ++m) acc2[g] = sk_mfma<T>(wf[m], on ? xq[g][i * 4 + m] : zero, acc2[g]);
+          } else {
 #pragma unroll
           for (int g = 0; g < CG; ++g)
 #pragma unroll
@@ -560,6 +582,7 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
               if (LN && (!MULTI || grp == 0)) sk_stats<T>(xv, ps[g], pss[g]);
               acc[g] = sk_mfma<T>(wf[m], xv, acc[g]);
             }
+          }
         } else if (W8) {
           const u32x4_t w0 = on ? wq[2 * i] : zero, w1 = on ? wq[2 * i + 1] : zero;
           const v8i_t wb = {(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
@@ -577,23 +600,34 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
           }
         } else {
           const u32x4_t wv = on ? wq[i] : zero;
+          if (SPLIT2 && second) {
+#pragma unroll
+            for (int g = 0; g < (SPLIT2 ? CG : 1); ++g) acc2[g] = sk_mfma<T>(wv, on ? xq[g][i] : zero, acc2[g]);
+          } else {
 #pragma unroll
           for (int g = 0; g < CG; ++g) {
             const u32x4_t xv = on ? xq[g][i] : zero;
             if (LN && (!MULTI || grp == 0)) sk_stats<T>(xv, ps[g], pss[g]);
             acc[g] = sk_mfma<T>(wv, xv, acc[g]);
           }
+          }
         }
       }
     };
     if constexpr (RING) {
+      static_assert(!SPLIT2 || SK_MAXS % 2 == 0, "SPLIT2 rings: the slice's midpoint is a step boundary");
 #pragma unroll
       for (int i = 0; i < SK_MAXS; ++i) {
 #pragma unroll
         for (int g = 0; g < CG; ++g) {
           const u32x4_t xv = rx[i % DX][g];
           if (LN) sk_stats<T>(xv, ps[g], pss[g]);
-          acc[g] = sk_mfma<T>(rw[i % DW], xv, acc[g]);
+          if constexpr (SPLIT2) {   // (compile-time: S = NW * SK_MAXS, so s_mid = s_lo + SK_MAXS / 2)
+            if (i >= SK_MAXS / 2) acc2[g] = sk_mfma<T>(rw[i % DW], xv, acc2[g]);
+            else acc[g] = sk_mfma<T>(rw[i % DW], xv, acc[g]);
+          } else {
+            acc[g] = sk_mfma<T>(rw[i % DW], xv, acc[g]);
+          }
         }
         if (i + DX < SK_MAXS) {
 #pragma unroll
@@ -629,6 +663,10 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
     TW_TS(2);
     // D[i = weight row (lane>>4)*4 + reg][j = stream lane&15]
     if (MULTI && grp > 0) __syncthreads();  // previous tile's readers are done with `red`
+    if constexpr (SPLIT2) {   // P_2w + P_2w+1: the addition the 16-wavefront kernel performs on its LDS tiles
+#pragma unroll
+      for (int g = 0; g < (SPLIT2 ? CG : 1); ++g) acc[g] += acc2[g];
+    }
 #pragma unroll
     for (int g = 0; g < CG; ++g)
 #pragma unroll
@@ -650,8 +688,14 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
         const int g = EALL ? gi * 2 + eh : gi;
         const int jg = g * 16 + j;  // stream
         float v = 0.f;
+        if constexpr (NW >= 16) {   // sixteen slices added in pairs: the order the 8-wavefront SPLIT2 flavour reproduces (kernel header)
 #pragma unroll
-        for (int w = 0; w < NW; ++w) v += red[(w * CG + g) * kRedTile + i * TW_RED_STRIDE + j];
+          for (int w = 0; w < NW; w += 2)
+            v += red[(w * CG + g) * kRedTile + i * TW_RED_STRIDE + j] + red[((w + 1) * CG + g) * kRedTile + i * TW_RED_STRIDE + j];
+        } else {
+#pragma unroll
+          for (int w = 0; w < NW; ++w) v += red[(w * CG + g) * kRedTile + i * TW_RED_STRIDE + j];
+        }
         const float vraw = v;
         if (LN) {
           if (!MULTI || grp == 0) {
@@ -659,10 +703,9 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
 #pragma unroll
             for (int w = 0; w < NW; ++w) { sx += pstat[w][jg][0]; sxx += pstat[w][jg][1]; }
             const float inv_k = __builtin_amdgcn_rcpf((float)K);
-            mean[gi] = sx * inv_k;
-            rstd[gi] = __frsqrt_rn(fmaxf(sxx * inv_k - mean[gi] * mean[gi], 0.f) + 1e-5f);
+            tw_ln_scalars(sx, sxx, inv_k, mean[gi], rstd[gi]);
           }
-          v = rstd[gi] * (v - mean[gi] * e_gw) + e_c;
+          v = tw_ln_apply(v, mean[gi], rstd[gi], e_gw, e_c);
         } else {
           v += e_c;
         }
@@ -872,9 +915,9 @@ __device__ __forceinline__ void fq_finish(const QRaw<T>& r, const FusedQ& fq, in
   s = tw_wave_sum(s);
   ss = tw_wave_sum(ss);
   const float inv_k = __builtin_amdgcn_rcpf((float)fq.d);
-  const float mean = s * inv_k;
-  const float rstd = __frsqrt_rn(fmaxf(ss * inv_k - mean * mean, 0.f) + 1e-5f);
-  qrow[lane] = tw_cast<T>(rstd * (r.u - mean * r.gw) + r.cb);
+  float mean, rstd;
+  tw_ln_scalars(s, ss, inv_k, mean, rstd);
+  qrow[lane] = tw_cast<T>(tw_ln_apply(r.u, mean, rstd, r.gw, r.cb));
 }
 
 // SINGLE: n_bound <= NW*64, so every K and V^T fragment of the head is requested before anything is waited for
@@ -1279,15 +1322,19 @@ struct SamplerMask {  // dynamic part of the mask: uniform scalars derived from 
   bool mask_eos, first, in_prompt, fin;
 };
 
+// b = row of the launch: a stream at the device position (ordinary step), or - rows mode, SamplerArgs::rows_streams > 0 - stream
+// b % rs at the host-known position row_pos0 + b / rs, sampled with the state the loop would have had there (draft-and-verify)
 __device__ __forceinline__ SamplerMask sampler_mask(const SamplerArgs& a, int b) {
   SamplerMask k;
   const int V = a.V;
-  const int pos = a.stt->pos;
+  const bool rows = a.rows_streams > 0;
+  const int stream = rows ? b % a.rows_streams : b;
+  const int pos = rows ? a.row_pos0 + b / a.rows_streams : a.stt->pos;
   const int n_prompt = a.stt->n_prompt;
   const int cur_len = pos + 1;
-  const int* seq = a.seq + (long long)b * a.seq_ld;
+  const int* seq = a.seq + (long long)stream * a.seq_ld;
   k.in_prompt = cur_len < n_prompt;     // still consuming the forced prompt
-  k.fin = a.finished[b] != 0;           // HF: finished rows keep receiving pad_token_id
+  k.fin = rows ? false : a.finished[b] != 0;           // HF: finished rows keep receiving pad_token_id
   k.first = (cur_len == n_prompt);
   const int n_new = cur_len - n_prompt;
   k.ts_begin = a.timestamps ? a.no_ts_id + 1 : V;
@@ -1296,7 +1343,7 @@ __device__ __forceinline__ SamplerMask sampler_mask(const SamplerArgs& a, int b)
   if (a.timestamps && !k.in_prompt) {
     last_ts = (n_new >= 1) && (seq[cur_len - 1] >= k.ts_begin);
     penult_ts = (n_new < 2) || (seq[cur_len - 2] >= k.ts_begin);
-    lastts_tok = a.last_ts[b];
+    lastts_tok = rows ? a.row_lastts[b] : a.last_ts[b];
   }
   k.b_lo = 0; k.b_hi = 0;  // range masked by the pairing rule
   if (last_ts) {
@@ -1429,22 +1476,32 @@ __device__ __forceinline__ void embed_row(const SamplerArgs& a, int b, int id, i
   }
 }
 
+// merge of the vocabulary slices of row b by one wavefront (all 64 lanes): the token HF's processors + argmax pick, in every lane
+__device__ __forceinline__ int sampler_merge(const SamplerArgs& a, int b, int lane) {
+  SamplerPartial p = a.partials[b * SAMPLER_NS_MAX + min(lane, a.n_slices - 1)];
+  const bool on = lane < a.n_slices;
+  MaxIdx bt{on ? p.bt_v : -INFINITY, on ? p.bt_i : 0x7fffffff}, bs{on ? p.bs_v : -INFINITY, on ? p.bs_i : 0x7fffffff};
+  const float my_m = bs.v;
+  bt = wave_best(bt);
+  bs = wave_best(bs);
+  float part_sum = (on && my_m > -INFINITY) ? p.sum * expf(my_m - bs.v) : 0.f;  // log-sum-exp merge of the slices
+  const float tot = wave_sum(part_sum);
+  bool force_ts = false;
+  if (a.timestamps && bs.v > -INFINITY) force_ts = (bs.v + logf(tot)) > bt.v;
+  int choice;
+  if (force_ts) choice = bs.i;
+  else choice = (bs.v > bt.v) ? bs.i : bt.i;
+  if (choice == 0x7fffffff) choice = 0;  // everything masked: torch.argmax of all -inf is 0
+  return choice;
+}
+
 __global__ __launch_bounds__(1024) void sampler_finish_kernel(SamplerArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int pos_now = a.stt->pos;              // (thread 0 advances it behind the barrier at the end)
   for (int b = tid >> 6; b < a.B; b += 16) {  // wavefront w <- streams w, w+16, ...
     int next_id = 0;
     const SamplerMask k = sampler_mask(a, b);
-    SamplerPartial p = a.partials[b * SAMPLER_NS_MAX + min(lane, a.n_slices - 1)];
-    const bool on = lane < a.n_slices;
-    MaxIdx bt{on ? p.bt_v : -INFINITY, on ? p.bt_i : 0x7fffffff}, bs{on ? p.bs_v : -INFINITY, on ? p.bs_i : 0x7fffffff};
-    const float my_m = bs.v;
-    bt = wave_best(bt);
-    bs = wave_best(bs);
-    float part_sum = (on && my_m > -INFINITY) ? p.sum * expf(my_m - bs.v) : 0.f;  // log-sum-exp merge of the slices
-    const float tot = wave_sum(part_sum);
-    bool force_ts = false;
-    if (a.timestamps && bs.v > -INFINITY) force_ts = (bs.v + logf(tot)) > bt.v;
+    const int choice = sampler_merge(a, b, lane);
     if (lane == 0) {
       const int cur_len = a.stt->pos + 1;
       int* seq = a.seq + (long long)b * a.seq_ld;
@@ -1456,10 +1513,6 @@ __global__ __launch_bounds__(1024) void sampler_finish_kernel(SamplerArgs a) {
         a.cur_ids[b] = a.pad;
         next_id = a.pad;
       } else {
-        int choice;
-        if (force_ts) choice = bs.i;
-        else choice = (bs.v > bt.v) ? bs.i : bt.i;
-        if (choice == 0x7fffffff) choice = 0;  // everything masked: torch.argmax of all -inf is 0
         seq[cur_len] = choice;
         a.cur_ids[b] = choice;
         next_id = choice;
@@ -1476,6 +1529,66 @@ __global__ __launch_bounds__(1024) void sampler_finish_kernel(SamplerArgs a) {
   }
   __syncthreads();
   if (tid == 0) a.stt->pos += 1;
+}
+
+// Rows mode (draft-and-verify; SamplerArgs): every row's token, the first position at which a stream's token differs from the token the
+// NEXT row was given, and - once the round is decided (a mismatch, or the round's last launch) - the state the ordinary loop would have
+// after producing the token at p_acc + 1 itself: that token appended to every stream's history (seq, cur_ids, last_ts, finished), the
+// device position = p_acc + 1.  Everything at positions > p_acc + 1 (self-attention K / V rows, alignment rows, stale given tokens) is
+// overwritten by the steps that follow before anything reads it.  One workgroup; rows = streams x positions <= 64.
+__global__ __launch_bounds__(1024) void sampler_rows_finish_kernel(SamplerArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int rs = a.rows_streams;
+  for (int r = tid >> 6; r < a.B; r += 16) {
+    const int stream = r % rs, p = a.row_pos0 + r / rs;
+    const SamplerMask k = sampler_mask(a, r);
+    int choice = sampler_merge(a, r, lane);
+    if (lane == 0) {
+      const int* seq = a.seq + (long long)stream * a.seq_ld;
+      if (k.in_prompt) choice = seq[p + 1];          // the prompt is not sampled
+      a.row_choice[r] = choice;
+      if (p < a.row_last_pos && choice != seq[p + 1]) atomicMin(&a.verify_state[0], p);
+    }
+  }
+  __syncthreads();
+  __shared__ int p_acc_s;
+  if (tid == 0) {
+    const int fm = a.verify_state[0];     // (this workgroup's own atomics, behind the barrier)
+    int p_acc = -1;
+    if (fm != 0x7fffffff) p_acc = fm;
+    else if (a.row_is_last) p_acc = a.row_last_pos;
+    p_acc_s = p_acc;
+  }
+  __syncthreads();
+  const int p_acc = p_acc_s;
+  if (p_acc < 0) {                        // undecided: the next launch of the round continues behind this launch's positions
+    if (tid == 0) a.stt->pos += a.B / rs;
+    return;
+  }
+  const int n_streams = rs;
+  if (tid < n_streams) {
+    const int b = tid;
+    const int n_prompt = a.stt->n_prompt;
+    const int ts_begin = a.timestamps ? a.no_ts_id + 1 : a.V;
+    int* seq = a.seq + (long long)b * a.seq_ld;
+    const int tok = a.row_choice[(p_acc - a.row_pos0) * rs + b];   // (a mismatch can only be found in THIS launch: earlier ones ended the round)
+    int lt = -1;
+    for (int i = n_prompt; i <= p_acc; ++i) if (a.timestamps && seq[i] >= ts_begin) lt = seq[i];
+    if (p_acc + 1 >= n_prompt) {          // a sampled token (not a prompt token)
+      if (a.timestamps && tok >= ts_begin) lt = tok;
+      a.finished[b] = (tok == a.eos) ? 1 : 0;
+    } else {
+      a.finished[b] = 0;
+    }
+    seq[p_acc + 1] = tok;
+    a.cur_ids[b] = tok;
+    a.last_ts[b] = lt;
+    a.verify_state[2 + b] = tok;
+  }
+  if (tid == 0) {
+    a.verify_state[1] = p_acc + 1;
+    a.stt->pos = p_acc + 1;
+  }
 }
 
 __global__ void advance_kernel(DecState* stt, int n) { stt->pos += n; }
@@ -1496,13 +1609,21 @@ static int cg_mode() {
   return m;
 }
 
-template <typename T, int NW, int SK_MAXS, bool MULTI, bool W8, int CG, int TR, bool A16 = false, int MODE = 0>
+template <typename T, int NW, int SK_MAXS, bool MULTI, bool W8, int CG, int TR, bool A16 = false, int MODE = 0, bool SPLIT2 = false>
 static hipError_t skinny_launch_cg(const GemvArgs& a, dim3 grid, size_t lds1, hipStream_t st) {
   const bool ln = a.ln_gw != nullptr;
   const size_t lds = lds1 * CG;
-#define SK_GO(LNV, EPIV) hipLaunchKernelGGL((skinny_mfma_kernel<T, NW, SK_MAXS, LNV, EPIV, MULTI, W8, CG, TR, A16, MODE>), grid, dim3(NW * 64), lds, st, \
+#define SK_GO(LNV, EPIV) hipLaunchKernelGGL((skinny_mfma_kernel<T, NW, SK_MAXS, LNV, EPIV, MULTI, W8, CG, TR, A16, MODE, SPLIT2>), grid, dim3(NW * 64), lds, st, \
                                             a.x, a.W, a.K, a.B, a.N, a.rg, a.wscale, a.bias, a.res, a.ln_gw, a)
-  if constexpr (TR != 16) {  // narrow tiles: plain / residual / GELU projections, one tile per workgroup
+  if constexpr (SPLIT2) {  // the 8-wavefront flavour of the long-K residual projection (fc2 above 16 rows): kernel header
+    if (ln || a.y_f32 || a.kcache || a.gelu) return hipErrorInvalidValue;
+    if constexpr (MULTI || NW != 8 || CG == 1) {
+      return hipErrorInvalidValue;
+    } else {
+      if (a.res) SK_GO(false, SK_RES);
+      else SK_GO(false, SK_STORE);
+    }
+  } else if constexpr (TR != 16) {  // narrow tiles: plain / residual / GELU projections, one tile per workgroup
     if (a.y_f32 || a.kcache) return hipErrorInvalidValue;
     if constexpr (MULTI || (W8 && TR != 8)) {
       return hipErrorInvalidValue;
@@ -1541,36 +1662,45 @@ static hipError_t skinny_launch_cg(const GemvArgs& a, dim3 grid, size_t lds1, hi
   return hipGetLastError();
 }
 
-template <typename T, int NW, int SK_MAXS, bool MULTI, bool W8, int TR>
+template <typename T, int NW, int SK_MAXS, bool MULTI, bool W8, int TR, bool SPLIT2 = false>
 static hipError_t skinny_launch_v(const GemvArgs& a, dim3 grid, size_t lds1, hipStream_t st) {
   if constexpr (W8) {
     // MXFP8 weights.  a.a16: W8A16 (weights widened in registers, bf16 activations) - the only flavour with several groups
     // of 16 streams (2 steps = 8 activation fragments per group in flight, further rounds for longer K)
     if (a.a16) {
-      if (a.B <= 16) return skinny_launch_cg<T, NW, SK_MAXS, MULTI, true, 1, TR, true>(a, grid, lds1, st);
+      if (a.B <= 16) {
+        if constexpr (SPLIT2) return hipErrorInvalidValue;
+        else return skinny_launch_cg<T, NW, SK_MAXS, MULTI, true, 1, TR, true>(a, grid, lds1, st);
+      }
       if constexpr (NW != 8 || SK_MAXS != 2) {
         return hipErrorInvalidValue;
       } else {
-        if (a.B <= 32) return skinny_launch_cg<T, NW, SK_MAXS, MULTI, true, 2, TR, true>(a, grid, lds1, st);
-        return skinny_launch_cg<T, NW, SK_MAXS, MULTI, true, 4, TR, true>(a, grid, lds1, st);
+        if (a.B <= 32) return skinny_launch_cg<T, NW, SK_MAXS, MULTI, true, 2, TR, true, 0, SPLIT2>(a, grid, lds1, st);
+        return skinny_launch_cg<T, NW, SK_MAXS, MULTI, true, 4, TR, true, 0, SPLIT2>(a, grid, lds1, st);
       }
     }
-    if (a.B > 16) return hipErrorInvalidValue;
-    return skinny_launch_cg<T, NW, SK_MAXS, MULTI, true, 1, TR>(a, grid, lds1, st);
-  }
-  if (a.B <= 16) return skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 1, TR>(a, grid, lds1, st);
-  // several groups of 16 streams: 8 wavefronts x 5 fragments in flight (more rounds for long K) keeps the per-group
-  // activation fragments inside the register file
-  if constexpr (W8 || NW != 8 || SK_MAXS != 5) {
+    if (a.B > 16 || SPLIT2) return hipErrorInvalidValue;
+    if constexpr (!SPLIT2) return skinny_launch_cg<T, NW, SK_MAXS, MULTI, true, 1, TR>(a, grid, lds1, st);
     return hipErrorInvalidValue;
   } else {
-    if (a.B <= 32) return skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 2, TR>(a, grid, lds1, st);
-    return skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 4, TR>(a, grid, lds1, st);
+    if (a.B <= 16) {
+      if constexpr (SPLIT2) return hipErrorInvalidValue;
+      else return skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 1, TR>(a, grid, lds1, st);
+    }
+    // several groups of 16 streams: 8 wavefronts x 5 fragments in flight (more rounds for long K) keeps the per-group
+    // activation fragments inside the register file
+    if constexpr (NW != 8 || SK_MAXS != 5) {
+      return hipErrorInvalidValue;
+    } else {
+      if (a.B <= 32) return skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 2, TR, false, 0, SPLIT2>(a, grid, lds1, st);
+      return skinny_launch_cg<T, NW, SK_MAXS, MULTI, W8, 4, TR, false, 0, SPLIT2>(a, grid, lds1, st);
+    }
   }
 }
 
+// split2: this launch is the several-groups form of a projection whose one-group form runs on 16 wavefronts (skinny_launch: `longk`)
 template <typename T, int NW, int TR>
-static hipError_t skinny_launch_nw(const GemvArgs& a0, hipStream_t st) {
+static hipError_t skinny_launch_nw(const GemvArgs& a0, hipStream_t st, bool split2 = false) {
   constexpr int E = ElemTraits<T>::kPer16B;
   GemvArgs a = a0;
   if (a.K % (4 * E) != 0 || a.B > 64) return hipErrorInvalidValue;
@@ -1588,17 +1718,23 @@ static hipError_t skinny_launch_nw(const GemvArgs& a0, hipStream_t st) {
     const int steps = a.K / E / 4;
     if (groups && a.rg == 1 && cg_mode() >= 2 && steps % NW == 0 && !a.y_f32) {
       const int spw = steps / NW;
-#define SK_RING(SPW) (a.B <= 32 ? skinny_launch_cg<T, NW, SPW, false, false, 2, TR, false, 2>(a, grid, lds, st) \
-                                : skinny_launch_cg<T, NW, SPW, false, false, 4, TR, false, 2>(a, grid, lds, st))
+#define SK_RING(SPW, SP2) (a.B <= 32 ? skinny_launch_cg<T, NW, SPW, false, false, 2, TR, false, 2, SP2>(a, grid, lds, st) \
+                                     : skinny_launch_cg<T, NW, SPW, false, false, 4, TR, false, 2, SP2>(a, grid, lds, st))
       if constexpr (E == 8) {          // 16-bit contexts: K = 1280 / 5120
-        if (spw == 5) return SK_RING(5);
-        if (spw == 20) return SK_RING(20);
+        if (spw == 5 && !split2) return SK_RING(5, false);
+        if (spw == 20) return split2 ? SK_RING(20, true) : SK_RING(20, false);
       } else {                         // strict-f32 contexts
-        if (spw == 10) return SK_RING(10);
-        if (spw == 40) return SK_RING(40);
+        if (spw == 10 && !split2) return SK_RING(10, false);
+        if (spw == 40) return split2 ? SK_RING(40, true) : SK_RING(40, false);
       }
 #undef SK_RING
     }
+    if (split2) {   // other long K (e.g. ffn = 4096): rounds of 5 fragments, the slice's midpoint found per step
+      if (!groups || a.rg != 1) return hipErrorInvalidValue;
+      return skinny_launch_v<T, NW, 5, false, false, TR, true>(a, grid, lds, st);
+    }
+  } else if (split2) {
+    return hipErrorInvalidValue;
   }
   if constexpr (TR != 16) {
     if (a.rg > 1) return hipErrorInvalidValue;
@@ -1616,7 +1752,7 @@ static hipError_t skinny_launch_nw(const GemvArgs& a0, hipStream_t st) {
 
 // MXFP8 weights: 128-k steps; 2 steps per wavefront cover K = 1280 with 8 wavefronts, 3 cover K = 5120 with 16
 template <int NW, int TR>
-static hipError_t skinny_launch_w8(const GemvArgs& a0, hipStream_t st) {
+static hipError_t skinny_launch_w8(const GemvArgs& a0, hipStream_t st, bool split2 = false) {
   GemvArgs a = a0;
   if (a.K % 128 != 0 || a.B > 64) return hipErrorInvalidValue;
   const size_t lds = (size_t)NW * kRedTile * 4;
@@ -1630,7 +1766,17 @@ static hipError_t skinny_launch_w8(const GemvArgs& a0, hipStream_t st) {
   static const int max_blocks_groups = env_int("TW_SK_MAX_BLOCKS_W8_GROUPS", 160);
   a.rg = (tiles + (groups ? max_blocks_groups : max_blocks) - 1) / (groups ? max_blocks_groups : max_blocks);
   if (a.rg < 1 || steps_per_wave > (groups ? 2 : 3)) a.rg = 1;   // several tiles per workgroup only with one round per tile
+  static const int dbg_mask = env_int("TW_DBG_W8_MULTI_MASK", 7);   // diagnostics: bit 0 QKV, 1 fc1, 2 logits may walk several tiles per workgroup
+  if (groups && a.rg > 1 && !((a.kcache ? 1 : (a.gelu ? 2 : (a.y_f32 ? 4 : 0))) & dbg_mask)) a.rg = 1;
   dim3 grid((tiles + a.rg - 1) / a.rg);
+  if (split2) {   // W8A16 above 16 rows, long K: rounds of 2 steps, two accumulator sets (skinny_mfma_kernel's header)
+    if constexpr (NW != 8) {
+      return hipErrorInvalidValue;
+    } else {
+      if (!groups || !a.a16 || a.rg != 1) return hipErrorInvalidValue;
+      return skinny_launch_v<bf16_t, NW, 2, false, true, TR, true>(a, grid, lds, st);
+    }
+  }
   if constexpr (TR != 16) {
     if (a.rg > 1) return hipErrorInvalidValue;
     if (steps_per_wave <= 2 || groups) return skinny_launch_v<bf16_t, NW, 2, false, true, TR>(a, grid, lds, st);
@@ -1648,19 +1794,22 @@ static hipError_t skinny_launch_w8(const GemvArgs& a0, hipStream_t st) {
 template <typename T>
 static hipError_t skinny_launch(const GemvArgs& a, hipStream_t st) {
   static const int nw_big = env_int("TW_SK_NW_BIGK", 16);  // wavefronts per tile when K is long (fc2: K = 5120)
-  const bool big = a.K >= 4096 && nw_big == 16 && !a.ln_gw && !a.y_f32 && !a.kcache && !a.gelu && a.B <= 16;
+  // long-K residual projection: 16 wavefronts per tile with one group of streams, 8 (two accumulator sets: the same sixteen K slices,
+  // the same order of additions - skinny_mfma_kernel's header) with several
+  const bool longk = a.K >= 4096 && nw_big == 16 && !a.ln_gw && !a.y_f32 && !a.kcache && !a.gelu;
+  const bool big = longk && a.B <= 16, split2 = longk && a.B > 16;
   if (a.wscale) {
     if (ElemTraits<T>::kCode != 1) return hipErrorInvalidValue;
-    if (a.tr == 8) return big ? skinny_launch_w8<16, 8>(a, st) : skinny_launch_w8<8, 8>(a, st);
+    if (a.tr == 8) return big ? skinny_launch_w8<16, 8>(a, st) : skinny_launch_w8<8, 8>(a, st, split2);
     if (a.tr != 0 && a.tr != 16) return hipErrorInvalidValue;
-    return big ? skinny_launch_w8<16, 16>(a, st) : skinny_launch_w8<8, 16>(a, st);
+    return big ? skinny_launch_w8<16, 16>(a, st) : skinny_launch_w8<8, 16>(a, st, split2);
   }
   static const int nw_narrow = env_int("TW_SK_NW_NARROW", 8);  // wavefronts per 8-row tile of the N = 1280, K = 1280 projections (4: A/B)
-  if (a.tr == 8 && !big && nw_narrow == 4 && a.B <= 16) return skinny_launch_nw<T, 4, 8>(a, st);
-  if (a.tr == 8) return big ? skinny_launch_nw<T, 16, 8>(a, st) : skinny_launch_nw<T, 8, 8>(a, st);
-  if (a.tr == 4) return big ? skinny_launch_nw<T, 16, 4>(a, st) : skinny_launch_nw<T, 8, 4>(a, st);
+  if (a.tr == 8 && !longk && nw_narrow == 4 && a.B <= 16) return skinny_launch_nw<T, 4, 8>(a, st);
+  if (a.tr == 8) return big ? skinny_launch_nw<T, 16, 8>(a, st) : skinny_launch_nw<T, 8, 8>(a, st, split2);
+  if (a.tr == 4) return big ? skinny_launch_nw<T, 16, 4>(a, st) : skinny_launch_nw<T, 8, 4>(a, st, split2);
   if (a.tr != 0 && a.tr != 16) return hipErrorInvalidValue;
-  return big ? skinny_launch_nw<T, 16, 16>(a, st) : skinny_launch_nw<T, 8, 16>(a, st);
+  return big ? skinny_launch_nw<T, 16, 16>(a, st) : skinny_launch_nw<T, 8, 16>(a, st, split2);
 }
 
 template <typename T>
@@ -1747,6 +1896,22 @@ hipError_t launch_sampler(const SamplerArgs& a0, hipStream_t st) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(sampler_finish_kernel, dim3(1), dim3(1024), 0, st, a);  // also advances the position
+  return hipGetLastError();
+}
+
+hipError_t launch_sampler_rows(const SamplerArgs& a0, hipStream_t st) {
+  if (a0.B < 1 || a0.B > 64 || !a0.partials || !a0.suppress_bits || a0.rows_streams < 1 || a0.B % a0.rows_streams != 0 || !a0.row_lastts ||
+      !a0.row_choice || !a0.verify_state)
+    return hipErrorInvalidValue;
+  SamplerArgs a = a0;
+  a.n_slices = 32;    // the slicing of launch_sampler (the partial sums are merged in the same order: same bits)
+  a.x_next = nullptr;
+  static const int many = env_int("TW_SAMPLER_SLICES_MANY", 32);
+  if (many == 8) return hipErrorInvalidValue;   // (A/B switch of the step sampler: the two slicings sum in different orders)
+  hipLaunchKernelGGL((sampler_part_kernel<32, 4>), dim3(32, a.B), dim3(256), 0, st, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(sampler_rows_finish_kernel, dim3(1), dim3(1024), 0, st, a);
   return hipGetLastError();
 }
 

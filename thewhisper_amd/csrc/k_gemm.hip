@@ -44,7 +44,7 @@ __device__ __forceinline__ float gelu_exact(float x) {
   p = fmaf(t, p, 1.421413741f);
   p = fmaf(t, p, -0.284496736f);
   p = fmaf(t, p, 0.254829592f);
-  const float e = 1.0f - p * t * __expf(-az * az);
+  const float e = fmaf(-(p * t), __expf(-az * az), 1.0f);   // (spelled out: one rounding sequence in every instantiation)
   return 0.5f * x * (1.0f + copysignf(e, z));
 }
 
@@ -188,7 +188,8 @@ __device__ __forceinline__ void gemm_ln_publish(const GemmEpilogue& ep, int tid,
   s += __shfl_xor(s, 1);
   ss += __shfl_xor(ss, 1);
   const float mean = s * inv_k;
-  const float rstd = 1.0f / sqrtf(fmaxf(ss * inv_k - mean * mean, 0.f) + 1e-5f);
+  const float m2 = mean * mean;
+  const float rstd = 1.0f / sqrtf(fmaxf(fmaf(ss, inv_k, -m2), 0.f) + 1e-5f);   // (fused operations spelled out: tw_common.h, tw_ln_scalars)
   const int row = tid >> 1;
   if ((tid & 1) == 0 && row < BM) ln_rows[row] = f32x2_t{mean, rstd};
 }
@@ -223,9 +224,9 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[NT][MT], int 
     }
     long long roff = 0;
     if (res && row_ok) roff = rowmap(ep.res_map, ep.res_mod > 0 ? (m % ep.res_mod) : m);
-    float st_s[NT / 2 > 0 ? NT / 2 : 1], st_ss[NT / 2 > 0 ? NT / 2 : 1];   // producer side: per 32-column block (two 16-column tiles)
+    float st_s[NT], st_ss[NT];   // producer side: this lane's group of four columns of every 16-column tile (tw_stat4)
 #pragma unroll
-    for (int i = 0; i < (NT / 2 > 0 ? NT / 2 : 1); ++i) { st_s[i] = 0.f; st_ss[i] = 0.f; }
+    for (int i = 0; i < NT; ++i) { st_s[i] = 0.f; st_ss[i] = 0.f; }
 #pragma unroll
     for (int a = 0; a < NT; ++a) {
       const int n = n_base + a * 16 + fq * 4;
@@ -256,14 +257,8 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[NT][MT], int 
       Vec4<T> ov;
 #pragma unroll
       for (int r = 0; r < 4; ++r) ov.set(r, v[r]);
-      if (ep.stats_out) {   // statistics of the values AS STORED (rounded to T): what the consumer's matrix product sees
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float x = ok ? ov.get(r) : 0.f;
-          st_s[a / 2] += x;
-          st_ss[a / 2] = fmaf(x, x, st_ss[a / 2]);
-        }
-      }
+      if (ep.stats_out)    // statistics of the values AS STORED (rounded to T): what the consumer's matrix product sees
+        tw_stat4(ok ? ov.get(0) : 0.f, ok ? ov.get(1) : 0.f, ok ? ov.get(2) : 0.f, ok ? ov.get(3) : 0.f, st_s[a], st_ss[a]);
       if (!ok) continue;
       if (ep.mode == EPI_ROWMAJOR) {
         ov.store(reinterpret_cast<T*>(ep.out) + rowmap(ep.c_map, m) + n);
@@ -296,8 +291,10 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4_t (&acc)[NT][MT], int 
     if (ep.stats_out) {
       // the 32 columns of a block live in the 4 lanes fq = 0..3 of row fr (8 values each): two lane swaps, lane fq = 0 stores
 #pragma unroll
-      for (int i = 0; i < (NT / 2 > 0 ? NT / 2 : 1); ++i) {
-        const float s = tw_xor32_sum(tw_xor16_sum(st_s[i])), ss = tw_xor32_sum(tw_xor16_sum(st_ss[i]));
+      for (int i = 0; i < NT / 2; ++i) {
+        // the fixed tree of tw_stat4's note: the four groups of each tile over the lanes fq, then the two tiles of the block
+        const float s = tw_xor32_sum(tw_xor16_sum(st_s[2 * i])) + tw_xor32_sum(tw_xor16_sum(st_s[2 * i + 1]));
+        const float ss = tw_xor32_sum(tw_xor16_sum(st_ss[2 * i])) + tw_xor32_sum(tw_xor16_sum(st_ss[2 * i + 1]));
         const int nb = n_base + i * 32;
         if (fq == 0 && row_ok && nb < N)
           reinterpret_cast<f32x2_t*>(ep.stats_out)[(long long)m * (N / 32) + nb / 32] = f32x2_t{s, ss};
@@ -396,13 +393,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const f32x4_t (&acc)[NT][MT
 #pragma unroll
       for (int r = 0; r < 4; ++r) { o0.set(r, v[r]); o1.set(r, v[4 + r]); }
       if (ep.stats_out) {   // (sum, sum of squares) of the values AS STORED, per row and 32-column block: 4 lanes x 8 columns
-        float s = 0.f, ss = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float x0 = ok ? o0.get(r) : 0.f, x1 = ok ? o1.get(r) : 0.f;
-          s += x0 + x1;
-          ss = fmaf(x0, x0, fmaf(x1, x1, ss));
-        }
+        float sa, ssa, sb, ssb;   // groups 2j and 2j + 1 of the block (tw_stat4's note: the same tree as the plain epilogue)
+        tw_stat4(ok ? o0.get(0) : 0.f, ok ? o0.get(1) : 0.f, ok ? o0.get(2) : 0.f, ok ? o0.get(3) : 0.f, sa, ssa);
+        tw_stat4(ok ? o1.get(0) : 0.f, ok ? o1.get(1) : 0.f, ok ? o1.get(2) : 0.f, ok ? o1.get(3) : 0.f, sb, ssb);
+        float s = sa + sb, ss = ssa + ssb;
         s += __shfl_xor(s, 1);
         ss += __shfl_xor(ss, 1);
         s += __shfl_xor(s, 2);

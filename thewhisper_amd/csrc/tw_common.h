@@ -47,6 +47,26 @@ __device__ __forceinline__ float tw_xor32_sum(float v) { float a = v, b = v; tw_
 __device__ __forceinline__ float tw_xor16_max(float v) { float a = v, b = v; tw_swap16(a, b); return fmaxf(a, b); }
 __device__ __forceinline__ float tw_xor32_max(float v) { float a = v, b = v; tw_swap32(a, b); return fmaxf(a, b); }
 __device__ __forceinline__ float tw_wave_sum(float v) { return tw_xor32_sum(tw_xor16_sum(tw_row16_sum(v))); }
+
+// Folded-LayerNorm scalars and their application, with the fused operations spelled out.  Left to the compiler, `ss * inv_k - mean * mean`
+// becomes fma(ss, inv_k, -(mean * mean)) in one template instantiation and fma(-mean, mean, ss * inv_k) in another (seen in the ISA of the
+// one-tile and the several-tiles MXFP8 projection kernels, round 6): results a few float32 ulps apart, i.e. a stream's bits would depend
+// on which kernel flavour the number of rows in its launch selects.
+__device__ __forceinline__ void tw_ln_scalars(float s, float ss, float inv_k, float& mean, float& rstd) {
+  mean = s * inv_k;
+  const float m2 = mean * mean;
+  rstd = __frsqrt_rn(fmaxf(fmaf(ss, inv_k, -m2), 0.f) + 1e-5f);
+}
+// (sum, sum of squares) of four consecutive columns in ONE order.  The per-(row, 32-column block) statistics the encoder GEMMs leave for
+// the folded LayerNorm of their consumer are built from these by a fixed tree - ((P0 + P1) + (P2 + P3)) + ((P4 + P5) + (P6 + P7)) over the
+// block's eight groups of four columns - by BOTH epilogues of k_gemm.hip (a lane of the plain epilogue holds groups q and 4 + q, a lane
+// of the LDS-staged one groups 2j and 2j + 1): until round 6 the two summed in different orders, i.e. a clip's encoder states depended
+// on whether its pass was large enough for the large-M kernel (tools/dbg/batch_invariance.py).
+__device__ __forceinline__ void tw_stat4(float x0, float x1, float x2, float x3, float& s, float& ss) {
+  s = ((x0 + x1) + x2) + x3;
+  ss = fmaf(x3, x3, fmaf(x2, x2, fmaf(x1, x1, x0 * x0)));
+}
+__device__ __forceinline__ float tw_ln_apply(float v, float mean, float rstd, float gw, float cb) { return fmaf(rstd, fmaf(-mean, gw, v), cb); }
 __device__ __forceinline__ float tw_wave_max(float v) { return tw_xor32_max(tw_xor16_max(tw_row16_max(v))); }
 
 template <typename T> struct ElemTraits;
@@ -320,8 +340,21 @@ struct SamplerArgs {   // A10 + argmax + bookkeeping
   // writes the NEXT step's input row, tok_emb[token] + pos_emb[pos + 1], in the fragment-major activation layout (what launch_embed
   // would write at the start of that step: one launch per step less).  dtype = the context's element type code (0 f32, 1 bf16, 2 f16).
   const void* tok_emb; const void* pos_emb; void* x_next; int d; int dtype;
+  // Rows mode (draft-and-verify, api.hip: verify_round): the B rows of `logits` are rows_streams streams x B / rows_streams
+  // consecutive positions starting at row_pos0 (host-known), row r = stream r % rows_streams at position row_pos0 + r / rows_streams, and
+  // every row is sampled with the state the ordinary loop would have had at that position IF the given tokens (seq) are what it had
+  // produced so far: history = seq[stream][0 .. p], last timestamp token = row_lastts[r] (host-computed), nothing finished.
+  int rows_streams; int row_pos0;
+  const int* row_lastts;     // [B] per row: last timestamp token among the generated tokens at positions <= p (-1 none)
+  int* row_choice;           // [B] out: the token the loop would have produced at position p + 1
+  int row_last_pos;          // last position of the ROUND (a round may take several launches): rows at p < row_last_pos are compared with seq[p + 1]
+  int row_is_last;           // this launch ends the round: without a mismatch the round's result is the token after row_last_pos
+  int* verify_state;         // [2 + 64]: [0] = first position whose choice differs from the given next token (INT_MAX none; atomicMin),
+                             //           [1] = p_acc + 1 once the round is decided (else 0): the device position, [2 + b] = token at p_acc + 1
 };
 hipError_t launch_sampler(const SamplerArgs& a, hipStream_t st);   // sampler + pos advance
+// rows mode: sampler over every row + the round's decision (see SamplerArgs); the position is NOT advanced unless the round is decided
+hipError_t launch_sampler_rows(const SamplerArgs& a, hipStream_t st);
 hipError_t launch_suppress_bitmap(const int* list, int n, unsigned* bits, int V, hipStream_t st);  // zero + set bits
 hipError_t launch_advance(DecState* stt, int n, hipStream_t st);     // pos += n only (teacher-forced stepping, prefill)
 

@@ -332,9 +332,12 @@ class WhisperEngine:
         suppress: Iterable[int] = (),
         want_alignment: bool = False,
         n_forced: int = 0,
+        n_draft: int = 0,
     ) -> Dict[str, np.ndarray]:
         """``n_forced``: the last ``n_forced`` tokens of every prompt row are forced OUTPUT tokens (they count as generated; a
-        batched prefill processes them - tw_greedy_opts::n_forced); the returned sequences contain them like generated ones."""
+        batched prefill processes them - tw_greedy_opts::n_forced); the returned sequences contain them like generated ones.
+        ``n_draft``: the last ``n_draft`` tokens of every prompt row are GUESSES of the output (tw_greedy_opts::n_draft): verified in
+        batched launches, the call returns what it returns without them; ``draft`` in the result says how many were confirmed."""
         prompt = np.ascontiguousarray(prompt, dtype=np.int32)
         B, n0 = prompt.shape
         o = _cabi.tw_greedy_opts()
@@ -351,12 +354,13 @@ class WhisperEngine:
         o.n_suppress, o.suppress = len(sp), sp_arr
         o.want_alignment = 1 if want_alignment else 0
         o.n_forced = int(n_forced)
+        o.n_draft = int(n_draft)
         out = np.full((B, int(max_length)), pad_id, dtype=np.int32)
         out_len = C.c_int32(0)
         sp = self._sp()
         # (calls with a forced prefix stay on the caller's stream: their batched prefill - launches of up to 64 rows - wants the whole
         #  chip; measured on the reuse path's short calls: 16.1 ms per tick there, 19.9 on the 160-CU stream)
-        if self.raw_stream is None and int(n_forced) == 0:
+        if self.raw_stream is None and int(n_forced) == 0 and int(n_draft) == 0:
             ds = self._decode_stream()
             if ds is not None:      # behind everything enqueued so far (the encoder stage); the call synchronises it before returning
                 torch.cuda.ExternalStream(ds, device=self.device).wait_stream(torch.cuda.current_stream(self.device))
@@ -367,7 +371,12 @@ class WhisperEngine:
         self._chk(rc, "tw_generate_greedy")
         self._release_held()   # the call returns after synchronising its stream, which is ordered after the encoder stage
         L = int(out_len.value)
-        return {"sequences": out[:, :L].astype(np.int64), "length": L}
+        res = {"sequences": out[:, :L].astype(np.int64), "length": L}
+        if int(n_draft) > 0:
+            v = [C.c_int32(0) for _ in range(4)]
+            self._chk(self.lib.tw_last_draft(self.ctx, *[C.byref(x) for x in v]), "tw_last_draft")
+            res["draft"] = {"offered": int(v[0].value), "accepted": int(v[1].value), "launches": int(v[2].value), "rounds": int(v[3].value)}
+        return res
 
     # ---- A11 ---------------------------------------------------------------------------------
     def token_timestamps(self, B: int, n_prompt: int, seq_len: int, num_frames: Optional[Sequence[int]] = None,

@@ -333,8 +333,12 @@ class AMDWhisperForConditionalGeneration(WhisperForConditionalGeneration, _Engin
             B = int(input_features.shape[0])
             eng.encode(input_features)
             eng.cross_kv(B)
-        elif encoder_outputs is None:
-            raise NotImplementedError("forward() needs input_features")
+        else:
+            # the encoder states live inside the engine (A2-A5): a tensor of `encoder_outputs` cannot be handed to it, and decoding
+            # against whatever the engine encoded LAST would silently answer for other audio.  HF's own callers of this form
+            # (detect_language, HF:models/whisper/generation_whisper.py:1610-1683) pass input_features whenever they have them.
+            raise NotImplementedError("forward() needs input_features: the MI355X engine keeps the encoder states internally and "
+                                      "does not accept `encoder_outputs`")
         B = int(decoder_input_ids.shape[0])
         eng.decoder_reset(B)
         ids = decoder_input_ids.detach().to("cpu").numpy()

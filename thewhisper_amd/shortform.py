@@ -61,12 +61,16 @@ class ShortFormPlan:
 class ChunkWork:
     """Decoding state of one <= chunk_length_s piece of audio (one row of a ``generate`` batch)."""
 
-    __slots__ = ("feats", "num_frames", "max_frames", "seek", "segments", "passes", "tag", "forced", "first_pass")
+    __slots__ = ("feats", "num_frames", "max_frames", "seek", "segments", "passes", "tag", "forced", "draft", "draft_result", "first_pass")
 
     def __init__(self, feats: torch.Tensor, num_frames: Optional[int], tag: Any = None):
         # SURVEY.md section 8f-3 (opt-in, streaming.py): output tokens of the FIRST seek iteration that are already known - they
         # are handed to the greedy loop as forced output (batched prefill) and the loop decodes only what follows
         self.forced: Optional[np.ndarray] = None
+        # ... or GUESSED (tw_greedy_opts::n_draft): verified by the engine in batched launches, the iteration's result is what it is
+        # without them; ``draft_result`` = the engine's report (tokens offered / confirmed, launches, rounds)
+        self.draft: Optional[np.ndarray] = None
+        self.draft_result: Optional[Dict[str, int]] = None
         self.first_pass: Optional[Tuple[np.ndarray, np.ndarray]] = None   # (ids after the prompt, their timestamps) of iteration 1
         self.feats = feats                      # [n_mels, frames] log-mel (device tensor); frames = 2 * T for short-form
         self.num_frames = num_frames            # frames of real audio (attention_mask.sum), None if no mask was given
@@ -251,8 +255,22 @@ class Pass:
                 raise ValueError("a pass takes forced prefixes of ONE length")
             n_forced = lens.pop()
             prompt = np.concatenate([prompt, np.stack([np.asarray(w.forced, dtype=np.int32) for w in works])], axis=1)
+        n_draft = 0
+        if any(w.draft is not None and w.seek == 0 for w in works):
+            if n_forced:
+                raise ValueError("a pass takes forced prefixes OR drafts")
+            lens = {len(w.draft) if (w.draft is not None and w.seek == 0) else 0 for w in works}
+            if len(lens) != 1:
+                raise ValueError("a pass takes drafts of ONE length")
+            n_draft = lens.pop()
+            prompt = np.concatenate([prompt, np.stack([np.asarray(w.draft, dtype=np.int32) for w in works])], axis=1)
         t0 = time.perf_counter()
-        out = engine.generate_greedy(prompt, n_forced=n_forced, **plan.greedy) if n_forced else engine.generate_greedy(prompt, **plan.greedy)
+        if n_forced:
+            out = engine.generate_greedy(prompt, n_forced=n_forced, **plan.greedy)
+        elif n_draft:
+            out = engine.generate_greedy(prompt, n_draft=n_draft, **plan.greedy)
+        else:
+            out = engine.generate_greedy(prompt, **plan.greedy)
         self.greedy_s = time.perf_counter() - t0        # the engine call (blocks until the loop has finished); the rest of run() is host work
         self._keep.clear()
         seq = torch.from_numpy(np.ascontiguousarray(out["sequences"])).to(torch.long)
@@ -296,6 +314,9 @@ class Pass:
             w.segments += segments
             w.passes += 1
             w.forced = None        # a prefix is forced ONCE: a chunk whose seek stays at 0 decodes its next iteration afresh
+            if w.draft is not None:
+                w.draft_result = out.get("draft")
+                w.draft = None
 
 
 def next_segment(work: ChunkWork, T: int) -> torch.Tensor:

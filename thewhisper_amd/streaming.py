@@ -38,6 +38,7 @@ class AMDWhisperBackend:
         asr_pipeline=None,
         reuse_committed_prefix: bool = False,
         reuse_margin_s: float = 1.0,
+        draft_previous_tick: bool = False,
         **pipeline_kwargs,
     ):
         """``reuse_committed_prefix`` (never the default): the reference scheduler hands over, every 0.5 s,
@@ -51,7 +52,16 @@ class AMDWhisperBackend:
         The option needs ONE BACKEND PER STREAM (the state of the previous call lives in the backend): besides the start time and the
         length, a call must begin with exactly the samples of its predecessor's buffer to reuse anything - a backend shared between
         sessions (gateway._LockedBackend, two schedulers on one pipeline) therefore never forces tokens of other audio, it just
-        decodes afresh - and ``reset()`` (what a scheduler's ``clear()`` should call) forgets the previous call."""
+        decodes afresh - and ``reset()`` (what a scheduler's ``clear()`` should call) forgets the previous call.
+
+        ``draft_previous_tick`` (round 6): the EXACT form of the same idea.  The previous call's tokens - all of them, no margin -
+        are handed to the greedy loop as a DRAFT (tw_greedy_opts::n_draft): the engine runs prompt + draft through the decoder in
+        batched launches WITH the logits and Whisper's logits processors of every position, keeps the draft up to the first
+        position where its own arg-max differs, takes that arg-max, offers the rest of the draft again behind it and decodes
+        step by step from where nothing more is confirmed.  The call returns what the plain backend returns - same ids, same
+        word timestamps - whatever the draft was (a draft of other audio only costs time), so the eligibility test is a matter
+        of speed, not of correctness.  ``reuse_stats`` counts drafted and confirmed tokens.  Not together with
+        ``reuse_committed_prefix``."""
         from .asr_pipeline import ASRPipeline
 
         if torch_dtype is None:
@@ -72,9 +82,13 @@ class AMDWhisperBackend:
             revision=revision,
             **pipeline_kwargs,
         )
+        if reuse_committed_prefix and draft_previous_tick:
+            raise ValueError("reuse_committed_prefix (approximate) and draft_previous_tick (exact) are alternatives")
         self.reuse_committed_prefix = bool(reuse_committed_prefix)
+        self.draft_previous_tick = bool(draft_previous_tick)
         self.reuse_margin_s = float(reuse_margin_s)
-        self.reuse_stats = {"calls": 0, "reused": 0, "forced_tokens": 0, "decoded_tokens": 0}
+        self.reuse_stats = {"calls": 0, "reused": 0, "forced_tokens": 0, "decoded_tokens": 0, "draft_tokens": 0, "confirmed_tokens": 0,
+                            "verify_launches": 0}
         self._reuse_codec = None      # JobCodec (learned plan), built on the first reuse-enabled call
         self._last = None             # what the previous call left: start time, samples, first-iteration tokens + timestamps
 
@@ -82,7 +96,7 @@ class AMDWhisperBackend:
         return {"use_cache": True, "num_beams": 1, "do_sample": False, "max_new_tokens": 128, "language": self.language}
 
     def transcribe(self, audio: np.ndarray, buffer_start_time: float, sample_rate: int) -> List[Dict[str, Any]]:
-        if self.reuse_committed_prefix:
+        if self.reuse_committed_prefix or self.draft_previous_tick:
             words = self._transcribe_with_reuse(np.asarray(audio), float(buffer_start_time), int(sample_rate))
             if words is not None:
                 return words
@@ -115,7 +129,11 @@ class AMDWhisperBackend:
         if audio.dtype != prev.dtype or not np.array_equal(audio[: len(prev)], prev):
             return None
         ids, ts = last["ids"], last["ts"]
-        if ids is None or ts is None or len(ids) == 0:
+        if ids is None or len(ids) == 0:
+            return None
+        if self.draft_previous_tick:      # exact whatever is offered: everything the previous call produced
+            return np.asarray(ids, dtype=np.int32)
+        if ts is None:
             return None
         limit = last["n_samples"] / sample_rate - self.reuse_margin_s
         keep = 0
@@ -133,11 +151,12 @@ class AMDWhisperBackend:
         from . import shortform
 
         if self._reuse_codec is None:
-            self.reuse_committed_prefix = False           # (the plan is learned from one ORDINARY call of this backend)
+            mode = (self.reuse_committed_prefix, self.draft_previous_tick)
+            self.reuse_committed_prefix = self.draft_previous_tick = False   # (the plan is learned from one ORDINARY call of this backend)
             codec = self.job_codec()
             if codec is None or not codec.learn():
                 return None                               # not eligible on this pipeline: stays the plain backend
-            self.reuse_committed_prefix = True
+            self.reuse_committed_prefix, self.draft_previous_tick = mode
             self._reuse_codec = codec
         codec = self._reuse_codec
         self.reuse_stats["calls"] += 1
@@ -151,7 +170,13 @@ class AMDWhisperBackend:
             budget = int(codec.plan.greedy.get("max_new_tokens", 128))
             if forced is not None and len(forced) >= budget - 1:
                 forced = forced[: max(0, budget - 2)]
-            if forced is not None and len(forced) >= 2:
+            if forced is not None and self.draft_previous_tick:
+                if len(forced) >= 1:
+                    job.works[0].draft = forced
+                    self.reuse_stats["reused"] += 1
+                    self.reuse_stats["draft_tokens"] += int(len(forced))
+                forced = None
+            elif forced is not None and len(forced) >= 2:
                 job.works[0].forced = forced
                 self.reuse_stats["reused"] += 1
                 self.reuse_stats["forced_tokens"] += int(len(forced))
@@ -162,7 +187,11 @@ class AMDWhisperBackend:
                     raise RuntimeError(f"a chunk needed more than {shortform.MAX_SEEK_PASSES} seek passes")
         if len(job.works) == 1 and job.works[0].first_pass is not None:
             ids, ts = job.works[0].first_pass
-            self.reuse_stats["decoded_tokens"] += int(len(ids)) - (int(len(forced)) if forced is not None else 0)
+            dr = job.works[0].draft_result
+            if dr is not None:
+                self.reuse_stats["confirmed_tokens"] += int(dr["accepted"])
+                self.reuse_stats["verify_launches"] += int(dr["launches"])
+            self.reuse_stats["decoded_tokens"] += int(len(ids)) - (int(len(forced)) if forced is not None else 0) - (int(dr["accepted"]) if dr else 0)
             self._last = {"start": buffer_start_time, "n_samples": len(audio), "sr": sample_rate, "ids": ids, "ts": ts,
                           "audio": np.array(audio, copy=True)}
         return codec.close(job)
