@@ -199,7 +199,8 @@ def test_backend_with_drafts_reproduces_the_plain_backend_on_the_scheduler_seque
 
     gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "pipeline_golden.json")))["streaming_micro_c10"]
     audio = wo.synth_audio(16000 * gold["seconds"], gold["seed"], gold["kind"])
-    plain = AMDWhisperBackend(None, chunk_length_s=10, asr_pipeline=build_amd_pipeline("micro", 10, 1, device="cuda", engine_factory=None))
+    plain = AMDWhisperBackend(None, chunk_length_s=10, asr_pipeline=build_amd_pipeline("micro", 10, 1, device="cuda", engine_factory=None),
+                              draft_previous_tick=False)
     draft = AMDWhisperBackend(None, chunk_length_s=10, asr_pipeline=build_amd_pipeline("micro", 10, 1, device="cuda", engine_factory=None),
                               draft_previous_tick=True)
     for c in gold["calls"]:

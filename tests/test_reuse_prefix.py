@@ -26,7 +26,8 @@ def backends(device="cpu", engine_factory="oracle"):
     from thewhisper_amd import AMDWhisperBackend
 
     ef = oracle_engine_factory if engine_factory == "oracle" else None
-    plain = AMDWhisperBackend(None, chunk_length_s=10, asr_pipeline=build_amd_pipeline("micro", 10, 1, device=device, engine_factory=ef))
+    plain = AMDWhisperBackend(None, chunk_length_s=10, asr_pipeline=build_amd_pipeline("micro", 10, 1, device=device, engine_factory=ef),
+                              draft_previous_tick=False)
     reuse = AMDWhisperBackend(None, chunk_length_s=10, asr_pipeline=build_amd_pipeline("micro", 10, 1, device=device, engine_factory=ef),
                               reuse_committed_prefix=True, reuse_margin_s=1.0)
     return plain, reuse
@@ -130,7 +131,8 @@ def draft_backends(device="cpu", engine_factory="oracle"):
     from thewhisper_amd import AMDWhisperBackend
 
     ef = oracle_engine_factory if engine_factory == "oracle" else None
-    plain = AMDWhisperBackend(None, chunk_length_s=10, asr_pipeline=build_amd_pipeline("micro", 10, 1, device=device, engine_factory=ef))
+    plain = AMDWhisperBackend(None, chunk_length_s=10, asr_pipeline=build_amd_pipeline("micro", 10, 1, device=device, engine_factory=ef),
+                              draft_previous_tick=False)
     draft = AMDWhisperBackend(None, chunk_length_s=10, asr_pipeline=build_amd_pipeline("micro", 10, 1, device=device, engine_factory=ef),
                               draft_previous_tick=True)
     return plain, draft

@@ -162,7 +162,7 @@ def test_continuous_hub_fills_passes_across_requests_and_answers_early():
     from thewhisper_amd.serving import BatchingHub
 
     pipe = build(batch_size=4, chunk_s=30)
-    backend = AMDWhisperBackend(None, chunk_length_s=30, asr_pipeline=pipe)
+    backend = AMDWhisperBackend(None, chunk_length_s=30, asr_pipeline=pipe, draft_previous_tick=False)   # (engine calls are counted below)
     backend._generate_kwargs = lambda: {"use_cache": True, "num_beams": 1, "do_sample": False, "max_new_tokens": 24, "language": "en"}
     lens = [480000, 336000, 160000, 475679, 240000, 480000]
     bufs = [(wo.synth_audio(n, 40 + i, ["speechlike", "noise", "sine", "speechlike", "zeros", "noise"][i]), 1.5 * i, 16000)
@@ -204,7 +204,7 @@ def test_hub_prefetches_the_encoder_stage_of_arrivals_during_a_pass():
     from thewhisper_amd.serving import BatchingHub
 
     pipe = build(batch_size=4, chunk_s=30)
-    backend = AMDWhisperBackend(None, chunk_length_s=30, asr_pipeline=pipe)
+    backend = AMDWhisperBackend(None, chunk_length_s=30, asr_pipeline=pipe, draft_previous_tick=False)   # (engine calls are counted below)
     backend._generate_kwargs = lambda: {"use_cache": True, "num_beams": 1, "do_sample": False, "max_new_tokens": 24, "language": "en"}
     lens = [480000, 336000, 160000, 475679, 240000, 480000, 400000]
     bufs = [(wo.synth_audio(n, 40 + i, ["speechlike", "noise", "sine", "speechlike", "zeros", "noise", "sine"][i]), 1.5 * i, 16000)
@@ -243,7 +243,7 @@ def test_hub_encodes_the_rows_that_sit_a_pass_out_on_the_side():
     from thewhisper_amd.serving import BatchingHub
 
     pipe = build(batch_size=4, chunk_s=30)
-    backend = AMDWhisperBackend(None, chunk_length_s=30, asr_pipeline=pipe)
+    backend = AMDWhisperBackend(None, chunk_length_s=30, asr_pipeline=pipe, draft_previous_tick=False)   # (engine calls are counted below)
     backend._generate_kwargs = lambda: {"use_cache": True, "num_beams": 1, "do_sample": False, "max_new_tokens": 24, "language": "en"}
     lens = [480000, 336000, 475679, 240000, 480000, 400000]
     bufs = [(wo.synth_audio(n, 60 + i, ["speechlike", "noise", "speechlike", "sine", "noise", "speechlike"][i]), 0.5 * i, 16000)

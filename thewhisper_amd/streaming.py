@@ -38,7 +38,7 @@ class AMDWhisperBackend:
         asr_pipeline=None,
         reuse_committed_prefix: bool = False,
         reuse_margin_s: float = 1.0,
-        draft_previous_tick: bool = False,
+        draft_previous_tick: Optional[bool] = None,
         **pipeline_kwargs,
     ):
         """``reuse_committed_prefix`` (never the default): the reference scheduler hands over, every 0.5 s,
@@ -61,7 +61,9 @@ class AMDWhisperBackend:
         step by step from where nothing more is confirmed.  The call returns what the plain backend returns - same ids, same
         word timestamps - whatever the draft was (a draft of other audio only costs time), so the eligibility test is a matter
         of speed, not of correctness.  ``reuse_stats`` counts drafted and confirmed tokens.  Not together with
-        ``reuse_committed_prefix``."""
+        ``reuse_committed_prefix``.  Because the result is the plain call's, this is ON by default (``None`` = on unless
+        ``reuse_committed_prefix`` was asked for); ``False`` gives the reference's behaviour literally - every tick decoded from
+        scratch (R:thestage_speechkit/streaming/streaming_pipeline.py:388-435)."""
         from .asr_pipeline import ASRPipeline
 
         if torch_dtype is None:
@@ -82,6 +84,8 @@ class AMDWhisperBackend:
             revision=revision,
             **pipeline_kwargs,
         )
+        if draft_previous_tick is None:
+            draft_previous_tick = not reuse_committed_prefix
         if reuse_committed_prefix and draft_previous_tick:
             raise ValueError("reuse_committed_prefix (approximate) and draft_previous_tick (exact) are alternatives")
         self.reuse_committed_prefix = bool(reuse_committed_prefix)
@@ -151,12 +155,10 @@ class AMDWhisperBackend:
         from . import shortform
 
         if self._reuse_codec is None:
-            mode = (self.reuse_committed_prefix, self.draft_previous_tick)
-            self.reuse_committed_prefix = self.draft_previous_tick = False   # (the plan is learned from one ORDINARY call of this backend)
             codec = self.job_codec()
-            if codec is None or not codec.learn():
+            if codec is None or not codec.learn():        # (the plan is learned from one ORDINARY call of this backend: JobCodec.learn)
+                self.reuse_committed_prefix = self.draft_previous_tick = False
                 return None                               # not eligible on this pipeline: stays the plain backend
-            self.reuse_committed_prefix, self.draft_previous_tick = mode
             self._reuse_codec = codec
         codec = self._reuse_codec
         self.reuse_stats["calls"] += 1
@@ -283,7 +285,13 @@ class JobCodec:
         the model object records the short-form plan (model.py).  False if the call turned out not to be eligible."""
         model = self.pipe.model
         model.last_plan = None
-        self.backend.transcribe(np.zeros(self.backend.sample_rate, dtype=np.float32), 0.0, self.backend.sample_rate)
+        b = self.backend
+        mode = (b.reuse_committed_prefix, b.draft_previous_tick)     # (the ORDINARY call: the reuse / draft paths bypass HF's generate)
+        b.reuse_committed_prefix = b.draft_previous_tick = False
+        try:
+            b.transcribe(np.zeros(b.sample_rate, dtype=np.float32), 0.0, b.sample_rate)
+        finally:
+            b.reuse_committed_prefix, b.draft_previous_tick = mode
         plan = model.last_plan
         if plan is None or not plan.return_token_timestamps or not plan.return_segments:
             return False
