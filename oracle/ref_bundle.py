@@ -74,14 +74,29 @@ def reference_dir() -> Optional[str]:
     if not os.path.isfile(BUNDLE):
         return None
     digest = hashlib.sha256(open(BUNDLE, "rb").read()).hexdigest()[:12]
-    dst = os.path.join(tempfile.gettempdir(), f"tw_reference_{digest}")
-    if not _has_package(dst):
+    # (round-5 advice) a predictable name under a world-writable directory is only trusted when it is a directory THIS user owns and
+    # nobody else can write to; anything else is ignored and the bundle is unpacked into a fresh private directory (mkdtemp: 0700)
+    dst = os.path.join(tempfile.gettempdir(), f"tw_reference_{digest}_{os.getuid()}")
+
+    def _mine(d):
+        try:
+            st = os.stat(d)
+        except OSError:
+            return False
+        return st.st_uid == os.getuid() and not (st.st_mode & 0o022)
+
+    if not (_mine(dst) and _has_package(dst)):
         tmp = tempfile.mkdtemp(prefix="tw_reference_", dir=tempfile.gettempdir())
         with tarfile.open(BUNDLE, "r:gz") as tar:
             for m in tar.getmembers():      # plain relative file members only
                 if not m.isfile() or m.name.startswith("/") or ".." in m.name.split("/"):
                     raise RuntimeError(f"unexpected member in {BUNDLE}: {m.name}")
-            tar.extractall(tmp)
+            try:
+                tar.extractall(tmp, filter="data")
+            except TypeError:               # (Python < 3.10.12 without the extraction filters)
+                tar.extractall(tmp)
+        if os.path.lexists(dst) and not _mine(dst):
+            return tmp if _has_package(tmp) else None     # somebody else's directory sits on the name: use the private copy
         try:
             os.rename(tmp, dst)
         except OSError:                     # another process unpacked it meanwhile

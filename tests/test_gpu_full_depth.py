@@ -183,7 +183,7 @@ def check_timestamps(z, eng, ts, streams, dtype, n_rows, bounds, dump=None, ctrl
     return rep, problems
 
 
-def run_case(name, dtype, logit_tol, enc_tol, top_abs, ts_bounds, check_ids=True, margin_mult=4.0):
+def run_case(name, dtype, logit_tol, enc_tol, top_abs, ts_bounds, check_ids=True, margin_mult=4.0, min_argmax_agreement=None):
     """Shared body: returns a dict of measured deviations (printed, asserted against the stated bounds)."""
     z, dims, w, pcm, heads = load_case(name)
     T, B = 50 * int(z["chunk_s"]), pcm.shape[0]
@@ -329,6 +329,12 @@ def run_case(name, dtype, logit_tol, enc_tol, top_abs, ts_bounds, check_ids=True
             if slice_worst[0] > 4 * logit_tol:     # rounding noise adds up like a random walk under the random signs: ~ the rel-L2 itself
                 problems.append(f"a vocabulary slice's random-sign projection is off by {slice_worst[0]:.4f} of the slice norm (> {4 * logit_tol})")
         rep["top1_rule_binds_on_frac_of_steps"] = round(bound_steps[0] / max(1, bound_steps[1]), 3)
+        # id-level statement that CAN fail whatever the margins are (round-5 advice, for the flavour whose top-1 rule is switched off):
+        # the share of teacher-forced steps (both passes) whose arg-max is the fp32 reference's
+        n_flip = len(rep["greedy_path_subm_flips"]) + len(rep["rand_path_subm_flips"]) + len(top1_bad)
+        rep["argmax_agreement_frac"] = round(1.0 - n_flip / max(1, bound_steps[1]), 4)
+        if min_argmax_agreement is not None and rep["argmax_agreement_frac"] < min_argmax_agreement:
+            problems.append(f"arg-max identical to fp32 on only {rep['argmax_agreement_frac']:.3f} of the teacher-forced steps (< {min_argmax_agreement})")
         if top1_bad:
             problems.append(f"top-1 differs above the margin bound at (stream, step, margin) {top1_bad[:8]}")
         if not (rep["greedy_path_logits_rel_l2"] < logit_tol and rep["rand_path_logits_rel_l2"] < logit_tol):
@@ -421,7 +427,9 @@ F16 = dict(logit_tol=5e-3, enc_tol=4e-3, top_abs=0.02, ts_bounds=dict(surface_re
 # (0.0806), surface rel-L2 (0.399 -> 0.396) and path excess (0.157 -> 0.166) stayed where they were: with 40 % error on the alignment
 # surface the DTW path is decided by noise.  The floor is kept only as a sanity bound (0.15); the bounds that hold the flavour are the
 # logits / top-8 / surface / excess ones.  (W8A16, the flavour that ships, moved 0.50 -> see profiles/r06_gpu_tests_full_depth.log.)
-FP8A8 = dict(logit_tol=0.108, enc_tol=3e-2, top_abs=0.5, margin_mult=float("inf"), ts_bounds=dict(surface_rel=0.5, excess_frac=0.2, within_1_frame=0.15))
+# (round 6) ... and an id-level floor that does not depend on margins: arg-max identical to fp32 on >= 85 % of all teacher-forced steps
+# (measured 0.93-0.97 in rounds 5 / 6; an arg-max regression of the W8A8 path now fails the suite)
+FP8A8 = dict(logit_tol=0.108, enc_tol=3e-2, top_abs=0.5, margin_mult=float("inf"), min_argmax_agreement=0.85, ts_bounds=dict(surface_rel=0.5, excess_frac=0.2, within_1_frame=0.15))
 FP8A16 = dict(logit_tol=0.083, enc_tol=3e-2, top_abs=0.27, margin_mult=2.0, ts_bounds=dict(surface_rel=0.2, excess_frac=0.0175, within_1_frame=0.4))
 
 

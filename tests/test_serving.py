@@ -379,12 +379,13 @@ def test_prefetcher_take_skips_rows_of_failed_requests():
     from thewhisper_amd.serving import _Prefetcher
 
     pf = _Prefetcher.__new__(_Prefetcher)
-    pf.lock, pf.dead, pf.ahead, pf.count = threading.Lock(), set(), [], 5
+    pf.lock, pf.dead, pf.ahead, pf.count = threading.Lock(), [], [], 5
     w = [object() for _ in range(5)]
     pf.pre = collections.deque((w[i], i, f"seg{i}") for i in range(5))
     pf.ahead = [w[4], object()]
-    pf.drop({id(w[0]), id(w[2]), id(w[4])})
-    assert len(pf.ahead) == 1
+    gone = object()                              # a chunk of a failed request that is not with the prefetcher: nothing to remember
+    pf.drop([w[0], w[2], w[4], gone])            # (round-5 advice: the work OBJECTS, not ids - ids of freed works are reused)
+    assert len(pf.ahead) == 1 and len(pf.dead) == 3 and not any(x is gone for x in pf.dead)
     works, slot0, keep = pf.take(4)
     assert works == [w[1]] and slot0 == 1 and keep == ["seg1"]    # the run of consecutive slots ends in front of a dead row
     works, slot0, _ = pf.take(4)

@@ -78,7 +78,8 @@ class _Prefetcher:
         self.stop = False
         self.pre: "collections.deque" = collections.deque()    # (work, side slot, segment tensor), slot order
         self.ahead: List[Any] = []            # chunks of requests in flight that sit the running pass out: encoded first, in one call
-        self.dead: set = set()                # ids of pre-encoded chunks whose request has failed (drop)
+        self.dead: List[Any] = []             # pre-encoded chunks whose request has failed (drop): the OBJECTS, compared with `is` -
+                                              # ids of freed works are reused by CPython and would discard a live chunk's row
         self.new_jobs: List[Any] = []
         self.count = 0                        # filled slots of the sibling context
         self.thread = threading.Thread(target=self._run, name="thewhisper-prefetch", daemon=True)
@@ -102,10 +103,11 @@ class _Prefetcher:
         """Up to `free` pre-encoded rows from the front (consecutive sibling slots): ([works], first slot, [tensors to keep])."""
         works, keep, slot0 = [], [], None
         while self.pre and len(works) < free:
-            if id(self.pre[0][0]) in self.dead:     # a chunk of a request that has failed meanwhile (drop): nobody waits for it
+            if any(self.pre[0][0] is w for w in self.dead):   # a chunk of a request that has failed meanwhile (drop): nobody waits for it
                 if works:
                     break                           # ... and the run of CONSECUTIVE slots ends in front of it
-                self.pre.popleft()
+                gone = self.pre.popleft()[0]
+                self.dead = [w for w in self.dead if w is not gone]
                 continue
             w, slot, seg = self.pre.popleft()
             if slot0 is None:
@@ -117,12 +119,14 @@ class _Prefetcher:
             self.dead.clear()
         return works, slot0, keep
 
-    def drop(self, dead_ids):
+    def drop(self, dead_works):
         """(batcher thread, prefetcher paused)  Forget the chunks of failed requests: not encoded ahead any more, and their
-        pre-encoded rows are skipped by `take` (their sibling slots stay unused until the queue has drained)."""
+        pre-encoded rows are skipped by `take` (their sibling slots stay unused until the queue has drained).  Under the lock a chunk
+        is in `ahead`, in `pre` or not with the prefetcher at all (`_encode_ahead` moves it under the same lock), so only those in `pre`
+        need remembering - as OBJECTS (no id of a freed work can match a live one), each forgotten when `take` pops it."""
         with self.lock:       # (the prefetcher may be running: a failed pass.run() is reported after resume())
-            self.ahead = [w for w in self.ahead if id(w) not in dead_ids]
-            self.dead |= set(dead_ids)
+            self.ahead = [w for w in self.ahead if not any(w is x for x in dead_works)]
+            self.dead += [w for (w, _slot, _seg) in self.pre if any(w is x for x in dead_works) and not any(w is x for x in self.dead)]
 
     def shutdown(self):
         self.stop = True
@@ -438,8 +442,7 @@ class BatchingHub:
             if pf is not None and hit:
                 # their other chunks must not be adopted or encoded ahead any more: the futures are answered, the rows would only
                 # occupy later passes (and a chunk of a dead job that exceeds MAX_SEEK_PASSES would fail the LIVE jobs of its pass)
-                dead = set(id(w) for j in hit for w in j.works)
-                pf.drop(dead)
+                pf.drop([w for j in hit for w in j.works])
 
         def shutdown():
             if pf is not None:
