@@ -36,7 +36,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 (cd $ROOT && python tools/pmc_step_traffic.py $(find /tmp/prof_FETCH_SIZE -name "*counter_collection.csv" | head -1) \
    $(find /tmp/prof_WRITE_SIZE -name "*counter_collection.csv" | head -1) \
-   '{"model": "large-v3", "streams": 16, "chunk_s": 10, "dtype": "bf16", "new_tokens": 128}' > $OUT/${R}_pmc_step_traffic.json)
+   '{"model": "large-v3", "streams": 16, "chunk_s": 10, "dtype": "f16", "new_tokens": 128}' > $OUT/${R}_pmc_step_traffic.json)   # (bench.py's default dtype since round 6)
 d=/tmp/prof_mfma; rm -rf $d
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $d -o p -- python $ROOT/bench.py $PMCARGS --new-tokens 8 > /dev/null 2> $OUT/${R}_pmc_mfma.err
 c=$(find $d -name "*counter_collection.csv" | head -1)
