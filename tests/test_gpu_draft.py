@@ -213,3 +213,66 @@ def test_backend_with_drafts_reproduces_the_plain_backend_on_the_scheduler_seque
     print(f"\nDRAFT (MI355X, micro model, golden stream): {st['reused']} of {st['calls']} calls offered a draft, {st['draft_tokens']} tokens offered, "
           f"{st['confirmed_tokens']} confirmed, {st['verify_launches']} verify launches")
     assert st["reused"] >= 1 and st["draft_tokens"] > 0
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_config3_trace_at_the_real_width_draft_ids_equal_plain_ids(dtype):
+    """BASELINE config 3's call pattern (tests/golden/config3_trace.json: the rolling buffers the REFERENCE'S scheduler hands its
+    backend for a 60 s stream, R:thestage_speechkit/streaming/streaming_pipeline.py:388-435, :770-796) at whisper-large-v3's width
+    (d = 1280, ffn = 5120, 20 heads, full vocabulary; 2 + 2 layers so that the case takes seconds): the first 60 calls through the
+    plain backend and through `draft_previous_tick=True` on the same engine - the token ids the engine decoded (every seek pass,
+    before tokenizer / filter / merge) are IDENTICAL call by call, the words too, and drafts were offered and confirmed.  What
+    bench.py reports for the full depth (`config3.with_draft_previous_tick.token_identity_mean` = 1.0) is asserted here."""
+    import json
+    import os
+
+    import bench
+    from thewhisper_amd import AMDWhisperBackend, ASRPipeline, synthetic
+    from thewhisper_amd.engine import WhisperEngine
+    from transformers import WhisperFeatureExtractor
+
+    dims = dict(bench.DIMS["large-v3"], enc_layers=2, dec_layers=2)
+    heads = [(1, 0), (1, 3)]
+    trace = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config3_trace.json")))
+    chunk_s = trace["chunk_length_s"]
+    tdt = {"f16": torch.float16, "bf16": torch.bfloat16}[dtype]
+    eng = WhisperEngine(dims, 50 * chunk_s, max_batch=1, dtype=dtype, alignment_heads=heads, use_graph=True)
+    try:
+        eng.load_state_dict(bench.random_state_dict(dims, torch.device("cuda", 0), seed=0))
+        model = synthetic.skeleton_model(dims, device="cuda:0", dtype=tdt, alignment_heads=heads)
+        pipe = ASRPipeline(model, feature_extractor=WhisperFeatureExtractor(feature_size=dims["n_mels"], chunk_length=chunk_s),
+                           tokenizer=synthetic.build_tokenizer(dims["vocab"]), chunk_length_s=chunk_s, device="cuda:0", torch_dtype=tdt,
+                           batch_size=1, engine=eng)
+        stream = (np.random.default_rng(trace["seed"]).standard_normal(16000 * trace["seconds"]) * 0.1).clip(-1, 1).astype(np.float32)
+        seen = []
+        inner = eng.generate_greedy
+
+        def recording(prompt, **kw):
+            out = inner(prompt, **kw)
+            for row in out["sequences"][:, 3:]:
+                hit = np.nonzero(row == int(kw.get("eos_id", 50257)))[0]
+                seen.append(np.asarray(row[: int(hit[0])] if len(hit) else row, dtype=np.int64))
+            return out
+
+        eng.generate_greedy = recording
+        got = {}
+        for variant in ("plain", "draft"):
+            be = AMDWhisperBackend(None, chunk_length_s=chunk_s, asr_pipeline=pipe, draft_previous_tick=(variant == "draft"))
+            be.transcribe(stream[:16000], 0.0, 16000)      # plan learning outside the compared calls
+            be.reset()
+            ids, words = [], []
+            for c in trace["calls"][:60]:
+                seen.clear()
+                words.append(be.transcribe(stream[c["offset"] : c["offset"] + c["n"]], c["t0"], 16000))
+                ids.append(np.concatenate(seen) if seen else np.zeros(0, np.int64))
+            got[variant] = (ids, words, dict(be.reuse_stats))
+        for i, (a, b) in enumerate(zip(got["plain"][0], got["draft"][0])):
+            assert len(a) == len(b) and (a == b).all(), f"{dtype}: call {i} of the trace decodes other ids with a draft"
+        assert got["plain"][1] == got["draft"][1]
+        st = got["draft"][2]
+        print(f"\nCONFIG3 {dtype} (large-v3 width, 2 + 2 layers, 60 calls): {st['reused']} calls offered a draft, {st['draft_tokens']} tokens offered, "
+              f"{st['confirmed_tokens']} confirmed, {st['verify_launches']} verify launches; ids identical on every call")
+        assert st["reused"] >= 30 and st["confirmed_tokens"] > 0
+    finally:
+        eng.generate_greedy = inner
+        eng.close()
