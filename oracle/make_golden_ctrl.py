@@ -42,6 +42,7 @@ CTRL = {
     "full_large-v3_c10": [0, 1],
     "full_large-v3_c10_b16": [0, 1, 2, 3],
     "full_large-v3_c15": [0],
+    "full_large-v3_c20": [0, 1],
     "full_large-v3_c15_b4": [0, 1, 2, 3],
     "full_turbo_c30": [0],
 }

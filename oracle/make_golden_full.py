@@ -10,6 +10,7 @@ are consumed, so only small outputs are stored under tests/golden/full_*.npz):
   full_large-v3_c10    whisper-large-v3   32+32 layers, 10 s chunks (T = 500), 2 clips     (BASELINE configs 3/4)
   full_turbo_c30       large-v3-turbo     32+4  layers, 30 s chunk  (T = 1500), 1 clip     (BASELINE config 2)
   full_large-v3_c15    whisper-large-v3   32+32 layers, 15 s chunks (T = 750), 1 clip      (BASELINE config 5)
+  full_large-v3_c20    whisper-large-v3   32+32 layers, 20 s chunks (T = 1000), 2 clips    (the fourth chunk length the reference advertises)
   full_large-v3_c10_b16  whisper-large-v3 32+32 layers, 10 s chunks, **16 clips, 160 new tokens** (the batch and the length
                        bench.py times: configs[3]'s per-GPU share; reaches the 128- / 192-key self-attention variants)
   full_large-v3_c15_b4   whisper-large-v3 32+32 layers, 15 s chunks, 4 clips, 128 new tokens (config 5 at the length its
@@ -43,6 +44,8 @@ CASES = {
     "full_large-v3_c10": ("large-v3", 10, [("speechlike", 21), ("noise", 22)], 0, 32),
     "full_turbo_c30": ("large-v3-turbo", 30, [("speechlike", 23)], 0, 32),
     "full_large-v3_c15": ("large-v3", 15, [("speechlike", 24)], 0, 32),
+    # 20 s chunks (T = 1000; R:README.md:49 advertises 10 / 15 / 20 / 30 s engines): round 6
+    "full_large-v3_c20": ("large-v3", 20, [("speechlike", 25), ("noise", 26)], 0, 32),
     "full_large-v3_c10_b16": ("large-v3", 10, [(("speechlike", "noise", "sine", "speechlike")[i % 4], 100 + i) for i in range(16)], 0, 160),
     # BASELINE config 5 at the shape its driver-timed leg runs (15 s chunks, 128 new tokens): 4 clips, one of each audio kind
     "full_large-v3_c15_b4": ("large-v3", 15, [(("speechlike", "noise", "sine", "speechlike")[i % 4], 200 + i) for i in range(4)], 0, 128),

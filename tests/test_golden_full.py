@@ -9,7 +9,7 @@ from oracle import whisper_oracle as wo
 from tests.util import rel_l2
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-NAMES = ["full_large-v3_c10", "full_turbo_c30", "full_large-v3_c15", "full_large-v3_c10_b16"]
+NAMES = ["full_large-v3_c10", "full_turbo_c30", "full_large-v3_c15", "full_large-v3_c10_b16", "full_large-v3_c20"]
 
 
 @pytest.mark.parametrize("name", NAMES)

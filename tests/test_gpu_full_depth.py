@@ -5,6 +5,7 @@ by oracle/make_golden_full.py at the true model sizes with the oracle's seeded w
   full_large-v3_c10   large-v3 32+32 layers, T = 500   (configs 3/4)      bf16 + strict f32
   full_turbo_c30      turbo 32+4 layers,    T = 1500   (config 2)         bf16 (+ f32: two-pass 1500-key cross attention)
   full_large-v3_c15   large-v3 32+32 layers, T = 750   (config 5)         bf16 + the fp8 context (ids, timestamps, logits)
+  full_large-v3_c20   large-v3 32+32 layers, T = 1000  (20 s chunks)      bf16 + f16 + strict f32
   full_large-v3_c10_b16  large-v3, T = 500, 16 clips x 160 new tokens (what bench.py times)   bf16 + strict f32
 
 Tolerances (stated once; measured values are printed by the tests and recorded in DESIGN.md section 2):
@@ -440,6 +441,8 @@ CASES = [("full_turbo_c30", "bf16"), ("full_turbo_c30", "f16"), ("full_turbo_c30
          ("full_large-v3_c10_b16", "bf16"), ("full_large-v3_c10_b16", "f16"), ("full_large-v3_c10_b16", "f32"),
          ("full_large-v3_c15", "bf16"), ("full_large-v3_c15", "f16"),
          ("full_large-v3_c15", "fp8a8"), ("full_large-v3_c15", "fp8a16"),
+         # 20 s chunks (T = 1000: 15 full 64-key tiles + 40, the two-chunk cross attention): the fourth length the reference advertises
+         ("full_large-v3_c20", "bf16"), ("full_large-v3_c20", "f16"), ("full_large-v3_c20", "f32"),
          # config 5 at the length its driver-timed leg decodes: 4 clips x 128 new tokens at 15 s
          ("full_large-v3_c15_b4", "bf16"), ("full_large-v3_c15_b4", "fp8a8"), ("full_large-v3_c15_b4", "fp8a16")]
 
