@@ -215,11 +215,12 @@ def test_backend_with_drafts_reproduces_the_plain_backend_on_the_scheduler_seque
     assert st["reused"] >= 1 and st["draft_tokens"] > 0
 
 
-@pytest.mark.parametrize("dtype", ["f16", "bf16"])
-def test_config3_trace_at_the_real_width_draft_ids_equal_plain_ids(dtype):
+@pytest.mark.parametrize("dtype,layers,n_calls", [("f16", 2, 60), ("bf16", 2, 60), ("f16", 32, 30)])
+def test_config3_trace_at_the_real_width_draft_ids_equal_plain_ids(dtype, layers, n_calls):
     """BASELINE config 3's call pattern (tests/golden/config3_trace.json: the rolling buffers the REFERENCE'S scheduler hands its
     backend for a 60 s stream, R:thestage_speechkit/streaming/streaming_pipeline.py:388-435, :770-796) at whisper-large-v3's width
-    (d = 1280, ffn = 5120, 20 heads, full vocabulary; 2 + 2 layers so that the case takes seconds): the first 60 calls through the
+    (d = 1280, ffn = 5120, 20 heads, full vocabulary; 2 + 2 layers so that the case takes seconds, and the first 30 calls at the
+    FULL 32 + 32 layers in float16): the first calls of the trace through the
     plain backend and through `draft_previous_tick=True` on the same engine - the token ids the engine decoded (every seek pass,
     before tokenizer / filter / merge) are IDENTICAL call by call, the words too, and drafts were offered and confirmed.  What
     bench.py reports for the full depth (`config3.with_draft_previous_tick.token_identity_mean` = 1.0) is asserted here."""
@@ -231,8 +232,8 @@ def test_config3_trace_at_the_real_width_draft_ids_equal_plain_ids(dtype):
     from thewhisper_amd.engine import WhisperEngine
     from transformers import WhisperFeatureExtractor
 
-    dims = dict(bench.DIMS["large-v3"], enc_layers=2, dec_layers=2)
-    heads = [(1, 0), (1, 3)]
+    dims = dict(bench.DIMS["large-v3"], enc_layers=layers, dec_layers=layers)
+    heads = [(layers - 1, 0), (layers - 1, 3)]
     trace = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "config3_trace.json")))
     chunk_s = trace["chunk_length_s"]
     tdt = {"f16": torch.float16, "bf16": torch.bfloat16}[dtype]
@@ -261,7 +262,7 @@ def test_config3_trace_at_the_real_width_draft_ids_equal_plain_ids(dtype):
             be.transcribe(stream[:16000], 0.0, 16000)      # plan learning outside the compared calls
             be.reset()
             ids, words = [], []
-            for c in trace["calls"][:60]:
+            for c in trace["calls"][:n_calls]:
                 seen.clear()
                 words.append(be.transcribe(stream[c["offset"] : c["offset"] + c["n"]], c["t0"], 16000))
                 ids.append(np.concatenate(seen) if seen else np.zeros(0, np.int64))
@@ -270,9 +271,9 @@ def test_config3_trace_at_the_real_width_draft_ids_equal_plain_ids(dtype):
             assert len(a) == len(b) and (a == b).all(), f"{dtype}: call {i} of the trace decodes other ids with a draft"
         assert got["plain"][1] == got["draft"][1]
         st = got["draft"][2]
-        print(f"\nCONFIG3 {dtype} (large-v3 width, 2 + 2 layers, 60 calls): {st['reused']} calls offered a draft, {st['draft_tokens']} tokens offered, "
+        print(f"\nCONFIG3 {dtype} (large-v3 width, {layers} + {layers} layers, {n_calls} calls): {st['reused']} calls offered a draft, {st['draft_tokens']} tokens offered, "
               f"{st['confirmed_tokens']} confirmed, {st['verify_launches']} verify launches; ids identical on every call")
-        assert st["reused"] >= 30 and st["confirmed_tokens"] > 0
+        assert st["reused"] >= n_calls // 2 and st["confirmed_tokens"] > 0
     finally:
         eng.generate_greedy = inner
         eng.close()
