@@ -277,3 +277,61 @@ def test_config3_trace_at_the_real_width_draft_ids_equal_plain_ids(dtype, layers
     finally:
         eng.generate_greedy = inner
         eng.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16", "fp8a16", "fp8a8"])
+def test_draft_fuzz_random_drafts_never_change_the_result(dtype):
+    """Property test of `n_draft` on the micro model: 60 random situations per dtype - 1 ... 16 streams, 6 ... 90 new tokens, fixed or
+    free length (<eos> allowed early), timestamp grammar on or off, a suppress list or none, drafts of random length whose tokens are
+    corrupted at a random rate (0 = the true continuation ... 1 = rubbish, sometimes in one stream only) - and in every one of them the
+    call returns the plain call's ids, length, alignment rows and token timestamps; graph replay on and off."""
+    dims = wo.PRESETS["micro"]
+    w = wo.make_weights(dims, 0)
+    heads = [(1, 0), (1, 1)]
+    T = 100
+    rng = np.random.default_rng({"f32": 1, "bf16": 2, "f16": 3, "fp8a16": 4, "fp8a8": 5}[dtype])
+    engines = {g: make_engine(dims, w, T=T, max_batch=16, dtype=dtype, heads=heads, use_graph=g) for g in (True, False)}
+    try:
+        pcm = clips(T * 320, 16)
+        n_engaged = 0
+        for case in range(60):
+            eng = engines[bool(case % 2)]
+            B = int(rng.choice([1, 1, 2, 3, 5, 16]))
+            sel = rng.permutation(16)[:B]
+            mel = eng.logmel(torch.from_numpy(pcm[sel]).cuda(), out_dtype=torch.float32)
+            eng.encode(mel); eng.cross_kv(B)
+            max_new = int(rng.integers(6, 91))
+            ts_on = bool(rng.integers(0, 2))
+            kw = dict(max_new_tokens=max_new, min_new_tokens=max_new if rng.integers(0, 2) else 0, timestamps=ts_on, want_alignment=True)
+            if rng.integers(0, 3) == 0:
+                kw["suppress"] = tuple(int(x) for x in rng.integers(0, 50000, size=20))
+            prompt = np.tile(np.array(PROMPT if ts_on else PROMPT + [50364], dtype=np.int32), (B, 1))
+            n0 = prompt.shape[1]
+            full = eng.generate_greedy(prompt, **kw)
+            L, seq = full["length"], full["sequences"]
+            al = eng.get_alignment(B, L - 1)
+            ts = eng.token_timestamps(B, n0, L, [2 * T] * B)
+            gen = seq[:, n0:]
+            n_ok = int(min([np.nonzero(r == 50257)[0][0] if (r == 50257).any() else len(r) for r in gen]))
+            n_ok = min(n_ok, max_new - 2)
+            if n_ok < 1:
+                continue
+            nd = int(rng.integers(1, n_ok + 1))
+            draft = gen[:, :nd].copy().astype(np.int32)
+            rate = float(rng.choice([0.0, 0.0, 0.03, 0.15, 0.5, 1.0]))
+            rows = range(B) if rng.integers(0, 2) else [int(rng.integers(0, B))]
+            for b in rows:
+                for j in range(nd):
+                    if rng.random() < rate:
+                        draft[b, j] = int(rng.integers(0, 50000))
+            draft = np.where(draft == 50257, 0, draft).astype(np.int32)
+            out = eng.generate_greedy(np.concatenate([prompt, draft], axis=1), n_draft=nd, **kw)
+            what = f"{dtype} case {case}: B={B} max_new={max_new} ts={ts_on} nd={nd} rate={rate} graph={bool(case % 2)}"
+            assert out["length"] == L and np.array_equal(out["sequences"], seq), what
+            assert np.array_equal(eng.get_alignment(B, L - 1), al), what
+            assert np.array_equal(eng.token_timestamps(B, n0, L, [2 * T] * B), ts), what
+            n_engaged += 1
+        assert n_engaged >= 40
+    finally:
+        for e in engines.values():
+            e.close()
