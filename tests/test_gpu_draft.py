@@ -335,3 +335,40 @@ def test_draft_fuzz_random_drafts_never_change_the_result(dtype):
     finally:
         for e in engines.values():
             e.close()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_batch_composition_fuzz_at_the_real_width(dtype):
+    """Property form of "who else is in the batch does not matter" (large-v3 width, 1 + 2 layers, T = 500 so that a 16-clip pass reaches
+    the large-M encoder kernel): 12 random passes - 1 ... 40 clips drawn at random, in random slots - and in every one of them each
+    clip's encoder states and teacher-forced logits are bit for bit those of the clip alone."""
+    dims = dims_variant("large-v3", enc_layers=1, dec_layers=2)
+    w = wo.make_weights(dims, 2)
+    T, N = 500, 40
+    eng = make_engine(dims, w, T=T, max_batch=N, dtype=dtype, heads=[(1, 0)], use_graph=False)
+    try:
+        mel = eng.logmel(torch.from_numpy(clips(T * 320, N)).cuda())
+        ids = PROMPT + [4242, 99]
+        rng = np.random.default_rng(7)
+
+        def run(sel):
+            B = len(sel)
+            enc = eng.encode(mel[torch.as_tensor(sel)], return_hidden=True).float().cpu().numpy()
+            eng.cross_kv(B); eng.decoder_reset(B)
+            lg = np.stack([eng.decode_step([int(t)] * B).cpu().numpy() for t in ids], axis=1)
+            return enc, lg
+
+        alone = {}
+        for case in range(12):
+            B = int(rng.choice([1, 2, 3, 7, 15, 16, 17, 31, 33, 40]))
+            sel = rng.permutation(N)[:B].tolist()
+            enc, lg = run(sel)
+            for slot in {0, B - 1, int(rng.integers(0, B))}:
+                c = sel[slot]
+                if c not in alone:
+                    alone[c] = run([c])
+                    enc, lg = run(sel)      # (the one-clip pass overwrote the context)
+                assert np.array_equal(enc[slot], alone[c][0][0]), f"{dtype}: clip {c} in slot {slot} of a {B}-clip pass: encoder states differ"
+                assert np.array_equal(lg[slot], alone[c][1][0]), f"{dtype}: clip {c} in slot {slot} of a {B}-clip pass: logits differ"
+    finally:
+        eng.close()
