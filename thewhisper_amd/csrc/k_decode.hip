@@ -365,10 +365,17 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
   // MODE (several groups of streams only; picked by the launcher): 0 = rounds of SK_MAXS fragments, 2 = operand rings over the
   // wavefront's whole K slice (TW_CG_RING above; SK_MAXS = the slice's step count).  (1 - rounds with the next round's weights
   // requested a round ahead - was measured in round 5 and dropped: fc2 at 64 streams 12.1 -> 12.6 us, profiles/r05_projection_probe.txt)
-  constexpr bool RING = CG > 1 && TW_CG_RING && !MULTI && !W8 && MODE == 2;
+  constexpr bool RING = CG > 1 && TW_CG_RING && !W8 && MODE == 2;
+  // RING with MULTI = DUAL (round 5's "two tiles per workgroup", back in round 6): the workgroup contracts TWO weight tiles (tile0,
+  // tile0 + 1; the launcher sets RG = 2) against ONE sweep of the activation rings - half the activation (L2) traffic of two workgroups,
+  // 160 instead of 320 workgroups for the 5120-row launches (QKV, fc1).  Round 5 removed it because stream 63 of 64 decoded other ids
+  // than stream 0 on the same audio; the cause was not in this structure but in the LayerNorm variance, which hipcc fused differently
+  // for the two stream groups an epilogue thread finishes (profiles/r06_mode3_root_cause.txt) - spelled out now (tw_ln_scalars).
+  constexpr bool DUAL = RING && MULTI;
   constexpr int DW = RING ? (SK_MAXS < 5 ? SK_MAXS : 5) : 1;   // ring depths (steps)
   constexpr int DX = RING ? (SK_MAXS < 3 ? SK_MAXS : 3) : 1;
   u32x4_t rw[DW], rx[DX][CG];
+  u32x4_t rw2[DUAL ? DW : 1];
   // several groups: the two 256-thread halves of the workgroup take alternate groups in the epilogue (TW_CG_EPI_ALL)
   constexpr bool EALL = CG > 1 && TW_CG_EPI_ALL && NW >= 8;
   constexpr int GPT = EALL ? CG / 2 : CG;     // groups per epilogue thread
@@ -495,8 +502,8 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
     }
   };
 
-  auto ring_w = [&](int step) -> u32x4_t {   // one weight fragment of this workgroup's tile (RING: every step is inside the matrix)
-    const int tl = min(tile0, n_tiles - 1);
+  auto ring_w = [&](int step, int tile_ofs = 0) -> u32x4_t {   // one weight fragment of this workgroup's tile (RING: every step is inside the matrix)
+    const int tl = min(tile0 + tile_ofs, n_tiles - 1);
     if constexpr (TR == 16) {
       return sk_load_w<T>(W + ((long long)tl * S * 64 + lane) * E + (long long)step * (64 * E));
     } else {
@@ -511,7 +518,10 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
   if constexpr (RING) {
     // HBM first, then the first DX steps of activations in consumption order; everything else is requested as registers free up
 #pragma unroll
-    for (int i = 0; i < DW; ++i) rw[i] = ring_w(s_lo + i);
+    for (int i = 0; i < DW; ++i) {
+      rw[i] = ring_w(s_lo + i);
+      if constexpr (DUAL) rw2[i] = ring_w(s_lo + i, 1);
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < DX; ++i)
@@ -548,6 +558,7 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
 #pragma unroll
   for (int g = 0; g < GPT; ++g) { mean[g] = 0.f; rstd[g] = 1.f; }
   const int n_grp = MULTI ? RG : 1;
+  f32x4_t accd[DUAL ? CG : 1];   // DUAL: the second tile's accumulators, filled together with the first tile's
   for (int grp = 0; grp < n_grp; ++grp) {
     const int tile = tile0 + grp;
     f32x4_t acc[CG], acc2[SPLIT2 ? CG : 1];   // acc2: the second half of the wavefront's K slice (SPLIT2, see the kernel's header)
@@ -616,25 +627,37 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
     };
     if constexpr (RING) {
       static_assert(!SPLIT2 || SK_MAXS % 2 == 0, "SPLIT2 rings: the slice's midpoint is a step boundary");
+      static_assert(!(SPLIT2 && DUAL), "SPLIT2 is the long-K residual projection, DUAL the 5120-row launches");
+      if (!DUAL || grp == 0) {
 #pragma unroll
-      for (int i = 0; i < SK_MAXS; ++i) {
+        for (int g = 0; g < (DUAL ? CG : 1); ++g) accd[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int g = 0; g < CG; ++g) {
-          const u32x4_t xv = rx[i % DX][g];
-          if (LN) sk_stats<T>(xv, ps[g], pss[g]);
-          if constexpr (SPLIT2) {   // (compile-time: S = NW * SK_MAXS, so s_mid = s_lo + SK_MAXS / 2)
-            if (i >= SK_MAXS / 2) acc2[g] = sk_mfma<T>(rw[i % DW], xv, acc2[g]);
-            else acc[g] = sk_mfma<T>(rw[i % DW], xv, acc[g]);
-          } else {
-            acc[g] = sk_mfma<T>(rw[i % DW], xv, acc[g]);
+        for (int i = 0; i < SK_MAXS; ++i) {
+#pragma unroll
+          for (int g = 0; g < CG; ++g) {
+            const u32x4_t xv = rx[i % DX][g];
+            if (LN) sk_stats<T>(xv, ps[g], pss[g]);
+            if constexpr (SPLIT2) {   // (compile-time: S = NW * SK_MAXS, so s_mid = s_lo + SK_MAXS / 2)
+              if (i >= SK_MAXS / 2) acc2[g] = sk_mfma<T>(rw[i % DW], xv, acc2[g]);
+              else acc[g] = sk_mfma<T>(rw[i % DW], xv, acc[g]);
+            } else {
+              acc[g] = sk_mfma<T>(rw[i % DW], xv, acc[g]);
+              if constexpr (DUAL) accd[g] = sk_mfma<T>(rw2[i % DW], xv, accd[g]);
+            }
           }
-        }
-        if (i + DX < SK_MAXS) {
+          if (i + DX < SK_MAXS) {
 #pragma unroll
-          for (int g = 0; g < CG; ++g) rx[i % DX][g] = ring_x(g, s_lo + i + DX);
+            for (int g = 0; g < CG; ++g) rx[i % DX][g] = ring_x(g, s_lo + i + DX);
+          }
+          if (i + DW < SK_MAXS) {
+            rw[i % DW] = ring_w(s_lo + i + DW);
+            if constexpr (DUAL) rw2[i % DW] = ring_w(s_lo + i + DW, 1);
+          }
+          __builtin_amdgcn_sched_barrier(0);   // keep the software pipeline in this order
         }
-        if (i + DW < SK_MAXS) rw[i % DW] = ring_w(s_lo + i + DW);
-        __builtin_amdgcn_sched_barrier(0);   // keep the software pipeline in this order
+      } else {   // DUAL, second tile: contracted together with the first (same K slices, same order: bit-identical to a tile of its own)
+#pragma unroll
+        for (int g = 0; g < (DUAL ? CG : 1); ++g) acc[g] = accd[g];
       }
     } else {
     mfma_round(s_lo);  // operands already in flight
@@ -657,7 +680,7 @@ void skinny_mfma_kernel(const void* x_arg, const void* w_arg, int k_arg, int b_a
     for (int g = 0; g < GPT; ++g) n_res[g] = 0.f;
     if (MULTI) {
       const int nt = min(tile + 1, n_tiles - 1);
-      load_w(nt, s_lo);
+      if constexpr (!RING) load_w(nt, s_lo);
       load_epi(nt, n_c, n_gw, n_res);
     }
     TW_TS(2);
@@ -1605,7 +1628,7 @@ static int env_int(const char* name, int dflt) {
 // how launches for more than 16 streams move their operands (skinny_mfma_kernel's MODE): 2 = operand rings where the shape allows
 // (default), 0 = plain rounds (rounds 3-4); TW_SK_CG_MODE for A/B runs
 static int cg_mode() {
-  static const int m = env_int("TW_SK_CG_MODE", 2);
+  static const int m = env_int("TW_SK_CG_MODE", 3);   // 3 = 2 + two tiles per workgroup (DUAL) for the launches with more tiles than TW_SK_RING_BLOCKS
   return m;
 }
 
@@ -1714,18 +1737,27 @@ static hipError_t skinny_launch_nw(const GemvArgs& a0, hipStream_t st, bool spli
   if (a.rg < 1 || steps_per_wave > (groups ? 5 : 10)) a.rg = 1;  // several tiles per workgroup only with one round per tile
   dim3 grid((tiles + a.rg - 1) / a.rg);
   if constexpr (NW == 8) {
-    // more than 16 streams, one tile per workgroup, K an exact multiple of the wavefronts' step: operand rings (skinny_mfma_kernel MODE 2)
+    // more than 16 streams, K an exact multiple of the wavefronts' step: operand rings (skinny_mfma_kernel MODE 2), one tile per
+    // workgroup - or, for the launches with more 16-row tiles than the decode loop has compute units (QKV, fc1: 320 on 160 CUs),
+    // TWO tiles per workgroup contracted against one sweep of the activation rings (DUAL: half the activation traffic)
     const int steps = a.K / E / 4;
+    static const int ring_blocks = env_int("TW_SK_RING_BLOCKS", 160);
     if (groups && a.rg == 1 && cg_mode() >= 2 && steps % NW == 0 && !a.y_f32) {
       const int spw = steps / NW;
-#define SK_RING(SPW, SP2) (a.B <= 32 ? skinny_launch_cg<T, NW, SPW, false, false, 2, TR, false, 2, SP2>(a, grid, lds, st) \
-                                     : skinny_launch_cg<T, NW, SPW, false, false, 4, TR, false, 2, SP2>(a, grid, lds, st))
+      bool dual = false;
+      if constexpr (TR == 16)
+        dual = cg_mode() >= 3 && !split2 && (a.kcache || a.gelu) && ring_blocks > 0 && tiles > ring_blocks && tiles <= 2 * ring_blocks && tiles % 2 == 0 && spw == (E == 8 ? 5 : 10);   // (exactly the shapes instantiated below)
+      if (dual) { a.rg = 2; grid = dim3(tiles / 2); }
+#define SK_RING(SPW, SP2, MU) (a.B <= 32 ? skinny_launch_cg<T, NW, SPW, MU, false, 2, TR, false, 2, SP2>(a, grid, lds, st) \
+                                         : skinny_launch_cg<T, NW, SPW, MU, false, 4, TR, false, 2, SP2>(a, grid, lds, st))
       if constexpr (E == 8) {          // 16-bit contexts: K = 1280 / 5120
-        if (spw == 5 && !split2) return SK_RING(5, false);
-        if (spw == 20) return split2 ? SK_RING(20, true) : SK_RING(20, false);
+        if constexpr (TR == 16) { if (dual && spw == 5) return SK_RING(5, false, true); }
+        if (spw == 5 && !split2) return SK_RING(5, false, false);
+        if (spw == 20) return split2 ? SK_RING(20, true, false) : SK_RING(20, false, false);
       } else {                         // strict-f32 contexts
-        if (spw == 10 && !split2) return SK_RING(10, false);
-        if (spw == 40) return split2 ? SK_RING(40, true) : SK_RING(40, false);
+        if constexpr (TR == 16) { if (dual && spw == 10) return SK_RING(10, false, true); }
+        if (spw == 10 && !split2) return SK_RING(10, false, false);
+        if (spw == 40) return split2 ? SK_RING(40, true, false) : SK_RING(40, false, false);
       }
 #undef SK_RING
     }
